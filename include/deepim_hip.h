@@ -1,0 +1,236 @@
+/*
+ * deepim_hip.h — C ABI of libdeepim_hip.so, the MI355X (gfx950) implementation of
+ * mx-DeepIM's render-and-compare inner loop.
+ *
+ * Boundary rules
+ *   - plain C linkage, plain pointers and sizes, no torch / MXNet types;
+ *   - every `deepim_*` entry returns 0 on success, non-zero on failure
+ *     (`deepim_last_error()` gives the HIP error text); nothing prints-and-continues
+ *     the way the reference's CUDA wrapper does (lib/flow_c/gpu_flow_kernel.cu:18-25);
+ *   - "d_" / unprefixed tensor pointers are DEVICE pointers obtained from
+ *     deepim_malloc(); tensors are dense NCHW float32 unless stated;
+ *   - all work is enqueued on the context's HIP stream and is asynchronous;
+ *     deepim_sync() / the d2h copy are the synchronisation points.
+ *
+ * Each entry cites the reference interface it replaces (path:line under the
+ * reference checkout).
+ */
+#ifndef DEEPIM_HIP_H_
+#define DEEPIM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct deepim_ctx deepim_ctx;
+
+/* ---------------------------------------------------------------- runtime -- */
+/* replaces `mx.gpu(i)` contexts + MXNet NDArray storage (deepim/core/tester.py:27-47) */
+int deepim_create(int device_id, deepim_ctx** out);
+int deepim_destroy(deepim_ctx* ctx);
+const char* deepim_last_error(void);
+int deepim_device_count(int* n);
+int deepim_malloc(deepim_ctx* ctx, size_t bytes, void** dptr);
+int deepim_free(deepim_ctx* ctx, void* dptr);
+int deepim_memset(deepim_ctx* ctx, void* dptr, int value, size_t bytes);
+int deepim_h2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* sync */
+int deepim_d2h(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* sync */
+int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* async */
+int deepim_sync(deepim_ctx* ctx);
+/* strided channel-slice copy: dst[b, dst_coff:dst_coff+C, :] = src[b, :, :] (MXNet Concat, async) */
+int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff,
+                         const float* src, int C, int B, size_t hw);
+void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
+/* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
+int deepim_timer_create(deepim_ctx* ctx, int* timer_id);
+int deepim_timer_start(deepim_ctx* ctx, int timer_id);
+int deepim_timer_stop(deepim_ctx* ctx, int timer_id);
+int deepim_timer_elapsed_ms(deepim_ctx* ctx, int timer_id, float* ms);  /* syncs on stop event */
+/* hipGraph capture of a launch sequence on the context stream */
+int deepim_graph_begin(deepim_ctx* ctx);
+int deepim_graph_end(deepim_ctx* ctx, int* graph_id);
+int deepim_graph_launch(deepim_ctx* ctx, int graph_id);
+
+/* ------------------------------------------------ F-group: depth warp / flow -- */
+/* B2 drop-in. Same symbol, argument list and host-pointer contract as
+ * lib/flow_c/gpu_flow.hpp:1-3 (`_flow`, defined gpu_flow_kernel.cu:82-148):
+ * all pointers are HOST float32, caller-owned, synchronous. Unlike the
+ * reference it aborts via deepim_last_error + stderr + nonzero `deepim_flow_status()`
+ * when HIP fails. */
+void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt,
+           float* KT, float* Kinv, int batch_size, int height, int width,
+           int device_id);
+int deepim_flow_status(void);
+/* device-pointer variant of the same kernel (gpu_flow_kernel.cu:32-69) */
+int deepim_flow_forward(deepim_ctx* ctx, float* flow, float* valid,
+                        const float* depth_src, const float* depth_tgt,
+                        const float* KT /*B,3,4 device*/, const float* Kinv_host /*3,3 HOST*/,
+                        int B, int H, int W);
+/* lib/pair_matching/flow.py:12-63 `calc_flow` semantics (un-rounded bounds test
+ * is on rounded coords, valid needs depth_src != 0 and |d_tgt| > 1e-10);
+ * KT = K·se3 (B,3,4), Kinv (3,3); flow channel order [dh,dw] unless standard_rep */
+int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow /*B,H,W,2*/, float* visible /*B,H,W*/,
+                             const float* depth_src, const float* depth_tgt,
+                             const float* KT, const float* Kinv_host, float thresh,
+                             int standard_rep, int B, int H, int W);
+/* deepim/operator_py/flow_updater.py:42-102 `FlowUpdater` forward: integer flow
+ * from rounded+clamped coords; pose_src/pose_tgt (B,3,4); K, Kinv host 3x3 */
+int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow /*B,2,H,W*/, float* flow_weights /*B,2,H,W*/,
+                                const float* depth_src, const float* depth_tgt,
+                                const float* pose_src, const float* pose_tgt,
+                                const float* K_host, float thresh, int wh_rep,
+                                int B, int H, int W);
+/* batch_updater_py_multi.py:255-265: KT = K·(pose_tgt ∘ pose_src⁻¹) and
+ * mask_rendered = depth_rendered > 0.2 */
+int deepim_calc_KT(deepim_ctx* ctx, float* KT /*B,3,4*/, const float* pose_src,
+                   const float* pose_tgt, const float* K_host, int B);
+int deepim_depth_to_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n);
+
+/* --------------------------------------------------- Z-group: zoom / warp -- */
+/* zoom_mask.py:29-112 `ZoomMaskOperator.forward`.
+ * K_host: 3x3 float32 (host). Outputs are rounded resampled masks + zoom_factor (B,4). */
+int deepim_zoom_mask_forward(deepim_ctx* ctx,
+                             const float* mask_observed, const float* mask_gt_observed,
+                             const float* mask_rendered, const float* src_pose /*B,3,4*/,
+                             const float* K_host,
+                             float* zoom_mask_observed, float* zoom_mask_gt_observed,
+                             float* zoom_mask_rendered, float* zoom_factor /*B,4*/,
+                             int B, int H, int W);
+/* zoom_image.py:26-107 `ZoomImageOperator.forward` (no-mask variant). pixel_means_host: 3 floats
+ * in the channel order of the image tensor. */
+int deepim_zoom_image_forward(deepim_ctx* ctx,
+                              const float* image_observed, const float* image_rendered,
+                              const float* src_pose, const float* K_host,
+                              const float* pixel_means_host,
+                              float* zoom_image_observed, float* zoom_image_rendered,
+                              float* zoom_factor, int B, int H, int W);
+/* zoom_image_with_factor.py:31-65 */
+int deepim_zoom_image_with_factor_forward(deepim_ctx* ctx, const float* zoom_factor,
+                                          const float* image_observed, const float* image_rendered,
+                                          const float* pixel_means_host, int high_light_center,
+                                          float* zoom_image_observed, float* zoom_image_rendered,
+                                          int B, int H, int W);
+/* zoom_depth.py:24-44 */
+int deepim_zoom_depth_forward(deepim_ctx* ctx, const float* zoom_factor,
+                              const float* depth_observed, const float* depth_rendered,
+                              float* zoom_depth_observed, float* zoom_depth_rendered,
+                              int B, int H, int W);
+/* zoom_flow.py:28-71; flow_weights/zoom_flow_weights may be NULL when b_inv_zoom */
+int deepim_zoom_flow_forward(deepim_ctx* ctx, const float* zoom_factor, const float* flow,
+                             const float* flow_weights, float* zoom_flow, float* zoom_flow_weights,
+                             int b_inv_zoom, int B, int H, int W);
+/* zoom_mask_with_factor.py:29-64 */
+int deepim_zoom_mask_with_factor_forward(deepim_ctx* ctx, const float* zoom_factor, const float* mask,
+                                         float* zoom_mask, int b_inv_zoom, int B, int H, int W);
+/* zoom_trans.py:22-46 forward, :48-74 backward */
+int deepim_zoom_trans_forward(deepim_ctx* ctx, const float* zoom_factor, const float* trans_delta,
+                              float* zoom_trans_delta, int b_inv_zoom, int B);
+int deepim_zoom_trans_backward(deepim_ctx* ctx, const float* zoom_factor, const float* out_grad,
+                               float* in_grad, int b_inv_zoom, int b_zoom_grad, int B);
+/* Fused front end of the test graph (deepIM_flownet.py:33-62 + :563-622): ZoomMask +
+ * ZoomImageWithFactor [+ ZoomDepth] + `/255` + Concat written straight into the
+ * conv1 input (B,C,H,W), C = 8 (6 when masks_in_net==0, +2 with depth). Also returns zoom_factor.
+ * depth_* may be NULL. */
+int deepim_zoom_concat_forward(deepim_ctx* ctx,
+                               const float* image_observed, const float* image_rendered,
+                               const float* mask_observed, const float* mask_rendered,
+                               const float* depth_observed, const float* depth_rendered,
+                               const float* src_pose, const float* K_host,
+                               const float* pixel_means_host,
+                               float* net_input, float* zoom_factor,
+                               int B, int H, int W);
+/* debug/parity hook: the int32 source indices (x0,y0 = floor of the sampling
+ * position) the resampler uses for every output pixel: idx (B,2,H,W) int32 */
+int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W);
+/* sticky status of the zoom-factor computations since the last read (reading clears it):
+ * bit0 = an observed mask/image had no valid pixel — the reference raises ValueError there
+ * (np.min of an empty array, zoom_mask.py:55); the zoom factor is NaN for that sample */
+int deepim_zoom_status(deepim_ctx* ctx, int* status);
+
+/* ------------------------------------------ N-group: matching network ops -- */
+/* MXNet Convolution (+bias) [+LeakyReLU slope] (deepIM_flownet.py:63-107,123,145,176,317).
+ * `packed_w` comes from deepim_conv_pack_weights (one-time re-layout of the
+ * (Cout,Cin,kh,kw) tensor into MFMA tile order; size from deepim_conv_packed_size).
+ * slope == 1.0f means "no activation". out may have more channels than Cout
+ * (out_ctotal, written at channel offset out_coff) so Concat is free. */
+size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw);
+int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,kh,kw dev*/,
+                             int Cout, int Cin, int kh, int kw);
+int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                          const float* bias, int B, int Cin, int H, int W, int Cout,
+                          int kh, int kw, int stride, int pad, float slope,
+                          int out_ctotal, int out_coff);
+/* MXNet Deconvolution k4 s2 p0 (+bias) + Crop(offset 1,1 → Ho,Wo) [+LeakyReLU]
+ * (deepIM_flownet.py:127-143,149-165). w layout (Cin,Cout,4,4). */
+size_t deepim_deconv_packed_size(int Cin, int Cout);
+int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cin, int Cout);
+int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                                    const float* bias, int B, int Cin, int H, int W, int Cout,
+                                    int Ho, int Wo, int crop_y, int crop_x, float slope,
+                                    int out_ctotal, int out_coff);
+/* grouped (depthwise) Deconvolution k32 s16 no-bias + Crop(offset) to (Ho,Wo), times `scale`
+ * (deepIM_flownet.py:185-200,326-340,636-648,687-702). w (C,1,32,32). */
+int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const float* in, const float* w,
+                                   int B, int C, int H, int W, int Ho, int Wo,
+                                   int crop_y, int crop_x, float scale);
+/* FullyConnected y = x·Wᵀ + b [+LeakyReLU] (deepIM_flownet.py:112-116,211-215) */
+int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, const float* w /*O,I*/,
+                      const float* bias, int B, int I, int O, float slope);
+/* fc7-input → rot(4), trans(3) FCs + ZoomTrans(inverse) + Concat → se3 (B,7)
+ * (deepIM_flownet.py:715-726) */
+int deepim_pose_head_forward(deepim_ctx* ctx, float* se3 /*B,7*/, const float* feat /*B,F*/,
+                             const float* w_rot, const float* b_rot,
+                             const float* w_trans, const float* b_trans,
+                             const float* zoom_factor, int B, int F);
+
+/* --------------------------------------------- S-group: SE(3) pose update -- */
+/* RT_transform (lib/pair_matching/RT_transform.py:127-151) batched: pose_est (B,3,4) f32 from
+ * pose_src (B,3,4), se3 (B,7) = [quat(4) | trans(3)]. Computed in float64 like the reference,
+ * stored float32. rot_coord: 0 MODEL, 1 CAMERA, 2 CAMERA_NEW, 3 NAIVE. pose_est64 optional (B,3,4) f64. */
+int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
+                        const float* se3, const float* T_means_host, const float* T_stds_host,
+                        int rot_coord, int B);
+/* Transform3D forward/backward (deepim/operator_py/transform3d.py:34-151) */
+int deepim_transform3d_forward(deepim_ctx* ctx, float* out /*B,3,N*/, const float* points /*B,3,N*/,
+                               const float* rotation /*B,4*/, const float* translation /*B,3*/,
+                               const float* pose_src, const float* T_means_host,
+                               const float* T_stds_host, int rot_coord, int B, int N);
+int deepim_transform3d_backward(deepim_ctx* ctx, float* d_rotation /*B,4*/, float* d_translation /*B,3*/,
+                                const float* out_grad /*B,3,N*/, const float* points,
+                                const float* rotation, const float* translation,
+                                const float* pose_src, const float* T_means_host,
+                                const float* T_stds_host, int rot_coord, int B, int N);
+
+/* ---------------------------------------------------- H-group: heads/losses -- */
+/* point-matching loss (deepIM_flownet.py:265-312): per-element
+ * loss = weights · f((est − gt)/normalize), f ∈ {0: L1 |x|, 1: L2 x², 2: smooth-L1(σ)};
+ * writes loss elements (B,3,N), the batch sum and d loss/d est (scaled by grad_scale) */
+int deepim_point_matching_loss(deepim_ctx* ctx, float* loss /*B,3,N*/, float* loss_sum /*1*/,
+                               float* d_est /*B,3,N or NULL*/, const float* est, const float* gt,
+                               const float* weights /*B,3,N or NULL*/, float normalize,
+                               int loss_type, float sigma, float grad_scale, int B, int N);
+/* flow loss (deepIM_flownet.py:201-207): loss = w·(est − gt/normalize_flow)² */
+int deepim_flow_loss(deepim_ctx* ctx, float* loss /*n*/, float* loss_sum, float* d_est,
+                     const float* est, const float* gt, const float* weights,
+                     float normalize_flow, float grad_scale, size_t n);
+/* mask head test path (deepIM_flownet.py:647-666): sigmoid → ZoomMaskWithFactor(inverse)
+ * → round. `logits` is the cropped upsampled mask_conv3 output (B,1,H,W). prob optional. */
+int deepim_mask_head_forward(deepim_ctx* ctx, float* mask_pred /*B,1,H,W*/, float* prob /*or NULL*/,
+                             const float* logits, const float* zoom_factor, int B, int H, int W);
+/* mask loss (deepIM_flownet.py:342-361): LogisticRegressionOutput forward = sigmoid,
+ * backward = (p − y)·grad_scale */
+int deepim_mask_logistic(deepim_ctx* ctx, float* prob, float* d_logits /*or NULL*/,
+                         const float* logits, const float* label, float grad_scale, size_t n);
+/* GroupPicker (deepim/operator_py/group_picker.py:22-56) */
+int deepim_group_picker_forward(deepim_ctx* ctx, float* out /*B,C/G*/, const float* in /*B,C*/,
+                                const float* group_idx /*B*/, int group_num, int B, int C);
+int deepim_group_picker_backward(deepim_ctx* ctx, float* in_grad /*B,C*/, const float* out_grad,
+                                 const float* group_idx, int group_num, int B, int C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DEEPIM_HIP_H_ */

@@ -1,0 +1,59 @@
+// Shared internals of libdeepim_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/deepim_hip.h"
+
+struct deepim_ctx {
+  int device;
+  hipStream_t stream;
+  // small device scratch shared by the ops (bbox words, zoom factors, split-K partials)
+  void* scratch;
+  size_t scratch_bytes;
+  int* status;  // persistent device status word (bit0: empty observed mask/image in a zoom op)
+  // pinned host staging for small per-call attribute uploads (K, means, ...)
+  std::vector<hipEvent_t> timer_start, timer_stop;
+  std::vector<hipGraphExec_t> graphs;
+  bool capturing;
+};
+
+void deepim_set_error(const char* where, hipError_t e);
+void deepim_set_error_msg(const char* msg);
+
+#define DI_CHECK(expr)                                   \
+  do {                                                   \
+    hipError_t _e = (expr);                              \
+    if (_e != hipSuccess) {                              \
+      deepim_set_error(#expr, _e);                       \
+      return (int)_e;                                    \
+    }                                                    \
+  } while (0)
+
+#define DI_LAUNCH_CHECK()                                \
+  do {                                                   \
+    hipError_t _e = hipGetLastError();                   \
+    if (_e != hipSuccess) {                              \
+      deepim_set_error("kernel launch", _e);             \
+      return (int)_e;                                    \
+    }                                                    \
+  } while (0)
+
+#define DI_REQUIRE(cond, msg)                            \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      deepim_set_error_msg(msg);                         \
+      return -1;                                         \
+    }                                                    \
+  } while (0)
+
+// Grow-only scratch; never reallocated while a graph capture is open.
+int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out);
+
+static inline int di_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// small by-value attribute blocks passed as kernel arguments (live in SGPRs)
+struct Mat3 { float v[9]; };
+struct Vec3 { float v[3]; };

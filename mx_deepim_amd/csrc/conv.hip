@@ -1,0 +1,446 @@
+// N-group: FlowNetS convolution / deconvolution stack on the fp32 matrix cores.
+//   MXNet Convolution + bias + LeakyReLU   deepIM_flownet.py:63-107,123,145,176,317
+//   MXNet Deconvolution k4 s2 + Crop       deepIM_flownet.py:127-165
+//   MXNet Deconvolution k32 s16 grouped    deepIM_flownet.py:185-200,326-340
+//
+// Design (CDNA4): implicit GEMM  D[co][pixel] = Σ_k Wp[co][k] · X[k][pixel],
+// k = (ci,ky,kx) in the natural MXNet order, on v_mfma_f32_32x32x2_f32 — exact fp32,
+// result bit-identical to a k-ordered fmaf chain, at the fp32 vector peak (157 TF) but
+// from one wave per SIMD, leaving the VALU free for the im2col gather.
+//   * block = 256 threads = 4 wavefronts in a 2×2 grid over a BM×BN output tile
+//     (BM output channels × BN output pixels, pixels flattened over (n,ho,wo));
+//   * K is consumed in chunks of 16: the weight chunk is a contiguous 16×BM slab of
+//     the pre-packed weights (one dwordx4 per thread, straight into LDS [k][m]); the
+//     activation chunk is gathered global→registers→LDS [k][pixel] with the
+//     per-thread pixel fixed for the whole K loop, the (ci,ky,kx)→offset table read
+//     through the scalar cache, and zero padding applied by per-thread ky/kx bitmasks;
+//   * LDS is double-buffered (one s_barrier per chunk); operand reads are
+//     conflict-free ds_read_b32 (lanes 0-31 → 32 consecutive dwords of row k, lanes
+//     32-63 → row k+1, matching the 32x32x2 A/B fragment layout);
+//   * epilogue fuses bias + LeakyReLU and writes NCHW with 128 B runs per row; the
+//     output may be a channel slice of a wider tensor (free Concat).
+// Roofline: MFMA-bound (arithmetic intensity ≈ 300 FLOP/B).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KT = 16;        // K chunk
+constexpr int GRAN = 64;      // weight packing granule (rows)
+constexpr int MODE_CONV = 0;
+constexpr int MODE_DECONV = 1;  // k4 s2 p0 transposed conv, one launch z-slice per output parity
+
+struct ConvParams {
+  const float* in;
+  const float* wp;     // packed [Mgran][nchunk][KT][GRAN]
+  const int2* tab;     // per k: {element offset ci*H*W + ky*W + kx, (ky<<8)|kx}; padded k → ky = 31
+  const float* bias;
+  float* out;
+  int B, Cin, H, W;         // input
+  int Cout, Ho, Wo;         // output (after crop for deconv)
+  int stride, pad;
+  int nchunk;               // ceil(K/16)
+  int ngran;                // 64-row weight granules per (parity class of the) packed tensor
+  int out_ctotal, out_coff;
+  float slope;
+  int crop_y, crop_x;       // deconv crop offsets
+  long npix;                // B*Ho*Wo (conv) or pixels per parity class (deconv)
+};
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NG = BM / GRAN;            // weight granules per block
+  constexpr int EB = KT * BN / 256;        // gathered elements per thread per chunk
+  constexpr int KSTEP = 256 / BN;          // k rows covered per pass
+  __shared__ __attribute__((aligned(16))) float As[2][KT * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KT * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int mb = blockIdx.y;               // M tile
+  const long n0 = (long)blockIdx.x * BN;   // first pixel of the tile
+
+  // ---- per-thread gather state (fixed for the whole K loop) ----
+  const int gp = tid & (BN - 1);
+  const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+  const long pix = n0 + gp;
+  const float* gbase = p.in;
+  unsigned mky = 0, mkx = 0;
+  int par_y = 0, par_x = 0;
+  long npix = p.npix;
+  if (MODE == MODE_DECONV) {
+    par_y = (blockIdx.z >> 1); par_x = (blockIdx.z & 1);
+    const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
+    npix = (long)p.B * ((p.Ho - oy0 + 1) >> 1) * ((p.Wo - ox0 + 1) >> 1);
+  }
+  if (pix < npix) {
+    if (MODE == MODE_CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int r = (int)(pix - (long)n * hw);
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      gbase = p.in + (long)n * p.Cin * p.H * p.W + (long)hi0 * p.W + wi0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
+        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+      }
+    } else {
+      // parity class (par_y,par_x) of the UNCROPPED deconv output y = yo + crop_y.
+      // class pixels: yo = 2*qy + oy0 where oy0 makes (yo+crop_y)&1 == par_y.
+      const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
+      const int nqy = (p.Ho - oy0 + 1) >> 1, nqx = (p.Wo - ox0 + 1) >> 1;
+      const int hw = nqy * nqx;
+      const int n = (int)(pix / hw);
+      const int r = (int)(pix - (long)n * hw);
+      const int qy = r / nqx, qx = r - qy * nqx;
+      const int y = 2 * qy + oy0 + p.crop_y, x = 2 * qx + ox0 + p.crop_x;  // uncropped coords
+      // taps: ky = par_y + 2*jy (jy∈{0,1}) ↔ iy = (y - ky)/2 = (y>>1) - jy ; table kx/ky hold jy/jx
+      const int iy0 = (y >> 1), ix0 = (x >> 1);
+      gbase = p.in + (long)n * p.Cin * p.H * p.W + (long)iy0 * p.W + ix0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (iy0 - j >= 0 && iy0 - j < p.H) mky |= 1u << j;
+        if (ix0 - j >= 0 && ix0 - j < p.W) mkx |= 1u << j;
+      }
+    }
+  }
+
+  const float* wblk = p.wp + ((long)mb * NG) * p.nchunk * (KT * GRAN);
+  if (MODE == MODE_DECONV) wblk += (long)blockIdx.z * p.ngran * p.nchunk * (KT * GRAN);
+
+  float4 areg[NG];
+  float breg[EB];
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      areg[g] = *reinterpret_cast<const float4*>(wblk + ((long)g * p.nchunk + kc) * (KT * GRAN) + tid * 4);
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const int k = kc * KT + krow0 + e * KSTEP;
+      const int2 t = p.tab[k];
+      const unsigned ky = (unsigned)t.y >> 8, kx = (unsigned)t.y & 255u;
+      const bool ok = ((mky >> ky) & (mkx >> kx) & 1u) != 0;
+      breg[e] = ok ? gbase[t.x] : 0.f;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int e = tid * 4;
+      const int kk = e / GRAN, mm = e % GRAN;
+      *reinterpret_cast<float4*>(&As[buf][kk * BM + g * GRAN + mm]) = areg[g];
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) Bs[buf][(krow0 + e * KSTEP) * BN + gp] = breg[e];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int lrow = lane >> 5, lcol = lane & 31;
+  for (int kc = 0; kc < p.nchunk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < p.nchunk) load_chunk(kc + 1);
+    const float* as = &As[buf][lrow * BM + wm0 + lcol];
+    const float* bs = &Bs[buf][lrow * BN + wn0 + lcol];
+#pragma unroll
+    for (int s = 0; s < KT / 2; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[s * 2 * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[s * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < p.nchunk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + LeakyReLU, NCHW store ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = n0 + wn0 + j * 32 + lcol;
+    if (op >= npix) continue;
+    long obase;
+    if (MODE == MODE_CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(op / hw);
+      const int r = (int)(op - (long)n * hw);
+      obase = ((long)n * p.out_ctotal + p.out_coff) * hw + r;
+    } else {
+      const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
+      const int nqy = (p.Ho - oy0 + 1) >> 1, nqx = (p.Wo - ox0 + 1) >> 1;
+      const int hwq = nqy * nqx;
+      const int n = (int)(op / hwq);
+      const int r = (int)(op - (long)n * hwq);
+      const int qy = r / nqx, qx = r - qy * nqx;
+      obase = ((long)n * p.out_ctotal + p.out_coff) * p.Ho * p.Wo + (long)(2 * qy + oy0) * p.Wo + (2 * qx + ox0);
+    }
+    const long cstride = (long)p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * BM + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (co < p.Cout) {
+          float v = acc[i][j][r] + (p.bias ? p.bias[co] : 0.f);
+          v = v > 0.f ? v : v * p.slope;
+          p.out[obase + co * cstride] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------ packing ----
+// conv:   packed[g][kc][kk][mm] = w[(g*64+mm)][kc*16+kk]  (w as (Cout, K) row-major), zero padded
+__global__ void pack_conv_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int K, int nchunk,
+                                 long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int mm = (int)(i % GRAN);
+  const int kk = (int)((i / GRAN) % KT);
+  const int kc = (int)((i / (GRAN * KT)) % nchunk);
+  const int g = (int)(i / ((long)GRAN * KT * nchunk));
+  const int co = g * GRAN + mm, k = kc * KT + kk;
+  packed[i] = (co < Cout && k < K) ? w[(long)co * K + k] : 0.f;
+}
+// deconv (w: Cin,Cout,4,4): 4 parity classes z = py*2+px; per class K = Cin*4, k = ci*4 + jy*2 + jx,
+// tap ky = py + 2*jy, kx = px + 2*jx:  packed[z][g][kc][kk][mm] = w[ci][g*64+mm][ky][kx]
+__global__ void pack_deconv_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cin, int Cout,
+                                   int ngran, int nchunk, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int mm = (int)(i % GRAN);
+  const int kk = (int)((i / GRAN) % KT);
+  const int kc = (int)((i / (GRAN * KT)) % nchunk);
+  const int g = (int)((i / ((long)GRAN * KT * nchunk)) % ngran);
+  const int z = (int)(i / ((long)GRAN * KT * nchunk * ngran));
+  const int py = z >> 1, px = z & 1;
+  const int co = g * GRAN + mm, k = kc * KT + kk;
+  float v = 0.f;
+  if (co < Cout && k < Cin * 4) {
+    const int ci = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
+    v = w[(((long)ci * Cout + co) * 4 + (py + 2 * jy)) * 4 + (px + 2 * jx)];
+  }
+  packed[i] = v;
+}
+
+__global__ void build_conv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int kh, int kw, int H, int W) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  if (k >= K) { tab[k] = make_int2(0, (31 << 8)); return; }
+  const int kx = k % kw, ky = (k / kw) % kh, ci = k / (kw * kh);
+  tab[k] = make_int2(ci * H * W + ky * W + kx, (ky << 8) | kx);
+}
+__global__ void build_deconv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int H, int W) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  if (k >= K) { tab[k] = make_int2(0, (31 << 8)); return; }
+  const int ci = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
+  tab[k] = make_int2(ci * H * W - jy * W - jx, (jy << 8) | jx);
+}
+
+// grouped k32 s16 transposed conv (depthwise), cropped, scaled: ≤ 2x2 contributing inputs per output
+__global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                         const float* __restrict__ w, int C, int H, int W, int Ho,
+                                                         int Wo, int crop_y, int crop_x, float scale) {
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  const int yo = blockIdx.y;
+  const int bc = blockIdx.z;
+  if (xo >= Wo) return;
+  const int c = bc % C;
+  const int y = yo + crop_y, x = xo + crop_x;  // uncropped output coords: y = iy*16 + ky
+  const float* ip = in + (long)bc * H * W;
+  const float* wp = w + (long)c * 1024;
+  float acc = 0.f;
+  // iy ascending, ix ascending (matches a gather restatement of the scatter definition)
+  const int iy_hi = y >> 4, ix_hi = x >> 4;
+#pragma unroll
+  for (int dy = 1; dy >= 0; --dy) {
+    const int iy = iy_hi - dy;
+    const int ky = y - iy * 16;
+    if (iy < 0 || iy >= H || ky >= 32) continue;
+#pragma unroll
+    for (int dx = 1; dx >= 0; --dx) {
+      const int ix = ix_hi - dx;
+      const int kx = x - ix * 16;
+      if (ix < 0 || ix >= W || kx >= 32) continue;
+      acc = fmaf(ip[iy * W + ix], wp[ky * 32 + kx], acc);
+    }
+  }
+  out[((long)bc * Ho + yo) * Wo + xo] = acc * scale;
+}
+
+struct TileChoice { int bm, bn; };
+TileChoice choose_tile(int Cout, long npix) {
+  // biggest tile that still yields ≥ 2 blocks per CU on 256 CUs; small Cout → BM=64
+  const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+  for (auto& c : cands) {
+    if (c[0] > 64 && Cout <= 64) continue;
+    const long blocks = (long)di_div_up(Cout, c[0]) * di_div_up(npix, c[1]);
+    if (blocks >= 1024) return {c[0], c[1]};
+  }
+  return {64, 64};
+}
+
+template <int MODE>
+int launch_conv(deepim_ctx* ctx, const ConvParams& p, int gridz) {
+  const TileChoice t = choose_tile(p.Cout, p.npix);
+  dim3 grid(di_div_up(p.npix, t.bn), di_div_up(p.Cout, t.bm), gridz);
+  DI_REQUIRE(grid.y <= 65535 && grid.x > 0, "conv: grid too large");
+  if (t.bm == 128 && t.bn == 128)
+    hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  else if (t.bm == 64 && t.bn == 128)
+    hipLaunchKernelGGL((conv_mfma_kernel<64, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  else if (t.bm == 128 && t.bn == 64)
+    hipLaunchKernelGGL((conv_mfma_kernel<128, 64, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<64, 64, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+inline int gran_count(int Cout) { return di_div_up(Cout, 128) * 2; }  // whole 128-row tiles → BM=128 never overruns
+inline int chunk_count(int K) { return di_div_up(K, KT); }
+
+// tap tables are tiny; keep them in a per-context cache keyed by geometry
+struct TabKey { int mode, Cin, kh, kw, H, W; };
+struct TabEntry { TabKey key; int2* tab; };
+static std::vector<std::pair<deepim_ctx*, TabEntry>> g_tabs;
+
+int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, int2** out) {
+  for (auto& e : g_tabs) {
+    const TabKey& k = e.second.key;
+    if (e.first == ctx && k.mode == mode && k.Cin == Cin && k.kh == kh && k.kw == kw && k.H == H && k.W == W) {
+      *out = e.second.tab;
+      return 0;
+    }
+  }
+  DI_REQUIRE(!ctx->capturing, "conv tap table built during graph capture; run the sequence once eagerly first");
+  const int K = mode == MODE_CONV ? Cin * kh * kw : Cin * 4;
+  const int Kpad = chunk_count(K) * KT;
+  int2* tab;
+  DI_CHECK(hipMalloc((void**)&tab, (size_t)Kpad * sizeof(int2)));
+  if (mode == MODE_CONV)
+    hipLaunchKernelGGL(build_conv_tab_kernel, dim3(di_div_up(Kpad, 256)), dim3(256), 0, ctx->stream, tab, K, Kpad, kh,
+                       kw, H, W);
+  else
+    hipLaunchKernelGGL(build_deconv_tab_kernel, dim3(di_div_up(Kpad, 256)), dim3(256), 0, ctx->stream, tab, K, Kpad, H,
+                       W);
+  DI_LAUNCH_CHECK();
+  g_tabs.push_back({ctx, {{mode, Cin, kh, kw, H, W}, tab}});
+  *out = tab;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw) {
+  return (size_t)gran_count(Cout) * chunk_count(Cin * kh * kw) * KT * GRAN * sizeof(float);
+}
+
+extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh,
+                                        int kw) {
+  const int K = Cin * kh * kw, nchunk = chunk_count(K);
+  const long total = (long)gran_count(Cout) * nchunk * KT * GRAN;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
+                     nchunk, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                                     const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                     int stride, int pad, float slope, int out_ctotal, int out_coff) {
+  if (B == 0) return 0;
+  DI_REQUIRE(kh <= 8 && kw <= 8, "conv2d: kernel larger than 8 not supported");
+  DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
+  ConvParams p;
+  p.in = in; p.wp = packed_w; p.bias = bias; p.out = out;
+  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+  p.Ho = (H + 2 * pad - kh) / stride + 1;
+  p.Wo = (W + 2 * pad - kw) / stride + 1;
+  p.stride = stride; p.pad = pad;
+  p.nchunk = chunk_count(Cin * kh * kw);
+  p.ngran = gran_count(Cout);
+  p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
+  p.out_coff = out_coff;
+  p.slope = slope; p.crop_y = p.crop_x = 0;
+  p.npix = (long)B * p.Ho * p.Wo;
+  int2* tab;
+  int rc = get_tab(ctx, MODE_CONV, Cin, kh, kw, H, W, &tab);
+  if (rc) return rc;
+  p.tab = tab;
+  return launch_conv<MODE_CONV>(ctx, p, 1);
+}
+
+extern "C" size_t deepim_deconv_packed_size(int Cin, int Cout) {
+  return (size_t)4 * gran_count(Cout) * chunk_count(Cin * 4) * KT * GRAN * sizeof(float);
+}
+
+extern "C" int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cin, int Cout) {
+  const int nchunk = chunk_count(Cin * 4), ngran = gran_count(Cout);
+  const long total = (long)4 * ngran * nchunk * KT * GRAN;
+  hipLaunchKernelGGL(pack_deconv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cin, Cout,
+                     ngran, nchunk, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                                               const float* bias, int B, int Cin, int H, int W, int Cout, int Ho,
+                                               int Wo, int crop_y, int crop_x, float slope, int out_ctotal,
+                                               int out_coff) {
+  if (B == 0) return 0;
+  DI_REQUIRE(Ho + crop_y <= (H - 1) * 2 + 4 && Wo + crop_x <= (W - 1) * 2 + 4, "deconv: crop exceeds output");
+  ConvParams p;
+  p.in = in; p.wp = packed_w; p.bias = bias; p.out = out;
+  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+  p.Ho = Ho; p.Wo = Wo; p.stride = 2; p.pad = 0;
+  p.nchunk = chunk_count(Cin * 4);
+  p.ngran = gran_count(Cout);
+  p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
+  p.out_coff = out_coff;
+  p.slope = slope; p.crop_y = crop_y; p.crop_x = crop_x;
+  // every parity class has at most ceil(Ho/2)*ceil(Wo/2) pixels; size the grid for the largest, the
+  // kernel masks with its own per-class count
+  p.npix = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+  int2* tab;
+  int rc = get_tab(ctx, MODE_DECONV, Cin, 4, 4, H, W, &tab);
+  if (rc) return rc;
+  p.tab = tab;
+  return launch_conv<MODE_DECONV>(ctx, p, 4);
+}
+
+extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const float* in, const float* w, int B,
+                                              int C, int H, int W, int Ho, int Wo, int crop_y, int crop_x,
+                                              float scale) {
+  if (B == 0) return 0;
+  dim3 grid(di_div_up(Wo, 256), Ho, B * C);
+  hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
+                     scale);
+  DI_LAUNCH_CHECK();
+  return 0;
+}

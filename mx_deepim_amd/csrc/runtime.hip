@@ -1,0 +1,172 @@
+// Runtime half of the C ABI: context, device memory, copies, HIP-event stopwatch,
+// hipGraph capture. Replaces the MXNet context/NDArray plumbing the reference's
+// Predictor relies on (deepim/core/tester.py:27-47).
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void deepim_set_error(const char* where, hipError_t e) {
+  snprintf(g_err, sizeof(g_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+}
+void deepim_set_error_msg(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+extern "C" const char* deepim_last_error(void) { return g_err; }
+
+extern "C" int deepim_device_count(int* n) {
+  DI_CHECK(hipGetDeviceCount(n));
+  return 0;
+}
+
+extern "C" int deepim_create(int device_id, deepim_ctx** out) {
+  DI_REQUIRE(out != nullptr, "deepim_create: out is NULL");
+  int n = 0;
+  DI_CHECK(hipGetDeviceCount(&n));
+  DI_REQUIRE(device_id >= 0 && device_id < n, "deepim_create: no such device");
+  DI_CHECK(hipSetDevice(device_id));
+  deepim_ctx* c = new deepim_ctx();
+  c->device = device_id;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  c->capturing = false;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    deepim_set_error("hipStreamCreate", e);
+    delete c;
+    return (int)e;
+  }
+  e = hipMalloc((void**)&c->status, 64);
+  if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 64, c->stream);
+  if (e != hipSuccess) {
+    deepim_set_error("hipMalloc(status)", e);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int deepim_destroy(deepim_ctx* ctx) {
+  if (!ctx) return 0;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto g : ctx->graphs) hipGraphExecDestroy(g);
+  for (auto e : ctx->timer_start) hipEventDestroy(e);
+  for (auto e : ctx->timer_stop) hipEventDestroy(e);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->status) hipFree(ctx->status);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    DI_REQUIRE(!ctx->capturing, "scratch growth during graph capture; run the sequence once eagerly first");
+    DI_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) DI_CHECK(hipFree(ctx->scratch));
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    DI_CHECK(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return 0;
+}
+
+extern "C" int deepim_malloc(deepim_ctx* ctx, size_t bytes, void** dptr) {
+  DI_CHECK(hipSetDevice(ctx->device));
+  DI_CHECK(hipMalloc(dptr, bytes ? bytes : 4));
+  return 0;
+}
+extern "C" int deepim_free(deepim_ctx* ctx, void* dptr) {
+  if (!dptr) return 0;
+  DI_CHECK(hipSetDevice(ctx->device));
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  DI_CHECK(hipFree(dptr));
+  return 0;
+}
+extern "C" int deepim_memset(deepim_ctx* ctx, void* dptr, int value, size_t bytes) {
+  DI_CHECK(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return 0;
+}
+extern "C" int deepim_h2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" int deepim_d2h(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+extern "C" int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff, const float* src, int C,
+                                    int B, size_t hw) {
+  if (B == 0 || C == 0) return 0;
+  DI_CHECK(hipMemcpy2DAsync(dst + (size_t)dst_coff * hw, (size_t)dst_ctotal * hw * sizeof(float), src,
+                            (size_t)C * hw * sizeof(float), (size_t)C * hw * sizeof(float), (size_t)B,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+extern "C" int deepim_sync(deepim_ctx* ctx) {
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" void* deepim_stream(deepim_ctx* ctx) { return (void*)ctx->stream; }
+
+extern "C" int deepim_timer_create(deepim_ctx* ctx, int* timer_id) {
+  hipEvent_t a, b;
+  DI_CHECK(hipEventCreate(&a));
+  DI_CHECK(hipEventCreate(&b));
+  ctx->timer_start.push_back(a);
+  ctx->timer_stop.push_back(b);
+  *timer_id = (int)ctx->timer_start.size() - 1;
+  return 0;
+}
+extern "C" int deepim_timer_start(deepim_ctx* ctx, int id) {
+  DI_REQUIRE(id >= 0 && id < (int)ctx->timer_start.size(), "bad timer id");
+  DI_CHECK(hipEventRecord(ctx->timer_start[id], ctx->stream));
+  return 0;
+}
+extern "C" int deepim_timer_stop(deepim_ctx* ctx, int id) {
+  DI_REQUIRE(id >= 0 && id < (int)ctx->timer_stop.size(), "bad timer id");
+  DI_CHECK(hipEventRecord(ctx->timer_stop[id], ctx->stream));
+  return 0;
+}
+extern "C" int deepim_timer_elapsed_ms(deepim_ctx* ctx, int id, float* ms) {
+  DI_REQUIRE(id >= 0 && id < (int)ctx->timer_stop.size(), "bad timer id");
+  DI_CHECK(hipEventSynchronize(ctx->timer_stop[id]));
+  DI_CHECK(hipEventElapsedTime(ms, ctx->timer_start[id], ctx->timer_stop[id]));
+  return 0;
+}
+
+extern "C" int deepim_graph_begin(deepim_ctx* ctx) {
+  DI_REQUIRE(!ctx->capturing, "graph capture already open");
+  DI_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return 0;
+}
+extern "C" int deepim_graph_end(deepim_ctx* ctx, int* graph_id) {
+  DI_REQUIRE(ctx->capturing, "no graph capture open");
+  hipGraph_t g;
+  ctx->capturing = false;
+  DI_CHECK(hipStreamEndCapture(ctx->stream, &g));
+  hipGraphExec_t ge;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    deepim_set_error("hipGraphInstantiate", e);
+    return (int)e;
+  }
+  ctx->graphs.push_back(ge);
+  *graph_id = (int)ctx->graphs.size() - 1;
+  return 0;
+}
+extern "C" int deepim_graph_launch(deepim_ctx* ctx, int graph_id) {
+  DI_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size(), "bad graph id");
+  DI_CHECK(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
+  return 0;
+}

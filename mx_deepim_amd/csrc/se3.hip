@@ -1,0 +1,310 @@
+// S-group: SE(3) pose update and 3-D point transform.
+//   S1 RT_transform            lib/pair_matching/RT_transform.py:127-151 (+ :47-61, :74-95, :383-429)
+//   S5 Transform3D forward     deepim/operator_py/transform3d.py:34-97, :185-212
+//   S6 Transform3D backward    deepim/operator_py/transform3d.py:99-151, :153-183, :214-281
+//
+// The reference does this on the host with NumPy-1.x scalar promotion: float32 inputs,
+// `2.0 / Nq` and everything downstream in float64, a few float32 islands
+// (T_src[0] / T_src[2]). The kernels keep that pattern operation by operation (fp64 is
+// full rate on CDNA4; the work is a few hundred flops per pair). Reductions over the
+// N model points use wavefront shuffles + one LDS hop.
+#include "common.h"
+
+namespace {
+
+enum RotCoord { RC_MODEL = 0, RC_CAMERA = 1, RC_CAMERA_NEW = 2, RC_NAIVE = 3 };
+
+struct Vec3d { double v[3]; };
+
+// quaternion (already float32 scalars) → float64 matrix, RT_transform.py:409-429
+__device__ void quat2mat_f64(float w, float x, float y, float z, double* M) {
+  const double s = 2.0 / (double)(w * w + x * x + y * y + z * z);
+  const double X = x * s, Y = y * s, Z = z * s;
+  const double wX = w * X, wY = w * Y, wZ = w * Z;
+  const double xX = x * X, xY = x * Y, xZ = x * Z;
+  const double yY = y * Y, yZ = y * Z, zZ = z * Z;
+  M[0] = 1.0 - (yY + zZ); M[1] = xY - wZ; M[2] = xZ + wY;
+  M[3] = xY + wZ; M[4] = 1.0 - (xX + zZ); M[5] = yZ - wX;
+  M[6] = xZ - wY; M[7] = yZ + wX; M[8] = 1.0 - (xX + yY);
+}
+
+// T_transform, RT_transform.py:74-95 (T_src, T_delta float32; means/stds float64)
+__device__ void t_transform_f64(const float* Tsrc, const float* Td, const Vec3d& mu, const Vec3d& sd, int rc,
+                                double* T) {
+  double d1[3];
+  for (int i = 0; i < 3; ++i) d1[i] = (double)Td[i] * sd.v[i] + mu.v[i];
+  const double z2 = (double)Tsrc[2] / exp(d1[2]);
+  T[2] = z2;
+  if (rc == RC_CAMERA || rc == RC_MODEL) {
+    T[0] = z2 * (d1[0] + (double)(Tsrc[0] / Tsrc[2]));
+    T[1] = z2 * (d1[1] + (double)(Tsrc[1] / Tsrc[2]));
+  } else {  // CAMERA_NEW
+    T[0] = (double)Tsrc[2] * d1[0] + (double)Tsrc[0];
+    T[1] = (double)Tsrc[2] * d1[1] + (double)Tsrc[1];
+  }
+}
+
+__global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __restrict__ pose_est64,
+                                    const float* __restrict__ pose_src, const float* __restrict__ se3, Vec3d mu,
+                                    Vec3d sd, int rc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* P = pose_src + b * 12;
+  const float* q = se3 + b * 7;
+  const float* t = q + 4;
+  // quat = r / LA.norm(r)  (float32)
+  const float nrm = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  const float w = q[0] / nrm, x = q[1] / nrm, y = q[2] / nrm, z = q[3] / nrm;
+  double Rd[9];
+  const float Nq = ((w * w + x * x) + y * y) + z * z;
+  // quat2mat returns eye(3) when Nq < _FLOAT_EPS (RT_transform.py:236,412)
+  if (!((double)Nq < 2.220446049250313e-16)) quat2mat_f64(w, x, y, z, Rd);
+  else for (int i = 0; i < 9; ++i) Rd[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  double out[12];
+  if (rc == RC_NAIVE) {
+    // se3_mul(se3_mx, pose_src): float64·float32 products, result cast to float32 (projection.py:26-43)
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j)
+        out[i * 4 + j] = (double)(float)(Rd[i * 3 + 0] * P[0 * 4 + j] + Rd[i * 3 + 1] * P[1 * 4 + j] + Rd[i * 3 + 2] * P[2 * 4 + j]);
+      out[i * 4 + 3] = (double)(float)((Rd[i * 3 + 0] * P[3] + Rd[i * 3 + 1] * P[7] + Rd[i * 3 + 2] * P[11]) + (double)t[i]);
+    }
+  } else {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        if (rc == RC_MODEL)
+          out[i * 4 + j] = (double)P[i * 4 + 0] * Rd[0 * 3 + j] + (double)P[i * 4 + 1] * Rd[1 * 3 + j] + (double)P[i * 4 + 2] * Rd[2 * 3 + j];
+        else
+          out[i * 4 + j] = Rd[i * 3 + 0] * P[0 * 4 + j] + Rd[i * 3 + 1] * P[1 * 4 + j] + Rd[i * 3 + 2] * P[2 * 4 + j];
+      }
+    const float Tsrc[3] = {P[3], P[7], P[11]};
+    double T[3];
+    t_transform_f64(Tsrc, t, mu, sd, rc, T);
+    out[3] = T[0]; out[7] = T[1]; out[11] = T[2];
+  }
+  for (int i = 0; i < 12; ++i) {
+    pose_est[b * 12 + i] = (float)out[i];
+    if (pose_est64) pose_est64[b * 12 + i] = out[i];
+  }
+}
+
+// --- Transform3D --------------------------------------------------------------
+// quat2mat_forward (transform3d.py:185-212): identity unless |Nq-1| < 1e-2; float64 math, float32 result
+__device__ void t3d_quat2mat(const float* q, float* M) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float Nq = ((w * w + x * x) + y * y) + z * z;
+  const double dn = (double)(Nq - 1.f);
+  if (!(-1e-2 < dn && dn < 1e-2)) {
+    for (int i = 0; i < 9; ++i) M[i] = (i % 4 == 0) ? 1.f : 0.f;
+    return;
+  }
+  double Md[9];
+  quat2mat_f64(w, x, y, z, Md);
+  for (int i = 0; i < 9; ++i) M[i] = (float)Md[i];
+}
+
+// per-sample R_tgt (float32 3x3) and t_tgt (float32 3) → rt (B,12) as [R | t] rows
+__global__ void t3d_prepare_kernel(float* __restrict__ rt, const float* __restrict__ rotation,
+                                   const float* __restrict__ translation, const float* __restrict__ pose_src, Vec3d mu,
+                                   Vec3d sd, int rc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* P = pose_src + b * 12;
+  float Rd[9];
+  t3d_quat2mat(rotation + b * 4, Rd);
+  float* o = rt + b * 12;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float v;
+      if (rc == RC_MODEL) v = P[i * 4 + 0] * Rd[0 * 3 + j] + P[i * 4 + 1] * Rd[1 * 3 + j] + P[i * 4 + 2] * Rd[2 * 3 + j];
+      else v = Rd[i * 3 + 0] * P[0 * 4 + j] + Rd[i * 3 + 1] * P[1 * 4 + j] + Rd[i * 3 + 2] * P[2 * 4 + j];
+      o[i * 4 + j] = v;
+    }
+  const float Tsrc[3] = {P[3], P[7], P[11]};
+  const float* Td = translation + b * 3;
+  if (rc == RC_NAIVE) {  // T_transform_naive (RT_transform.py:98-102), float32
+    for (int i = 0; i < 3; ++i)
+      o[i * 4 + 3] = (Rd[i * 3 + 0] * Tsrc[0] + Rd[i * 3 + 1] * Tsrc[1] + Rd[i * 3 + 2] * Tsrc[2]) + Td[i];
+  } else {
+    double T[3];
+    t_transform_f64(Tsrc, Td, mu, sd, rc, T);
+    o[3] = (float)T[0]; o[7] = (float)T[1]; o[11] = (float)T[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void t3d_apply_kernel(float* __restrict__ out, const float* __restrict__ pts,
+                                                        const float* __restrict__ rt, int N) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* R = rt + b * 12;
+  const float* p = pts + (long)b * 3 * N;
+  const float x = p[n], y = p[N + n], z = p[2 * N + n];
+  float* o = out + (long)b * 3 * N;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i * N + n] = ((R[i * 4 + 0] * x + R[i * 4 + 1] * y) + R[i * 4 + 2] * z) + R[i * 4 + 3];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// one block per sample: 3 + 9 reductions over N, then the quaternion / translation chain rule
+__global__ __launch_bounds__(256) void t3d_backward_kernel(float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                                           const float* __restrict__ og, const float* __restrict__ pts,
+                                                           const float* __restrict__ rotation,
+                                                           const float* __restrict__ translation,
+                                                           const float* __restrict__ pose_src, Vec3 mu, Vec3 sd, int rc,
+                                                           int N) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* g = og + (long)b * 3 * N;
+  const float* p = pts + (long)b * 3 * N;
+  const float* P = pose_src + b * 12;
+  float s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float gv[3] = {g[n], g[N + n], g[2 * N + n]};
+    float pv[3] = {p[n], p[N + n], p[2 * N + n]};
+    if (rc == RC_NAIVE) {  // src_3d_points = Rm_src·P + T_src (transform3d.py:131-133)
+      float q[3];
+      for (int i = 0; i < 3; ++i) q[i] = ((P[i * 4 + 0] * pv[0] + P[i * 4 + 1] * pv[1]) + P[i * 4 + 2] * pv[2]) + P[i * 4 + 3];
+      for (int i = 0; i < 3; ++i) pv[i] = q[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      s[i] += gv[i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s[3 + i * 3 + j] = fmaf(gv[i], pv[j], s[3 + i * 3 + j]);
+    }
+  }
+  __shared__ float red[4][12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float v = wave_sum(s[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  float tot[12];
+  for (int i = 0; i < 12; ++i) tot[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  const float* Dt = tot;      // T_tgt_diff (3)
+  const float* Dr = tot + 3;  // Rm_tgt_diff (3x3) — or Rm_delta_diff directly for NAIVE
+  // ---- translation ----
+  float* dt = d_trans + b * 3;
+  const float* Td = translation + b * 3;
+  if (rc == RC_NAIVE) {
+    dt[0] = Dt[0]; dt[1] = Dt[1]; dt[2] = Dt[2];
+  } else {
+    const float Tsrc[3] = {P[3], P[7], P[11]};
+    float d1[3];
+    for (int i = 0; i < 3; ++i) d1[i] = Td[i] * sd.v[i] + mu.v[i];
+    const float z2 = Tsrc[2] / expf(d1[2]);
+    if (rc == RC_CAMERA || rc == RC_MODEL) {
+      dt[0] = (Dt[0] * (sd.v[0] * z2) + Dt[1] * 0.f) + Dt[2] * 0.f;
+      dt[1] = (Dt[0] * 0.f + Dt[1] * (sd.v[1] * z2)) + Dt[2] * 0.f;
+      const float share = -sd.v[2] * z2;
+      dt[2] = (Dt[0] * (share * (d1[0] + Tsrc[0] / Tsrc[2])) + Dt[1] * (share * (d1[1] + Tsrc[1] / Tsrc[2]))) +
+              Dt[2] * (-sd.v[2] * z2);
+    } else {
+      dt[0] = (Dt[0] * (sd.v[0] * Tsrc[2]) + Dt[1] * 0.f) + Dt[2] * 0.f;
+      dt[1] = (Dt[0] * 0.f + Dt[1] * (sd.v[1] * Tsrc[2])) + Dt[2] * 0.f;
+      dt[2] = (Dt[0] * 0.f + Dt[1] * 0.f) + Dt[2] * (-sd.v[2] * z2);
+    }
+  }
+  // ---- rotation: Rm_delta_diff then quat2mat_backward ----
+  float D[9];
+  if (rc == RC_MODEL) {  // Rm_src^T · Rm_tgt_diff
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) D[i * 3 + j] = (P[0 * 4 + i] * Dr[0 * 3 + j] + P[1 * 4 + i] * Dr[1 * 3 + j]) + P[2 * 4 + i] * Dr[2 * 3 + j];
+  } else if (rc == RC_NAIVE) {
+    for (int i = 0; i < 9; ++i) D[i] = Dr[i];
+  } else {  // Rm_tgt_diff · Rm_src^T
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) D[i * 3 + j] = (Dr[i * 3 + 0] * P[j * 4 + 0] + Dr[i * 3 + 1] * P[j * 4 + 1]) + Dr[i * 3 + 2] * P[j * 4 + 2];
+  }
+  const float* q = rotation + b * 4;
+  float* dq = d_rot + b * 4;
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  const float Nq = ((w * w + x * x) + y * y) + z * z;
+  const double dn = (double)(Nq - 1.f);
+  if (!(-1e-4 < dn && dn < 1e-4)) { dq[0] = dq[1] = dq[2] = dq[3] = 0.f; return; }
+  const float Ns = sqrtf(Nq);
+  const float w_ = w / Ns, x_ = x / Ns, y_ = y / Ns, z_ = z / Ns;
+  // transform3d.py:223-270 — float32 nine-term sums, left to right
+  float wd = 0.f * D[0];
+  wd = wd - z_ * D[1]; wd = wd + y_ * D[2]; wd = wd + z_ * D[3]; wd = wd + 0.f * D[4];
+  wd = wd - x_ * D[5]; wd = wd - y_ * D[6]; wd = wd + x_ * D[7]; wd = wd + 0.f * D[8];
+  float xd = 0.f * D[0];
+  xd = xd + y_ * D[1]; xd = xd + z_ * D[2]; xd = xd + y_ * D[3]; xd = xd - (2.f * x_) * D[4];
+  xd = xd - w_ * D[5]; xd = xd + z_ * D[6]; xd = xd + w_ * D[7]; xd = xd - (2.f * x_) * D[8];
+  float yd = (-2.f * y_) * D[0];
+  yd = yd + x_ * D[1]; yd = yd + w_ * D[2]; yd = yd + x_ * D[3]; yd = yd + 0.f * D[4];
+  yd = yd + z_ * D[5]; yd = yd - w_ * D[6]; yd = yd + z_ * D[7]; yd = yd - (2.f * y_) * D[8];
+  float zd = (-2.f * z_) * D[0];
+  zd = zd - w_ * D[1]; zd = zd + x_ * D[2]; zd = zd + w_ * D[3]; zd = zd - (2.f * z_) * D[4];
+  zd = zd + y_ * D[5]; zd = zd + x_ * D[6]; zd = zd + y_ * D[7]; zd = zd + 0.f * D[8];
+  const double wD = (double)wd * 2.0, xD = (double)xd * 2.0, yD = (double)yd * 2.0, zD = (double)zd * 2.0;
+  const float Ns3 = Ns * Ns * Ns;  // Nq_sqrt ** 3, float32
+  const double share = (double)Ns3 * ((((double)w * wD + (double)x * xD) + (double)y * yD) + (double)z * zD);
+  dq[0] = (float)((double)Ns * wD - (double)w * share);
+  dq[1] = (float)((double)Ns * xD - (double)x * share);
+  dq[2] = (float)((double)Ns * yD - (double)y * share);
+  dq[3] = (float)((double)Ns * zD - (double)z * share);
+}
+
+Vec3d vec3d_from(const float* h, double dflt) {
+  Vec3d v;
+  for (int i = 0; i < 3; ++i) v.v[i] = h ? (double)h[i] : dflt;
+  return v;
+}
+Vec3 vec3_from(const float* h, float dflt) {
+  Vec3 v;
+  for (int i = 0; i < 3; ++i) v.v[i] = h ? h[i] : dflt;
+  return v;
+}
+
+}  // namespace
+
+extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
+                                   const float* se3, const float* T_means_host, const float* T_stds_host,
+                                   int rot_coord, int B) {
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
+  hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
+                     pose_src, se3, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_transform3d_forward(deepim_ctx* ctx, float* out, const float* points, const float* rotation,
+                                          const float* translation, const float* pose_src,
+                                          const float* T_means_host, const float* T_stds_host, int rot_coord, int B,
+                                          int N) {
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "transform3d: unknown rot_coord");
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)B * 12 * sizeof(float), &scratch);
+  if (rc) return rc;
+  float* rt = (float*)scratch;
+  hipLaunchKernelGGL(t3d_prepare_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rt, rotation, translation,
+                     pose_src, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+  hipLaunchKernelGGL(t3d_apply_kernel, dim3(di_div_up(N, 256), B), dim3(256), 0, ctx->stream, out, points, rt, N);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_transform3d_backward(deepim_ctx* ctx, float* d_rotation, float* d_translation,
+                                           const float* out_grad, const float* points, const float* rotation,
+                                           const float* translation, const float* pose_src,
+                                           const float* T_means_host, const float* T_stds_host, int rot_coord, int B,
+                                           int N) {
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "transform3d: unknown rot_coord");
+  hipLaunchKernelGGL(t3d_backward_kernel, dim3(B), dim3(256), 0, ctx->stream, d_rotation, d_translation, out_grad,
+                     points, rotation, translation, pose_src, vec3_from(T_means_host, 0.f), vec3_from(T_stds_host, 1.f),
+                     rot_coord, N);
+  DI_LAUNCH_CHECK();
+  return 0;
+}

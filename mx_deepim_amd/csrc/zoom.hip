@@ -1,0 +1,474 @@
+// Z-group: zoom-in crop/warp.
+//   Z0 MXNet GridGenerator(affine)+BilinearSampler (third-party, call sites zoom_mask.py:96-107)
+//   Z1 zoom_mask.py:29-112            Z2 zoom_image_with_factor.py:31-65
+//   Z3 zoom_image.py:26-107           Z4 zoom_depth.py:24-44
+//   Z5 zoom_flow.py:28-71             Z6 zoom_mask_with_factor.py:29-64
+//   Z7 zoom_trans.py:22-74
+//
+// Three kernels: (1) per-sample bounding boxes of the two validity maps
+// (wavefront min/max reductions via DPP row/bank shuffles + one atomic per block),
+// (2) one thread per sample turns boxes + projected object centre into the zoom
+// factor with the reference's float64/float32 promotion pattern, (3) one generic
+// affine bilinear resampler that serves every Z op through a small by-value
+// channel plan (pre-op, post-op per channel) — lanes run along W so writes are
+// full 256 B wave stores and the 4-tap reads hit the same few source rows.
+// HBM-bound: algorithmic bytes = crop-region read + full-frame write per channel.
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+// ---------------------------------------------------------------- bbox ----
+enum BBoxMode { BB_MASK_GT = 0 /* v > 0.3 */, BB_MASK_RENDERED = 1 /* v > 0.2 */, BB_IMAGE = 2 /* sum_c(v+mean) > 0.01 */ };
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ void bbox_init_kernel(int* __restrict__ box, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) box[i] = (i & 1) ? -1 : INT_MAX;  // {minx,maxx,miny,maxy}
+}
+
+// grid (rows/ROWS_PER_BLOCK, B, 2 maps); block 256 threads sweep ROWS_PER_BLOCK rows
+constexpr int BB_ROWS = 8;
+__global__ __launch_bounds__(256) void bbox_kernel(int* __restrict__ box, const float* __restrict__ map0,
+                                                   const float* __restrict__ map1, int mode0, int mode1, Vec3 means,
+                                                   int H, int W) {
+  const int b = blockIdx.y, m = blockIdx.z;
+  const float* src = m == 0 ? map0 : map1;
+  const int mode = m == 0 ? mode0 : mode1;
+  const size_t plane = (size_t)H * W;
+  const int nch = mode == BB_IMAGE ? 3 : 1;
+  src += (size_t)b * nch * plane;
+  const int r0 = blockIdx.x * BB_ROWS;
+  int minx = INT_MAX, maxx = -1, miny = INT_MAX, maxy = -1;
+  for (int r = r0; r < min(r0 + BB_ROWS, H); ++r) {
+    for (int x = threadIdx.x; x < W; x += 256) {
+      const size_t p = (size_t)r * W + x;
+      bool valid;
+      if (mode == BB_MASK_GT) valid = src[p] > 0.3f;
+      else if (mode == BB_MASK_RENDERED) valid = src[p] > 0.2f;
+      else {
+        float s = (src[p] + means.v[0]) + (src[plane + p] + means.v[1]);
+        s = s + (src[2 * plane + p] + means.v[2]);
+        valid = s > 0.01f;
+      }
+      if (valid) { minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, r); maxy = max(maxy, r); }
+    }
+  }
+  minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+  __shared__ int red[4][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[wave][0] = minx; red[wave][1] = maxx; red[wave][2] = miny; red[wave][3] = maxy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) {
+      minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]);
+      miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
+    }
+    int* o = box + (b * 2 + m) * 4;
+    if (maxx >= 0) { atomicMin(o + 0, minx); atomicMax(o + 1, maxx); atomicMin(o + 2, miny); atomicMax(o + 3, maxy); }
+  }
+}
+
+// ---------------------------------------------------------- zoom factor ----
+// zoom_mask.py:47-103 / zoom_image.py:41-98, NumPy-1.x scalar promotion: K·t and the
+// centre are float32; distances to int64 box edges are float64; tx,ty are float32
+// when the centre is the projected one (float32 scalar / python int) and float64 in
+// the fallback branch; everything is stored to float32 at the end.
+__global__ void zoom_factor_kernel(float* __restrict__ zoom_factor, int* __restrict__ status,
+                                   const int* __restrict__ box, const float* __restrict__ src_pose, Mat3 K, int B,
+                                   int H, int W) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int* real = box + (b * 2 + 0) * 4;
+  const int* rend = box + (b * 2 + 1) * 4;
+  float* zf = zoom_factor + b * 4;
+  if (real[1] < 0) {  // reference raises ValueError (np.min of empty) — flag it
+    const float nanv = __int_as_float(0x7fc00000);
+    zf[0] = zf[1] = zf[2] = zf[3] = nanv;
+    atomicOr(status, 1);
+    return;
+  }
+  const double rsx = real[0], rex = real[1], rsy = real[2], rey = real[3];
+  const float* t = src_pose + b * 12;
+  const float t0 = t[3], t1 = t[7], t2 = t[11];
+  const float c0 = K.v[0] * t0 + K.v[1] * t1 + K.v[2] * t2;
+  const float c1 = K.v[3] * t0 + K.v[4] * t1 + K.v[5] * t2;
+  const float c2 = K.v[6] * t0 + K.v[7] * t1 + K.v[8] * t2;
+  const float cxf = c0 / c2, cyf = c1 / c2;
+  double osx, oex, osy, oey, zcx, zcy;
+  float txf, tyf;
+  if (rend[1] < 0) {
+    osx = rsx; oex = rex; osy = rsy; oey = rey;
+    zcx = (rsx + rex) * 0.5;
+    zcy = (rsy + rey) * 0.5;
+    txf = (float)(zcx / W * 2 - 1);
+    tyf = (float)(zcy / H * 2 - 1);
+  } else {
+    osx = rend[0]; oex = rend[1]; osy = rend[2]; oey = rend[3];
+    zcx = (double)cxf;
+    zcy = (double)cyf;
+    txf = cxf / (float)W * 2.f - 1.f;
+    tyf = cyf / (float)H * 2.f - 1.f;
+  }
+  const double left = fmax(zcx - osx, zcx - rsx);
+  const double right = fmax(oex - zcx, rex - zcx);
+  const double up = fmax(zcy - osy, zcy - rsy);
+  const double down = fmax(rey - zcy, oey - zcy);
+  const double crop = fmax(fmax(0.75 * right, 0.75 * left), fmax(up, down)) * 1.4 * 2;
+  const float wx = (float)(crop / H);
+  zf[0] = wx; zf[1] = wx; zf[2] = txf; zf[3] = tyf;
+}
+
+// ------------------------------------------------------------ resampler ----
+enum ChanFlags {
+  CF_PRE_BIN02 = 1,      // v = v > 0.2 ? 1 : 0 before sampling (zoom_mask.py:40-41)
+  CF_POST_ROUND = 2,     // roundf (mx.nd.round, half away from zero)
+  CF_POST_DIV255 = 4,    // /255 (deepIM_flownet.py:35-36)
+  CF_POST_MUL_WX = 8,    // *wx (zoom_flow.py:62)
+  CF_POST_DIV_WX = 16,   // /wx (zoom_flow.py:64)
+  CF_POST_ROUND_M045 = 32,  // round(v - 0.45) (zoom_flow.py:70-72)
+  CF_HIGHLIGHT = 64,     // maximum(v, centre map) before un-mean (zoom_image_with_factor.py:59-60)
+  CF_HIGHLIGHT_RED = 128,
+  CF_PRE_SIGMOID = 256,  // v = sigmoid(v) before the pre-binarise (mask head, deepIM_flownet.py:650)
+};
+struct Chan {
+  const float* src;  // plane of sample 0
+  float* dst;
+  long src_bstride, dst_bstride;  // elements between samples
+  float mean;                     // added before sampling, subtracted after
+  int flags;
+};
+constexpr int MAX_CHAN = 10;
+struct Plan {
+  Chan ch[MAX_CHAN];
+  int n;
+  int inverse;  // build the inverse zoom from the stored factor (zoom_flow.py:36-44)
+};
+
+struct Affine { float wx, wy, tx, ty, wx_in; };
+
+__device__ __forceinline__ Affine load_affine(const float* __restrict__ zoom_factor, int b, int inverse, int H, int W) {
+  const float wx_in = zoom_factor[b * 4 + 0], wy_in = zoom_factor[b * 4 + 1];
+  const float tx_in = zoom_factor[b * 4 + 2], ty_in = zoom_factor[b * 4 + 3];
+  Affine a;
+  a.wx_in = wx_in;
+  if (!inverse) { a.wx = wx_in; a.wy = wy_in; a.tx = tx_in; a.ty = ty_in; return a; }
+  a.wx = 1.f / wx_in;
+  a.wy = 1.f / wy_in;
+  const float crop_w = wx_in * (float)W, crop_h = wy_in * (float)H;
+  const double cx = (double)tx_in * 0.5 * W + 0.5 * W;
+  const double cy = (double)ty_in * 0.5 * H + 0.5 * H;
+  a.tx = (float)((W * 0.5 - cx) / (double)crop_w * 2);
+  a.ty = (float)((H * 0.5 - cy) / (double)crop_h * 2);
+  return a;
+}
+
+struct Taps {
+  int x0, y0;
+  bool in00, in01, in10, in11;  // [y][x]
+  float wy0, wx0;               // weight of the top row / left column
+};
+
+// GridGenerator(affine) + BilinearSampler coordinate math (Z0), f32, unfused
+__device__ __forceinline__ Taps make_taps(const Affine& a, int h, int w, int H, int W, float gx_step, float gy_step) {
+  const float xd = -1.0f + (float)w * gx_step;
+  const float yd = -1.0f + (float)h * gy_step;
+  const float xs = a.wx * xd + a.tx;
+  const float ys = a.wy * yd + a.ty;
+  const float xr = (xs + 1.f) * (float)(W - 1) / 2.f;
+  const float yr = (ys + 1.f) * (float)(H - 1) / 2.f;
+  Taps t;
+  // clamp before the int cast so huge/NaN coordinates are simply "all taps outside"
+  const float xf = floorf(fminf(fmaxf(xr, -4.f), (float)W + 4.f));
+  const float yf = floorf(fminf(fmaxf(yr, -4.f), (float)H + 4.f));
+  t.x0 = (int)xf;
+  t.y0 = (int)yf;
+  t.wx0 = 1.0f - (xr - xf);
+  t.wy0 = 1.0f - (yr - yf);
+  const bool x0in = t.x0 >= 0 && t.x0 <= W - 1, x1in = t.x0 + 1 >= 0 && t.x0 + 1 <= W - 1;
+  const bool y0in = t.y0 >= 0 && t.y0 <= H - 1, y1in = t.y0 + 1 >= 0 && t.y0 + 1 <= H - 1;
+  const bool finite = (xr == xr) && (yr == yr);
+  t.in00 = finite && y0in && x0in; t.in01 = finite && y0in && x1in;
+  t.in10 = finite && y1in && x0in; t.in11 = finite && y1in && x1in;
+  return t;
+}
+
+__device__ __forceinline__ float pre_op(float v, float mean, int flags) {
+  if (flags & CF_PRE_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+  if (flags & CF_PRE_BIN02) v = v > 0.2f ? 1.f : (v <= 0.2f ? 0.f : v);
+  return v + mean;
+}
+
+// BilinearSampler blend with the reference's float/double mix (bilinear_sampler.cc forward)
+__device__ __forceinline__ float blend(float tl, float tr, float bl, float br, float wy0, float wx0) {
+  const float t1 = tl * wy0 * wx0;
+  const double t2 = (double)(tr * wy0) * (1.0 - (double)wx0);
+  const double t3 = (double)bl * (1.0 - (double)wy0) * (double)wx0;
+  const double t4 = (double)br * (1.0 - (double)wy0) * (1.0 - (double)wx0);
+  return (float)((((double)t1 + t2) + t3) + t4);
+}
+
+// grid (ceil(W/256), H, B)
+__global__ __launch_bounds__(256) void resample_kernel(Plan plan, const float* __restrict__ zoom_factor, int H, int W,
+                                                       float gx_step, float gy_step) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (w >= W) return;
+  const Affine a = load_affine(zoom_factor, b, plan.inverse, H, W);
+  const Taps t = make_taps(a, h, w, H, W, gx_step, gy_step);
+  const long o00 = (long)t.y0 * W + t.x0;
+  const long opix = (long)h * W + w;
+  const bool spot = h >= (int)floorf((float)H / 2 - 5) && h < (int)ceilf((float)H / 2 + 5) &&
+                    w >= (int)floorf((float)W / 2 - 5) && w < (int)ceilf((float)W / 2 + 5);
+  for (int c = 0; c < plan.n; ++c) {
+    const Chan& ch = plan.ch[c];
+    const float* s = ch.src + (long)b * ch.src_bstride;
+    const int fl = ch.flags;
+    const float tl = t.in00 ? pre_op(s[o00], ch.mean, fl) : 0.f;
+    const float tr = t.in01 ? pre_op(s[o00 + 1], ch.mean, fl) : 0.f;
+    const float bl = t.in10 ? pre_op(s[o00 + W], ch.mean, fl) : 0.f;
+    const float br = t.in11 ? pre_op(s[o00 + W + 1], ch.mean, fl) : 0.f;
+    float v = blend(tl, tr, bl, br, t.wy0, t.wx0);
+    if (fl & CF_HIGHLIGHT) v = fmaxf(v, ((fl & CF_HIGHLIGHT_RED) && spot) ? 255.f : 0.f);
+    v = v - ch.mean;
+    if (fl & CF_POST_ROUND) v = roundf(v);
+    if (fl & CF_POST_DIV255) v = v / 255.0f;
+    if (fl & CF_POST_MUL_WX) v = v * a.wx_in;
+    if (fl & CF_POST_DIV_WX) v = v / a.wx_in;
+    if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
+    ch.dst[(long)b * ch.dst_bstride + opix] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void indices_kernel(int32_t* __restrict__ idx, const float* __restrict__ zoom_factor,
+                                                      int H, int W, float gx_step, float gy_step) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (w >= W) return;
+  const Affine a = load_affine(zoom_factor, b, 0, H, W);
+  const Taps t = make_taps(a, h, w, H, W, gx_step, gy_step);
+  const long plane = (long)H * W;
+  idx[((long)b * 2 + 0) * plane + (long)h * W + w] = t.x0;
+  idx[((long)b * 2 + 1) * plane + (long)h * W + w] = t.y0;
+}
+
+__global__ void zoom_trans_kernel(float* __restrict__ out, const float* __restrict__ zoom_factor,
+                                  const float* __restrict__ in, int mul, int scale_xy, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float wx = zoom_factor[b * 4 + 0];  // the reference reads wy from column 0 too (zoom_trans.py:31)
+  float x = in[b * 3 + 0], y = in[b * 3 + 1];
+  if (scale_xy) {
+    if (mul) { x = x * wx; y = y * wx; } else { x = x / wx; y = y / wx; }
+  }
+  out[b * 3 + 0] = x; out[b * 3 + 1] = y; out[b * 3 + 2] = in[b * 3 + 2];
+}
+
+int launch_resample(deepim_ctx* ctx, const Plan& plan, const float* zoom_factor, int B, int H, int W) {
+  if (B == 0) return 0;
+  const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
+  dim3 grid(di_div_up(W, 256), H, B);
+  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, ctx->stream, plan, zoom_factor, H, W, gx, gy);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+Chan make_chan(const float* src, float* dst, long sb, long db, float mean, int flags) {
+  Chan c; c.src = src; c.dst = dst; c.src_bstride = sb; c.dst_bstride = db; c.mean = mean; c.flags = flags;
+  return c;
+}
+
+Mat3 mat3_from(const float* h) { Mat3 m; for (int i = 0; i < 9; ++i) m.v[i] = h[i]; return m; }
+
+// boxes + factor; scratch layout: [B*2*4 int boxes]; status word lives in ctx->status
+int compute_zoom_factor(deepim_ctx* ctx, float* zoom_factor, const float* map0, const float* map1, int mode0, int mode1,
+                        const float* means3, const float* src_pose, const float* K_host, int B, int H, int W) {
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)(B * 8) * sizeof(int), &scratch);
+  if (rc) return rc;
+  int* box = (int*)scratch;
+  int* status = ctx->status;
+  Vec3 means = {{0, 0, 0}};
+  if (means3) for (int i = 0; i < 3; ++i) means.v[i] = means3[i];
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(di_div_up(B * 8, 256)), dim3(256), 0, ctx->stream, box, B * 8);
+  dim3 grid(di_div_up(H, BB_ROWS), B, 2);
+  hipLaunchKernelGGL(bbox_kernel, grid, dim3(256), 0, ctx->stream, box, map0, map1, mode0, mode1, means, H, W);
+  hipLaunchKernelGGL(zoom_factor_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, zoom_factor, status, box,
+                     src_pose, mat3_from(K_host), B, H, W);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int deepim_zoom_mask_forward(deepim_ctx* ctx, const float* mask_observed, const float* mask_gt_observed,
+                                        const float* mask_rendered, const float* src_pose, const float* K_host,
+                                        float* zoom_mask_observed, float* zoom_mask_gt_observed,
+                                        float* zoom_mask_rendered, float* zoom_factor, int B, int H, int W) {
+  if (B == 0) return 0;
+  int rc = compute_zoom_factor(ctx, zoom_factor, mask_gt_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
+                               src_pose, K_host, B, H, W);
+  if (rc) return rc;
+  const long p = (long)H * W;
+  Plan plan; plan.n = 3; plan.inverse = 0;
+  plan.ch[0] = make_chan(mask_observed, zoom_mask_observed, p, p, 0.f, CF_POST_ROUND);
+  plan.ch[1] = make_chan(mask_gt_observed, zoom_mask_gt_observed, p, p, 0.f, CF_POST_ROUND);
+  plan.ch[2] = make_chan(mask_rendered, zoom_mask_rendered, p, p, 0.f, CF_PRE_BIN02 | CF_POST_ROUND);
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+static void image_plan(Plan& plan, int base, const float* src, float* dst, long sb, long db, long plane,
+                       const float* means, int flags, int highlight) {
+  for (int c = 0; c < 3; ++c) {
+    int fl = flags;
+    if (highlight) fl |= CF_HIGHLIGHT | (c == 0 ? CF_HIGHLIGHT_RED : 0);
+    plan.ch[base + c] = make_chan(src + c * plane, dst + c * plane, sb, db, means[c], fl);
+  }
+}
+
+extern "C" int deepim_zoom_image_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                         const float* src_pose, const float* K_host, const float* pixel_means_host,
+                                         float* zoom_image_observed, float* zoom_image_rendered, float* zoom_factor,
+                                         int B, int H, int W) {
+  if (B == 0) return 0;
+  int rc = compute_zoom_factor(ctx, zoom_factor, image_observed, image_rendered, BB_IMAGE, BB_IMAGE, pixel_means_host,
+                               src_pose, K_host, B, H, W);
+  if (rc) return rc;
+  const long p = (long)H * W;
+  Plan plan; plan.n = 6; plan.inverse = 0;
+  image_plan(plan, 0, image_observed, zoom_image_observed, 3 * p, 3 * p, p, pixel_means_host, 0, 0);
+  image_plan(plan, 3, image_rendered, zoom_image_rendered, 3 * p, 3 * p, p, pixel_means_host, 0, 0);
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_zoom_image_with_factor_forward(deepim_ctx* ctx, const float* zoom_factor,
+                                                     const float* image_observed, const float* image_rendered,
+                                                     const float* pixel_means_host, int high_light_center,
+                                                     float* zoom_image_observed, float* zoom_image_rendered, int B,
+                                                     int H, int W) {
+  const long p = (long)H * W;
+  Plan plan; plan.n = 6; plan.inverse = 0;
+  image_plan(plan, 0, image_observed, zoom_image_observed, 3 * p, 3 * p, p, pixel_means_host, 0, 0);
+  image_plan(plan, 3, image_rendered, zoom_image_rendered, 3 * p, 3 * p, p, pixel_means_host, 0, high_light_center);
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_zoom_depth_forward(deepim_ctx* ctx, const float* zoom_factor, const float* depth_observed,
+                                         const float* depth_rendered, float* zoom_depth_observed,
+                                         float* zoom_depth_rendered, int B, int H, int W) {
+  const long p = (long)H * W;
+  Plan plan; plan.n = 2; plan.inverse = 0;
+  plan.ch[0] = make_chan(depth_observed, zoom_depth_observed, p, p, 0.f, 0);
+  plan.ch[1] = make_chan(depth_rendered, zoom_depth_rendered, p, p, 0.f, 0);
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_zoom_flow_forward(deepim_ctx* ctx, const float* zoom_factor, const float* flow,
+                                        const float* flow_weights, float* zoom_flow, float* zoom_flow_weights,
+                                        int b_inv_zoom, int B, int H, int W) {
+  const long p = (long)H * W;
+  Plan plan; plan.n = 2; plan.inverse = b_inv_zoom ? 1 : 0;
+  const int fl = b_inv_zoom ? CF_POST_MUL_WX : CF_POST_DIV_WX;
+  plan.ch[0] = make_chan(flow, zoom_flow, 2 * p, 2 * p, 0.f, fl);
+  plan.ch[1] = make_chan(flow + p, zoom_flow + p, 2 * p, 2 * p, 0.f, fl);
+  if (!b_inv_zoom) {
+    DI_REQUIRE(flow_weights && zoom_flow_weights, "ZoomFlow: flow_weights required when b_inv_zoom is false");
+    plan.ch[2] = make_chan(flow_weights, zoom_flow_weights, 2 * p, 2 * p, 0.f, CF_POST_ROUND_M045);
+    plan.ch[3] = make_chan(flow_weights + p, zoom_flow_weights + p, 2 * p, 2 * p, 0.f, CF_POST_ROUND_M045);
+    plan.n = 4;
+  }
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_zoom_mask_with_factor_forward(deepim_ctx* ctx, const float* zoom_factor, const float* mask,
+                                                    float* zoom_mask, int b_inv_zoom, int B, int H, int W) {
+  const long p = (long)H * W;
+  Plan plan; plan.n = 1; plan.inverse = b_inv_zoom ? 1 : 0;
+  plan.ch[0] = make_chan(mask, zoom_mask, p, p, 0.f, CF_PRE_BIN02 | CF_POST_ROUND);
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+// mask head test path, fused: sigmoid → (>0.2) → inverse zoom → round → round (deepIM_flownet.py:647-666)
+extern "C" int deepim_mask_head_forward(deepim_ctx* ctx, float* mask_pred, float* prob, const float* logits,
+                                        const float* zoom_factor, int B, int H, int W) {
+  const long p = (long)H * W;
+  Plan plan; plan.n = 1; plan.inverse = 1;
+  plan.ch[0] = make_chan(logits, mask_pred, p, p, 0.f, CF_PRE_SIGMOID | CF_PRE_BIN02 | CF_POST_ROUND);
+  int rc = launch_resample(ctx, plan, zoom_factor, B, H, W);
+  if (rc || !prob) return rc;
+  return deepim_mask_logistic(ctx, prob, nullptr, logits, nullptr, 0.f, (size_t)B * p);
+}
+
+extern "C" int deepim_zoom_trans_forward(deepim_ctx* ctx, const float* zoom_factor, const float* trans_delta,
+                                         float* zoom_trans_delta, int b_inv_zoom, int B) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(zoom_trans_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, zoom_trans_delta,
+                     zoom_factor, trans_delta, b_inv_zoom ? 1 : 0, 1, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int deepim_zoom_trans_backward(deepim_ctx* ctx, const float* zoom_factor, const float* out_grad,
+                                          float* in_grad, int b_inv_zoom, int b_zoom_grad, int B) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(zoom_trans_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, in_grad, zoom_factor,
+                     out_grad, b_inv_zoom ? 1 : 0, b_zoom_grad ? 1 : 0, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                          const float* mask_observed, const float* mask_rendered,
+                                          const float* depth_observed, const float* depth_rendered,
+                                          const float* src_pose, const float* K_host, const float* pixel_means_host,
+                                          float* net_input, float* zoom_factor, int B, int H, int W) {
+  if (B == 0) return 0;
+  DI_REQUIRE(mask_observed && mask_rendered, "zoom_concat: masks are required (ZoomMask computes the factor)");
+  const long p = (long)H * W;
+  const int C = 8 + (depth_observed ? 2 : 0);
+  // test graph: mask_gt_observed ≡ mask_observed (deepIM_flownet.py:564)
+  int rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
+                               src_pose, K_host, B, H, W);
+  if (rc) return rc;
+  Plan plan; plan.inverse = 0;
+  int n = 0;
+  const long db = (long)C * p;
+  image_plan(plan, 0, image_observed, net_input, 3 * p, db, p, pixel_means_host, CF_POST_DIV255, 0);
+  image_plan(plan, 3, image_rendered, net_input + 3 * p, 3 * p, db, p, pixel_means_host, CF_POST_DIV255, 0);
+  n = 6;
+  if (depth_observed) {
+    plan.ch[n] = make_chan(depth_observed, net_input + n * p, p, db, 0.f, CF_POST_DIV255); ++n;
+    plan.ch[n] = make_chan(depth_rendered, net_input + n * p, p, db, 0.f, CF_POST_DIV255); ++n;
+  }
+  plan.ch[n] = make_chan(mask_observed, net_input + n * p, p, db, 0.f, CF_POST_ROUND); ++n;
+  plan.ch[n] = make_chan(mask_rendered, net_input + n * p, p, db, 0.f, CF_PRE_BIN02 | CF_POST_ROUND); ++n;
+  plan.n = n;
+  return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W) {
+  if (B == 0) return 0;
+  const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
+  dim3 grid(di_div_up(W, 256), H, B);
+  hipLaunchKernelGGL(indices_kernel, grid, dim3(256), 0, ctx->stream, idx, zoom_factor, H, W, gx, gy);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// status word of the last zoom-factor computation: bit0 = an observed mask/image was empty
+// (sticky until read; reading clears it)
+extern "C" int deepim_zoom_status(deepim_ctx* ctx, int* status) {
+  DI_CHECK(hipMemcpyAsync(status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  DI_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(int), ctx->stream));
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}

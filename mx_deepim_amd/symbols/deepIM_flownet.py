@@ -1,0 +1,297 @@
+"""FlowNetS-backboned matching network of DeepIM as a resident device pipeline.
+
+Mirrors ``deepim/symbols/deepIM_flownet.py`` (reference): ``get_symbol`` / ``get_test_symbol_share``
+(:548-735), ``get_convs`` (:32-169) and ``init_weights`` (:753-845) keep their names and the MXNet
+parameter naming (``flow_conv1_weight`` ... ``trans_bias``), but instead of an MXNet Symbol the
+"symbol" is a bound chain of HIP launches on one stream:
+
+    zoom (ZoomMask + ZoomImageWithFactor [+ ZoomDepth] + /255 + Concat, one fused front end)
+    → 10 × (Convolution + bias + LeakyReLU 0.1) on the fp32 matrix cores
+    → fc6 → fc7 → rot/trans + inverse ZoomTrans → se3
+    [→ FlowNetS refinement decoder → mask / flow heads when the config keeps them in the test graph]
+    → RT_transform (pose update, lib/pair_matching/RT_transform.py:127-151)
+
+All activations, weights and the per-iteration pre-staged frames stay in HBM; nothing crosses
+PCIe inside the refinement loop.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from ..config import ROT_COORD_CODE, default_config
+from ..runtime import Context, DeviceArray, lib
+
+# name, Cout, kernel, stride, pad  (deepIM_flownet.py:63-107)
+ENCODER = [
+    ("flow_conv1", 64, 7, 2, 3),
+    ("conv2", 128, 5, 2, 2),
+    ("conv3", 256, 5, 2, 2),
+    ("conv3_1", 256, 3, 1, 1),
+    ("conv4", 512, 3, 2, 1),
+    ("conv4_1", 512, 3, 1, 1),
+    ("conv5", 512, 3, 2, 1),
+    ("conv5_1", 512, 3, 1, 1),
+    ("conv6", 1024, 3, 2, 1),
+    ("conv6_1", 1024, 3, 1, 1),
+]
+SLOPE = 0.1
+
+
+def _out_hw(h, w, k, s, p):
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+class deepIM_flownet(object):
+    def __init__(self):
+        self.cfg = None
+        self.ctx = None
+        self.B = 0
+        self.params = {}    # name -> DeviceArray (raw MXNet-layout parameters)
+        self.packed = {}    # conv/deconv name -> packed weights
+        self.act = {}
+
+    # ------------------------------------------------------------------ graph description
+    def get_symbol(self, cfg=None, is_train=False):
+        if cfg is None:
+            cfg = default_config()
+        if cfg.network.REGRESSOR_NUM != 1:
+            raise Exception("NOT IMPLEMENTED")  # deepIM_flownet.py:748
+        if is_train:
+            raise NotImplementedError("training graph (backward through the conv stack) is out of scope (SURVEY §8f)")
+        self.cfg = cfg
+        return self.get_test_symbol_share(cfg)
+
+    def get_test_symbol_share(self, cfg):
+        n = cfg.network
+        self.input_mask = bool(n.INPUT_MASK)
+        self.input_depth = bool(n.INPUT_DEPTH)
+        # deepIM_flownet.py:624 / :676 — which heads stay in the test graph
+        self.with_mask_head = bool(n.PRED_MASK) and (cfg.TEST.UPDATE_MASK not in ["init", "box_rendered"]
+                                                     or not cfg.TEST.FAST_TEST)
+        self.with_flow_head = bool(n.PRED_FLOW) and not cfg.TEST.FAST_TEST
+        self.with_decoder = self.with_mask_head or self.with_flow_head
+        self.cin = 6 + (2 if self.input_depth else 0) + (2 if self.input_mask else 0)
+        self.H, self.W = cfg.SCALES[0]
+        self.K = np.ascontiguousarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
+        # Prop-side channel reversal of the means (zoom_image_with_factor.py:79-81)
+        self.pixel_means = np.ascontiguousarray(np.asarray(n.PIXEL_MEANS, np.float32).reshape(3)[::-1])
+        self.T_means = np.ascontiguousarray(cfg.dataset.trans_means, dtype=np.float32).reshape(3)
+        self.T_stds = np.ascontiguousarray(cfg.dataset.trans_stds, dtype=np.float32).reshape(3)
+        self.rot_coord = ROT_COORD_CODE[n.ROT_COORD.lower()]
+        self.normalize_flow = float(cfg.dataset.NORMALIZE_FLOW)
+        return self
+
+    def arg_shape_dict(self):
+        """MXNet parameter names → shapes (what `sym.infer_shape` reports for the weights)."""
+        d = {}
+        cin = self.cin
+        for name, cout, k, s, p in ENCODER:
+            d[name + "_weight"] = (cout, cin, k, k)
+            d[name + "_bias"] = (cout,)
+            cin = cout
+        d["fc6_weight"], d["fc6_bias"] = (256, 1024 * 8 * 10), (256,)
+        d["fc7_weight"], d["fc7_bias"] = (256, 256), (256,)
+        d["rot_weight"], d["rot_bias"] = (4, 256), (4,)
+        d["trans_weight"], d["trans_bias"] = (3, 256), (3,)
+        if self.with_decoder:
+            d["Convolution1_weight"], d["Convolution1_bias"] = (2, 1024, 3, 3), (2,)
+            d["deconv5_weight"], d["deconv5_bias"] = (1024, 512, 4, 4), (512,)
+            d["upsample_flow6to5_weight"], d["upsample_flow6to5_bias"] = (2, 2, 4, 4), (2,)
+            d["Convolution2_weight"], d["Convolution2_bias"] = (2, 1026, 3, 3), (2,)
+            d["deconv4_weight"], d["deconv4_bias"] = (1026, 256, 4, 4), (256,)
+            d["upsample_flow5to4_weight"], d["upsample_flow5to4_bias"] = (2, 2, 4, 4), (2,)
+        if self.with_mask_head:
+            d["mask_conv3_weight"], d["mask_conv3_bias"] = (1, 770, 3, 3), (1,)
+            d["mask_upsampling_weight"] = (1, 1, 32, 32)
+        if self.with_flow_head:
+            d["Convolution3_weight"], d["Convolution3_bias"] = (2, 770, 3, 3), (2,)
+            d["upsampling_weight"] = (2, 1, 32, 32)
+        return d
+
+    @staticmethod
+    def _init_bilinear(shape):
+        """MXNet Initializer._init_bilinear (used at deepIM_flownet.py:808-822)."""
+        w = np.zeros(int(np.prod(shape)), dtype=np.float32)
+        f = np.ceil(shape[3] / 2.0)
+        c = (2 * f - 1 - f % 2) / (2.0 * f)
+        for i in range(w.size):
+            x = i % shape[3]
+            y = (i // shape[3]) % shape[2]
+            w[i] = (1 - abs(x / f - c)) * (1 - abs(y / f - c))
+        return w.reshape(shape)
+
+    def init_weights(self, cfg=None, arg_params=None, aux_params=None, seed=2333):
+        """Seeded synthetic parameters (no checkpoints offline): He-normal conv/FC so activations stay
+        O(1) through the 10 layers, rot/trans as the reference initialises them
+        (deepIM_flownet.py:795-803), bilinear upsampling kernels (:808-822)."""
+        rng = np.random.default_rng(seed)
+        arg_params = {} if arg_params is None else arg_params
+        for name, shape in self.arg_shape_dict().items():
+            if name in arg_params:
+                continue
+            if name.endswith("upsampling_weight"):
+                arg_params[name] = self._init_bilinear(shape)
+            elif name.endswith("_bias"):
+                arg_params[name] = (0.01 * rng.standard_normal(shape)).astype(np.float32)
+            elif name == "rot_weight":
+                w = rng.random(shape) * 0.01
+                w[0, :] = rng.random(shape[1]) + 0.01
+                arg_params[name] = w.astype(np.float32)
+            elif name == "trans_weight":
+                arg_params[name] = (0.01 * rng.standard_normal(shape)).astype(np.float32)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                if name.startswith("deconv") or name.startswith("upsample_flow"):
+                    fan_in = shape[0] * 4  # 2x2 taps reach each output of a k4 s2 transposed conv
+                gain = 2.0 / (1 + SLOPE ** 2)
+                arg_params[name] = (rng.standard_normal(shape) * np.sqrt(gain / fan_in)).astype(np.float32)
+        return arg_params
+
+    # ------------------------------------------------------------------ bind
+    def bind(self, ctx: Context, batch_size: int, arg_params: dict):
+        assert self.cfg is not None, "call get_symbol first"
+        self.ctx, self.B = ctx, int(batch_size)
+        B, H, W, h = self.B, self.H, self.W, ctx.handle
+        shapes = self.arg_shape_dict()
+        for name, shape in shapes.items():
+            assert name in arg_params, name
+            a = np.ascontiguousarray(arg_params[name], dtype=np.float32)
+            assert tuple(a.shape) == tuple(shape), (name, a.shape, shape)
+            self.params[name] = ctx.array(a)
+        # one-time weight re-layout into MFMA tile order
+        for name, shape in shapes.items():
+            if not name.endswith("_weight") or len(shape) != 4 or name.endswith("upsampling_weight"):
+                continue
+            base = name[: -len("_weight")]
+            if base.startswith("deconv") or base.startswith("upsample_flow"):
+                cin, cout = shape[0], shape[1]
+                nb = lib.load().deepim_deconv_packed_size(cin, cout)
+                pk = DeviceArray(ctx, (nb // 4,))
+                lib.deepim_deconv_pack_weights(h, pk, self.params[name], cin, cout)
+            else:
+                cout, cin, kh, kw = shape
+                nb = lib.load().deepim_conv_packed_size(cout, cin, kh, kw)
+                pk = DeviceArray(ctx, (nb // 4,))
+                lib.deepim_conv_pack_weights(h, pk, self.params[name], cout, cin, kh, kw)
+            self.packed[base] = pk
+        # activations
+        A = self.act
+        A["net_input"] = ctx.empty((B, self.cin, H, W))
+        A["zoom_factor"] = ctx.empty((B, 4))
+        hh, ww, cin = H, W, self.cin
+        self.enc_geom = []
+        for name, cout, k, s, p in ENCODER:
+            ho, wo = _out_hw(hh, ww, k, s, p)
+            A[name] = ctx.empty((B, cout, ho, wo))
+            self.enc_geom.append((name, cin, hh, ww, cout, k, s, p))
+            hh, ww, cin = ho, wo, cout
+        A["fc6"], A["fc7"], A["se3"] = ctx.empty((B, 256)), ctx.empty((B, 256)), ctx.empty((B, 7))
+        A["pose_est"] = ctx.empty((B, 3, 4))
+        if self.with_decoder:
+            A["flow6"] = ctx.empty((B, 2, 8, 10))
+            A["Concat2"] = ctx.empty((B, 1026, 15, 20))
+            A["flow5"] = ctx.empty((B, 2, 15, 20))
+            A["Concat3"] = ctx.empty((B, 770, 30, 40))
+        if self.with_mask_head:
+            A["mask_lowres"] = ctx.empty((B, 1, 30, 40))
+            A["mask_logits"] = ctx.empty((B, 1, H, W))
+            A["mask_observed_pred"] = ctx.empty((B, 1, H, W))
+        if self.with_flow_head:
+            A["flow_lowres"] = ctx.empty((B, 2, 30, 40))
+            A["zoom_flow_est"] = ctx.empty((B, 2, H, W))
+            A["flow_est"] = ctx.empty((B, 2, H, W))
+        ctx.sync()
+        return self
+
+    # ------------------------------------------------------------------ forward pieces
+    def _conv(self, name, src, dst, B, cin, h, w, cout, k, s, p, slope, ctotal=0, coff=0):
+        lib.deepim_conv2d_forward(self.ctx.handle, dst, src, self.packed[name], self.params[name + "_bias"], B, cin, h,
+                                  w, cout, k, k, s, p, ctypes.c_float(slope), ctotal, coff)
+
+    def _deconv(self, name, src, dst, B, cin, h, w, cout, ho, wo, slope, ctotal, coff):
+        lib.deepim_deconv4x4s2_crop_forward(self.ctx.handle, dst, src, self.packed[name], self.params[name + "_bias"],
+                                            B, cin, h, w, cout, ho, wo, 1, 1, ctypes.c_float(slope), ctotal, coff)
+
+    def zoom(self, data):
+        A, h = self.act, self.ctx.handle
+        if self.input_mask:
+            lib.deepim_zoom_concat_forward(
+                h, data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
+                data.get("depth_observed") if self.input_depth else None,
+                data.get("depth_rendered") if self.input_depth else None,
+                data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], self.B, self.H, self.W)
+        else:
+            # ZoomImage variant (deepIM_flownet.py:594-605): factor from non-black pixels; /255 + Concat after
+            raise NotImplementedError("INPUT_MASK=False test graph: use operator_py.ZoomImage + conv stack directly")
+
+    def encoder(self):
+        A = self.act
+        src = A["net_input"]
+        for name, cin, h, w, cout, k, s, p in self.enc_geom:
+            self._conv(name, src, A[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
+            src = A[name]
+
+    def pose_head(self):
+        A, P, h, B = self.act, self.params, self.ctx.handle, self.B
+        flat = A["conv6_1"].reshape((B, -1))
+        lib.deepim_fc_forward(h, A["fc6"], flat, P["fc6_weight"], P["fc6_bias"], B, flat.shape[1], 256,
+                              ctypes.c_float(SLOPE))
+        lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256,
+                              ctypes.c_float(SLOPE))
+        lib.deepim_pose_head_forward(h, A["se3"], A["fc7"], P["rot_weight"], P["rot_bias"], P["trans_weight"],
+                                     P["trans_bias"], A["zoom_factor"], B, 256)
+
+    def decoder(self):
+        """FlowNetS refinement (deepIM_flownet.py:120-167)."""
+        A, h, B = self.act, self.ctx.handle, self.B
+        self._conv("Convolution1", A["conv6_1"], A["flow6"], B, 1024, 8, 10, 2, 3, 1, 1, 1.0)
+        lib.deepim_copy_channels(h, A["Concat2"], 1026, 0, A["conv5_1"], 512, B, 15 * 20)
+        self._deconv("deconv5", A["conv6_1"], A["Concat2"], B, 1024, 8, 10, 512, 15, 20, SLOPE, 1026, 512)
+        self._deconv("upsample_flow6to5", A["flow6"], A["Concat2"], B, 2, 8, 10, 2, 15, 20, 1.0, 1026, 1024)
+        self._conv("Convolution2", A["Concat2"], A["flow5"], B, 1026, 15, 20, 2, 3, 1, 1, 1.0)
+        lib.deepim_copy_channels(h, A["Concat3"], 770, 0, A["conv4_1"], 512, B, 30 * 40)
+        self._deconv("deconv4", A["Concat2"], A["Concat3"], B, 1026, 15, 20, 256, 30, 40, SLOPE, 770, 512)
+        self._deconv("upsample_flow5to4", A["flow5"], A["Concat3"], B, 2, 15, 20, 2, 30, 40, 1.0, 770, 768)
+
+    def heads(self):
+        A, P, h, B, H, W = self.act, self.params, self.ctx.handle, self.B, self.H, self.W
+        if self.with_mask_head:  # deepIM_flownet.py:627-666
+            self._conv("mask_conv3", A["Concat3"], A["mask_lowres"], B, 770, 30, 40, 1, 3, 1, 1, 1.0)
+            lib.deepim_upsample16_crop_forward(h, A["mask_logits"], A["mask_lowres"], P["mask_upsampling_weight"], B, 1,
+                                               30, 40, H, W, 8, 8, ctypes.c_float(1.0))
+            lib.deepim_mask_head_forward(h, A["mask_observed_pred"], None, A["mask_logits"], A["zoom_factor"], B, H, W)
+        if self.with_flow_head:  # deepIM_flownet.py:677-713
+            self._conv("Convolution3", A["Concat3"], A["flow_lowres"], B, 770, 30, 40, 2, 3, 1, 1, 1.0)
+            lib.deepim_upsample16_crop_forward(h, A["zoom_flow_est"], A["flow_lowres"], P["upsampling_weight"], B, 2, 30,
+                                               40, H, W, 8, 8, ctypes.c_float(self.normalize_flow))
+            lib.deepim_zoom_flow_forward(h, A["zoom_factor"], A["zoom_flow_est"], None, A["flow_est"], None, 1, B, H, W)
+
+    def pose_update(self, src_pose, pose_out=None):
+        """RT_transform of every pair (tester.py:391-398)."""
+        out = self.act["pose_est"] if pose_out is None else pose_out
+        lib.deepim_rt_transform(self.ctx.handle, out, None, src_pose, self.act["se3"], self.T_means, self.T_stds,
+                                self.rot_coord, self.B)
+        return out
+
+    def forward(self, data):
+        """One network forward = `Predictor.predict` (tester.py:45-47). Returns the output dict (device arrays)."""
+        self.zoom(data)
+        self.encoder()
+        if self.with_decoder:
+            self.decoder()
+            self.heads()
+        self.pose_head()
+        out = {"se3": self.act["se3"], "zoom_factor": self.act["zoom_factor"]}
+        if self.with_mask_head:
+            out["mask_observed_pred"] = self.act["mask_observed_pred"]
+        if self.with_flow_head:
+            out["flow_est_crop"] = self.act["flow_est"]
+        return out
+
+    def refine_iteration(self, data, pose_out=None):
+        """One pose-refinement iteration for the bound batch: zoom → network → inverse ZoomTrans →
+        RT_transform.  `data["src_pose"]` is the current estimate; returns the refined (B,3,4) poses."""
+        self.forward(data)
+        return self.pose_update(data["src_pose"], pose_out)

@@ -1,0 +1,65 @@
+"""H-group oracle: losses and GroupPicker.  TEST INFRASTRUCTURE ONLY.
+Follows deepim/symbols/deepIM_flownet.py:200-207 (flow loss), :265-312 (point matching),
+:342-349 (LogisticRegressionOutput) with MXNet's documented abs / square / smooth_l1 / MakeLoss
+definitions (third-party: PARITY UNPINNED), and deepim/operator_py/group_picker.py:22-56."""
+import numpy as np
+
+f32 = np.float32
+
+
+def _loss_fn(x, loss_type, sigma):
+    if loss_type == "L1":
+        return np.abs(x), np.sign(x)
+    if loss_type == "L2":
+        return x * x, 2 * x
+    s2 = f32(sigma) * f32(sigma)
+    small = np.abs(x) < f32(1.0) / s2
+    f = np.where(small, f32(0.5) * (f32(sigma) * x) * (f32(sigma) * x), np.abs(x) - f32(0.5) / s2)
+    df = np.where(small, s2 * x, np.where(x > 0, f32(1), f32(-1)))
+    return f.astype(f32), df.astype(f32)
+
+
+def point_matching_loss(est, gt, weights, normalize, loss_type="L1", sigma=1.0, grad_scale=1.0):
+    est, gt = np.asarray(est, f32), np.asarray(gt, f32)
+    x = ((est - gt) / f32(normalize)).astype(f32)
+    f, df = _loss_fn(x, loss_type, sigma)
+    w = np.ones_like(x) if weights is None else np.asarray(weights, f32)
+    loss = (w * f).astype(f32)
+    d_est = (f32(grad_scale) * w * df / f32(normalize)).astype(f32)
+    return loss, float(loss.astype(np.float64).sum()), d_est
+
+
+def flow_loss(est, gt, weights, normalize_flow, grad_scale=1.0):
+    est, gt = np.asarray(est, f32), np.asarray(gt, f32)
+    d = (est - gt / f32(normalize_flow)).astype(f32)
+    w = np.ones_like(d) if weights is None else np.asarray(weights, f32)
+    loss = (w * (d * d)).astype(f32)
+    return loss, float(loss.astype(np.float64).sum()), (f32(grad_scale) * w * f32(2) * d).astype(f32)
+
+
+def mask_logistic(logits, label, grad_scale=1.0):
+    logits = np.asarray(logits, f32)
+    p = (f32(1.0) / (f32(1.0) + np.exp(-logits, dtype=f32))).astype(f32)
+    g = None if label is None else ((p - np.asarray(label, f32)) * f32(grad_scale)).astype(f32)
+    return p, g
+
+
+def group_picker(x, group_idx, group_num):
+    x = np.asarray(x, f32)
+    cg = x.shape[1] // group_num
+    out = np.zeros((x.shape[0], cg), f32)
+    for b in range(x.shape[0]):
+        g = int(np.squeeze(group_idx[b]))
+        assert 0 <= g < group_num
+        out[b] = x[b, cg * g:cg * (g + 1)]
+    return out
+
+
+def group_picker_backward(out_grad, group_idx, group_num, C):
+    og = np.asarray(out_grad, f32)
+    cg = C // group_num
+    g_in = np.zeros((og.shape[0], C), f32)
+    for b in range(og.shape[0]):
+        g = int(np.squeeze(group_idx[b]))
+        g_in[b, cg * g:cg * (g + 1)] = og[b]
+    return g_in

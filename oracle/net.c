@@ -1,0 +1,117 @@
+/* N-group oracle: MXNet Convolution / Deconvolution / FullyConnected semantics in plain C.
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) — never linked into the product.
+ *
+ * Follows the layer definitions wired at deepim/symbols/deepIM_flownet.py:63-167 (conv stack),
+ * :176-200/:317-340 (heads + k32 s16 grouped upsampling) and MXNet 1.2's documented operator
+ * definitions (third-party, not vendored: PARITY UNPINNED by reference tests; cross-checked
+ * against torch-CPU in tests/).  Accumulation is a float32 fmaf chain in (ci,ky,kx) order per
+ * output element — the same order the MI355X fp32-MFMA kernel uses, so conv/deconv parity is
+ * checked bit-for-bit.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+/* out (B,Cout,Ho,Wo) */
+void oracle_conv2d(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
+                   int Cout, int kh, int kw, int stride, int pad, float slope) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int n = 0; n < B; ++n)
+    for (int co = 0; co < Cout; ++co) {
+      float* acc = out + ((size_t)n * Cout + co) * Ho * Wo;
+      memset(acc, 0, sizeof(float) * Ho * Wo);
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float* ip = in + ((size_t)n * Cin + ci) * H * W;
+        for (int ky = 0; ky < kh; ++ky)
+          for (int kx = 0; kx < kw; ++kx) {
+            const float wv = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
+            int wo_lo = 0, wo_hi = Wo;
+            while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
+            while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
+            for (int ho = 0; ho < Ho; ++ho) {
+              const int hi = ho * stride - pad + ky;
+              if (hi < 0 || hi >= H) continue;
+              const float* row = ip + (size_t)hi * W - pad + kx;
+              float* arow = acc + (size_t)ho * Wo;
+              if (stride == 1) {
+                for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo], arow[wo]);
+              } else {
+                for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo * stride], arow[wo]);
+              }
+            }
+          }
+      }
+      const float bv = bias ? bias[co] : 0.f;
+      for (int i = 0; i < Ho * Wo; ++i) acc[i] = lrelu(acc[i] + bv, slope);
+    }
+}
+
+/* MXNet Deconvolution k4 s2 p0, w (Cin,Cout,4,4), cropped at (crop_y,crop_x) to (Ho,Wo). */
+void oracle_deconv4x4s2_crop(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H,
+                             int W, int Cout, int Ho, int Wo, int crop_y, int crop_x, float slope) {
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int n = 0; n < B; ++n)
+    for (int co = 0; co < Cout; ++co) {
+      float* o = out + ((size_t)n * Cout + co) * Ho * Wo;
+      for (int yo = 0; yo < Ho; ++yo)
+        for (int xo = 0; xo < Wo; ++xo) {
+          const int y = yo + crop_y, x = xo + crop_x;
+          float acc = 0.f;
+          for (int ci = 0; ci < Cin; ++ci) {
+            const float* ip = in + ((size_t)n * Cin + ci) * H * W;
+            const float* wp = w + ((size_t)ci * Cout + co) * 16;
+            for (int ky = y & 1; ky < 4; ky += 2) {
+              const int iy = (y - ky) / 2;
+              const int yok = (y - ky) >= 0 && iy < H;
+              for (int kx = x & 1; kx < 4; kx += 2) {
+                const int ix = (x - kx) / 2;
+                const int ok = yok && (x - kx) >= 0 && ix < W;
+                acc = fmaf(wp[ky * 4 + kx], ok ? ip[iy * W + ix] : 0.f, acc);
+              }
+            }
+          }
+          o[yo * Wo + xo] = lrelu(acc + (bias ? bias[co] : 0.f), slope);
+        }
+    }
+}
+
+/* depthwise Deconvolution k32 s16 p0 no-bias, w (C,1,32,32), crop, times scale */
+void oracle_upsample16_crop(float* out, const float* in, const float* w, int B, int C, int H, int W, int Ho, int Wo,
+                            int crop_y, int crop_x, float scale) {
+#pragma omp parallel for schedule(dynamic)
+  for (int bc = 0; bc < B * C; ++bc) {
+    const float* ip = in + (size_t)bc * H * W;
+    const float* wp = w + (size_t)(bc % C) * 1024;
+    for (int yo = 0; yo < Ho; ++yo)
+      for (int xo = 0; xo < Wo; ++xo) {
+        const int y = yo + crop_y, x = xo + crop_x;
+        float acc = 0.f;
+        for (int iy = 0; iy < H; ++iy) {
+          const int ky = y - iy * 16;
+          if (ky < 0 || ky >= 32) continue;
+          for (int ix = 0; ix < W; ++ix) {
+            const int kx = x - ix * 16;
+            if (kx < 0 || kx >= 32) continue;
+            acc = fmaf(ip[iy * W + ix], wp[ky * 32 + kx], acc);
+          }
+        }
+        out[((size_t)bc * Ho + yo) * Wo + xo] = acc * scale;
+      }
+  }
+}
+
+/* FullyConnected y = x·Wᵀ + b, float64 accumulation (most accurate order-free reference) */
+void oracle_fc(float* out, const float* in, const float* w, const float* bias, int B, int I, int O, float slope) {
+#pragma omp parallel for collapse(2)
+  for (int b = 0; b < B; ++b)
+    for (int o = 0; o < O; ++o) {
+      double acc = 0.0;
+      const float* x = in + (size_t)b * I;
+      const float* wr = w + (size_t)o * I;
+      for (int k = 0; k < I; ++k) acc += (double)x[k] * (double)wr[k];
+      out[(size_t)b * O + o] = lrelu((float)acc + (bias ? bias[o] : 0.f), slope);
+    }
+}

@@ -1,0 +1,87 @@
+"""End-to-end CPU oracle of one pose-refinement iteration.  TEST INFRASTRUCTURE ONLY.
+
+Composition follows deepim/symbols/deepIM_flownet.py:548-735 (test graph), :32-169 (get_convs) and
+deepim/core/tester.py:340-398 (predict → RT_transform).
+"""
+import numpy as np
+
+from . import net, se3, zoom
+
+f32 = np.float32
+SLOPE = 0.1
+ENCODER = [("flow_conv1", 2, 3), ("conv2", 2, 2), ("conv3", 2, 2), ("conv3_1", 1, 1), ("conv4", 2, 1), ("conv4_1", 1, 1),
+           ("conv5", 2, 1), ("conv5_1", 1, 1), ("conv6", 2, 1), ("conv6_1", 1, 1)]
+
+
+def encoder(params, x):
+    acts = {}
+    for name, s, p in ENCODER:
+        x = net.conv2d(x, params[name + "_weight"], params[name + "_bias"], s, p, SLOPE)
+        acts[name] = x
+    return acts
+
+
+def pose_head(params, feat, zoom_factor):
+    fc6 = net.fc(feat.reshape(feat.shape[0], -1), params["fc6_weight"], params["fc6_bias"], SLOPE)
+    fc7 = net.fc(fc6, params["fc7_weight"], params["fc7_bias"], SLOPE)
+    rot = net.fc(fc7, params["rot_weight"], params["rot_bias"], 1.0)
+    tr = net.fc(fc7, params["trans_weight"], params["trans_bias"], 1.0)
+    tr = zoom.zoom_trans(zoom_factor, tr, b_inv_zoom=True)
+    return fc6, fc7, np.concatenate([rot, tr], axis=1).astype(f32)
+
+
+def decoder(params, acts):
+    P = params
+    flow6 = net.conv2d(acts["conv6_1"], P["Convolution1_weight"], P["Convolution1_bias"], 1, 1, 1.0)
+    d5 = net.deconv4x4s2_crop(acts["conv6_1"], P["deconv5_weight"], P["deconv5_bias"], 15, 20, (1, 1), SLOPE)
+    up6 = net.deconv4x4s2_crop(flow6, P["upsample_flow6to5_weight"], P["upsample_flow6to5_bias"], 15, 20, (1, 1), 1.0)
+    concat2 = np.concatenate([acts["conv5_1"], d5, up6], axis=1)
+    flow5 = net.conv2d(concat2, P["Convolution2_weight"], P["Convolution2_bias"], 1, 1, 1.0)
+    d4 = net.deconv4x4s2_crop(concat2, P["deconv4_weight"], P["deconv4_bias"], 30, 40, (1, 1), SLOPE)
+    up5 = net.deconv4x4s2_crop(flow5, P["upsample_flow5to4_weight"], P["upsample_flow5to4_bias"], 30, 40, (1, 1), 1.0)
+    concat3 = np.concatenate([acts["conv4_1"], d4, up5], axis=1)
+    return {"flow6": flow6, "Concat2": concat2, "flow5": flow5, "Concat3": concat3}
+
+
+def sigmoid(x):
+    x = np.asarray(x, f32)
+    return (f32(1.0) / (f32(1.0) + np.exp(-x, dtype=f32))).astype(f32)
+
+
+def mask_head(params, concat3, zoom_factor, H, W):
+    low = net.conv2d(concat3, params["mask_conv3_weight"], params["mask_conv3_bias"], 1, 1, 1.0)
+    logits = net.upsample16_crop(low, params["mask_upsampling_weight"], H, W, (8, 8), 1.0)
+    prob = sigmoid(logits)
+    inv = zoom.zoom_mask_with_factor(zoom_factor, prob, b_inv_zoom=True)
+    return low, logits, zoom.roundf(inv)
+
+
+def flow_head(params, concat3, zoom_factor, H, W, normalize_flow):
+    low = net.conv2d(concat3, params["Convolution3_weight"], params["Convolution3_bias"], 1, 1, 1.0)
+    zflow = net.upsample16_crop(low, params["upsampling_weight"], H, W, (8, 8), normalize_flow)
+    (flow,) = zoom.zoom_flow(zoom_factor, zflow, None, b_inv_zoom=True)
+    return low, zflow, flow
+
+
+def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", heads=False,
+                     normalize_flow=20.0):
+    """-> dict with net_input, zoom_factor, encoder activations, se3 (B,7), pose_est (B,3,4 float64)."""
+    x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
+                           data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"))
+    out = {"net_input": x, "zoom_factor": zf}
+    acts = encoder(params, x)
+    out.update(acts)
+    if heads:
+        dec = decoder(params, acts)
+        out.update(dec)
+        H, W = x.shape[2:]
+        out["mask_lowres"], out["mask_logits"], out["mask_observed_pred"] = mask_head(params, dec["Concat3"], zf, H, W)
+        out["flow_lowres"], out["zoom_flow_est"], out["flow_est"] = flow_head(params, dec["Concat3"], zf, H, W, normalize_flow)
+    out["fc6"], out["fc7"], out["se3"] = pose_head(params, acts["conv6_1"], zf)
+    B = x.shape[0]
+    pose = np.zeros((B, 3, 4))
+    for b in range(B):
+        pose[b] = se3.RT_transform(np.asarray(data["src_pose"][b], f32), out["se3"][b, :4], out["se3"][b, 4:], T_means,
+                                   T_stds, rot_coord)
+    out["pose_est"] = pose
+    return out

@@ -1,0 +1,128 @@
+"""N-group parity on the GPU (C ABI) against the C oracle: conv / deconv bit-exact (both are
+k-ordered fp32 fmaf chains), FC within 1e-5 relative."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import net as onet
+from mx_deepim_amd.runtime import DeviceArray, lib
+
+pytestmark = pytest.mark.gpu
+cf = ctypes.c_float
+
+
+def _pack_conv(ctx, w):
+    cout, cin, kh, kw = w.shape
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cout, cin, kh, kw) // 4,))
+    lib.deepim_conv_pack_weights(ctx.handle, pk, ctx.array(w), cout, cin, kh, kw)
+    return pk
+
+
+def _run_conv(ctx, x, w, b, s, p, slope):
+    B, cin, H, W = x.shape
+    cout, _, kh, kw = w.shape
+    ho, wo = (H + 2 * p - kh) // s + 1, (W + 2 * p - kw) // s + 1
+    out = ctx.empty((B, cout, ho, wo))
+    lib.deepim_conv2d_forward(ctx.handle, out, ctx.array(x), _pack_conv(ctx, w), None if b is None else ctx.array(b), B,
+                              cin, H, W, cout, kh, kw, s, p, cf(slope), 0, 0)
+    return out.asnumpy()
+
+
+# (B, Cin, H, W, Cout, k, s, p): every kernel geometry of the encoder at reduced spatial size, the
+# small-Cout heads, ragged sizes, each tile config (128x128, 64x128, 128x64, 64x64)
+CASES = [
+    (2, 8, 96, 128, 64, 7, 2, 3),     # flow_conv1 geometry
+    (1, 64, 60, 80, 128, 5, 2, 2),    # conv2
+    (2, 16, 33, 47, 256, 5, 2, 2),    # conv3, ragged spatial
+    (3, 24, 15, 20, 256, 3, 1, 1),    # conv3_1
+    (2, 32, 30, 40, 512, 3, 2, 1),    # conv4
+    (2, 1024, 8, 10, 2, 3, 1, 1),     # Convolution1 (Cout = 2)
+    (1, 770, 30, 40, 1, 3, 1, 1),     # mask_conv3 (Cout = 1, Cin not a multiple of 16)
+    (1, 3, 9, 11, 70, 3, 1, 1),       # K = 27 (pads to 32), Cout not a multiple of 64
+    (1, 128, 120, 160, 256, 3, 1, 1),  # ≥1024 blocks of 128x128
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bit_exact(ctx, case):
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = _run_conv(ctx, x, w, b, s, p, 0.1)
+    ref = onet.conv2d(x, w, b, s, p, 0.1)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_conv_matches_torch_cpu(ctx):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 8, 64, 80)).astype(np.float32)
+    w = (rng.standard_normal((64, 8, 7, 7)) / 20).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    got = _run_conv(ctx, x, w, b, 2, 3, 0.1)
+    t = torch.nn.functional.leaky_relu(
+        torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=2, padding=3), 0.1)
+    np.testing.assert_allclose(got, t.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_conv_channel_slice_output(ctx):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((2, 8, 20, 24)).astype(np.float32)
+    w = rng.standard_normal((64, 8, 3, 3)).astype(np.float32)
+    out = ctx.zeros((2, 100, 20, 24))
+    lib.deepim_conv2d_forward(ctx.handle, out, ctx.array(x), _pack_conv(ctx, w), None, 2, 8, 20, 24, 64, 3, 3, 1, 1,
+                              cf(1.0), 100, 30)
+    got = out.asnumpy()
+    np.testing.assert_array_equal(got[:, 30:94], onet.conv2d(x, w, None, 1, 1, 1.0))
+    assert not got[:, :30].any() and not got[:, 94:].any()
+
+
+@pytest.mark.parametrize("case", [(2, 1024, 8, 10, 512, 15, 20), (2, 1026, 15, 20, 256, 30, 40), (2, 2, 8, 10, 2, 15, 20),
+                                  (1, 5, 7, 9, 3, 16, 20)])
+def test_deconv_crop_bit_exact(ctx, case):
+    B, cin, H, W, cout, ho, wo = case
+    rng = np.random.default_rng(7 + cin)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    pk = DeviceArray(ctx, (lib.load().deepim_deconv_packed_size(cin, cout) // 4,))
+    lib.deepim_deconv_pack_weights(ctx.handle, pk, ctx.array(w), cin, cout)
+    out = ctx.empty((B, cout, ho, wo))
+    lib.deepim_deconv4x4s2_crop_forward(ctx.handle, out, ctx.array(x), pk, ctx.array(b), B, cin, H, W, cout, ho, wo, 1, 1,
+                                        cf(0.1), 0, 0)
+    np.testing.assert_array_equal(out.asnumpy(), onet.deconv4x4s2_crop(x, w, b, ho, wo, (1, 1), 0.1))
+
+
+def test_upsample16_crop(ctx):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 2, 30, 40)).astype(np.float32)
+    w = onet.bilinear_upsample_weights(2)
+    out = ctx.empty((2, 2, 480, 640))
+    lib.deepim_upsample16_crop_forward(ctx.handle, out, ctx.array(x), ctx.array(w), 2, 2, 30, 40, 480, 640, 8, 8, cf(20.0))
+    np.testing.assert_array_equal(out.asnumpy(), onet.upsample16_crop(x, w, 480, 640, (8, 8), 20.0))
+
+
+@pytest.mark.parametrize("shape", [(16, 81920, 256), (3, 256, 256), (2, 256, 4), (17, 1024, 40)])
+def test_fc(ctx, shape):
+    B, I, O = shape
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, I)).astype(np.float32)
+    w = (rng.standard_normal((O, I)) / np.sqrt(I)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    out = ctx.empty((B, O))
+    lib.deepim_fc_forward(ctx.handle, out, ctx.array(x), ctx.array(w), ctx.array(b), B, I, O, cf(0.1))
+    ref = onet.fc(x, w, b, 0.1)
+    np.testing.assert_allclose(out.asnumpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_copy_channels(ctx):
+    rng = np.random.default_rng(4)
+    src = rng.standard_normal((3, 5, 6, 7)).astype(np.float32)
+    dst = ctx.zeros((3, 9, 6, 7))
+    lib.deepim_copy_channels(ctx.handle, dst, 9, 2, ctx.array(src), 5, 3, 42)
+    got = dst.asnumpy()
+    np.testing.assert_array_equal(got[:, 2:7], src)
+    assert not got[:, :2].any() and not got[:, 7:].any()
