@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py — pose-refinement iterations/sec of the DeepIM render-and-compare inner loop on MI355X.
+
+Workload (BASELINE.json configs[1]): LINEMOD-'ape'-like pairs, batch 16 per GPU, 4 refinement
+iterations, 480x640, fp32.  One *step* = one pass of the hot path over one batch = the 4-iteration loop
+over the 16 pairs (64 pose-refinement iterations): zoom → FlowNetS encoder → fc6/fc7 → rot/trans +
+inverse ZoomTrans → RT_transform, the refined pose feeding the next iteration's ZoomMask.  The OpenGL
+re-render between iterations is outside the path: iterations 2-4 consume pre-staged
+synthetic rendered frames already resident in HBM.  Inputs are resident in HBM before the timed region.
+
+N>1: one process per GPU (torch.distributed.run), per-GPU batch fixed (weak scaling), pairs are
+independent; after every refinement iteration the refined poses are all-gathered over RCCL (48 B/pair).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mx_deepim_amd import synthetic  # noqa: E402
+from mx_deepim_amd.config import default_config  # noqa: E402
+from mx_deepim_amd.runtime import Context, lib  # noqa: E402
+from mx_deepim_amd.symbols import deepIM_flownet  # noqa: E402
+from mx_deepim_amd.symbols.deepIM_flownet import ENCODER  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def encoder_flops_per_pair(cin=8, H=480, W=640):
+    total, h, w = 0, H, W
+    for _, cout, k, s, p in ENCODER:
+        h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        total += 2 * cout * cin * k * k * h * w
+        cin = cout
+    return total
+
+
+def cpu_baseline(params, cfg, batch, pairs=2):
+    """Oracle ('port' of the reference CPU path; MXNet itself is not installable offline) timed on the
+    host cores over a bounded sample: `pairs` pair-iterations of the same workload."""
+    from oracle import pipeline as opipe
+    from oracle import net as onet
+    onet.build()
+    means_rev = np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
+    t0 = time.time()
+    for b in range(pairs):
+        data = {"image_observed": batch["image_observed"][b:b + 1], "image_rendered": batch["image_rendered"][0][b:b + 1],
+                "mask_observed": batch["mask_observed"][b:b + 1], "mask_rendered": batch["mask_rendered"][0][b:b + 1],
+                "src_pose": batch["src_pose"][0][b:b + 1]}
+        opipe.refine_iteration(params, data, batch["K"], means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds,
+                               cfg.network.ROT_COORD)
+    dt = time.time() - t0
+    return {"value": pairs / dt, "unit": "pose-refinement iters/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d pair-iterations (B=1, 480x640, FAST_TEST graph) of the same synthetic workload, "
+                      "numpy + C/OpenMP oracle, OMP threads = all cores" % pairs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
+    ap.add_argument("--iters", type=int, default=4, help="refinement iterations per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = Context.get(local_rank)
+    h = ctx.handle
+    B, NIT = args.batch, args.iters
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    params = net.init_weights(cfg, seed=2333)
+    net.bind(ctx, B, params)
+    batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=NIT, with_depth=False)
+    image_observed = ctx.array(batch["image_observed"])
+    frames = [{"image_rendered": ctx.array(batch["image_rendered"][f]), "mask_rendered": ctx.array(batch["mask_rendered"][f]),
+               "mask_observed": ctx.array(batch["mask_observed_frames"][f])} for f in range(NIT)]
+    pose_init = ctx.array(batch["src_pose"][0])
+    pose_cur = ctx.empty((B, 3, 4))
+
+    gather_in = gather_out = ext_stream = None
+    if world > 1:
+        gather_in = torch.empty((B, 12), dtype=torch.float32, device="cuda")
+        gather_out = torch.empty((world * B, 12), dtype=torch.float32, device="cuda")
+        ext_stream = torch.cuda.ExternalStream(lib.load().deepim_stream(h))
+
+    enc_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
+    zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
+
+    def step(timers=None, ztimers=None):
+        lib.deepim_d2d(h, pose_cur, pose_init, pose_cur.nbytes)
+        for it in range(NIT):
+            data = {"image_observed": image_observed, "src_pose": pose_cur}
+            data.update(frames[it])
+            if ztimers:
+                ztimers[it].start()
+            net.zoom(data)
+            if ztimers:
+                ztimers[it].stop()
+            if timers:
+                timers[it].start()
+            net.encoder()
+            if timers:
+                timers[it].stop()
+            net.pose_head()
+            net.pose_update(pose_cur, pose_cur)   # refined pose becomes the next iteration's src_pose
+            if world > 1:                          # every rank/host gets all refined poses
+                lib.deepim_d2d(h, gather_in.data_ptr(), pose_cur, pose_cur.nbytes)
+                with torch.cuda.stream(ext_stream):
+                    dist.all_gather_into_tensor(gather_out, gather_in)
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(enc_timers[s], zoom_timers[s])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # sanity: poses finite, zoom status clean
+    import ctypes
+    st = ctypes.c_int(0)
+    lib.deepim_zoom_status(h, ctypes.byref(st))
+    pose_final = pose_cur.asnumpy()
+    assert np.all(np.isfinite(pose_final)) and st.value == 0, ("bad poses / zoom status", st.value)
+
+    if rank == 0:
+        iters_total = world * B * NIT * args.steps
+        enc_ms = float(np.mean([t.elapsed_ms() for row in enc_timers for t in row]))
+        zoom_ms = float(np.mean([t.elapsed_ms() for row in zoom_timers for t in row]))
+        flops = encoder_flops_per_pair(net.cin) * B
+        achieved = flops / (enc_ms * 1e-3) / 1e12
+        zoom_bytes = 2 * (net.cin * 480 * 640 * 4) * B   # read + write every zoomed channel once
+        out = {
+            "metric": "pose-refinement iters/sec (4-iter loop, 480x640)",
+            "value": iters_total / dt,
+            "unit": "pose-refinement iters/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LINEMOD-ape-like synthetic pairs, batch %d per GPU, %d refinement iters, 480x640, "
+                                   "FAST_TEST graph (8-ch input), pre-staged rendered frames (render excluded)" % (B, NIT),
+                       "pairs_per_gpu": B, "iters": NIT, "parallelism": "pairs sharded across %d GPU(s), RCCL all-gather "
+                                                                        "of refined poses per iteration" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (10 encoder launches per iteration)",
+                         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_launch_group": flops, "ms_per_launch_group": enc_ms},
+            "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
+                              "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms},
+        }
+        if args.layers:
+            out["layers"] = layer_timings(ctx, net)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, cfg, batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def layer_timings(ctx, net, reps=5):
+    import ctypes
+    res = []
+    src = net.act["net_input"]
+    for name, cin, h, w, cout, k, s, p in net.enc_geom:
+        t = ctx.timer()
+        net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        t.start()
+        for _ in range(reps):
+            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        t.stop()
+        ms = t.elapsed_ms() / reps
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        fl = 2.0 * cout * cin * k * k * ho * wo * net.B
+        res.append({"layer": name, "ms": ms, "tflops": fl / (ms * 1e-3) / 1e12})
+        src = net.act[name]
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -106,7 +106,8 @@ def make_batch(B, seed=2333, H=480, W=640, n_frames=1, with_depth=True, n_points
     rng = np.random.default_rng(seed)
     K = K_LINEMOD
     out = {k: [] for k in ("image_observed", "mask_observed", "depth_gt_observed", "pose_tgt", "point_cloud_model")}
-    frames = {k: [[] for _ in range(n_frames)] for k in ("image_rendered", "mask_rendered", "depth_rendered", "src_pose")}
+    frames = {k: [[] for _ in range(n_frames)]
+              for k in ("image_rendered", "mask_rendered", "depth_rendered", "src_pose", "mask_observed_frames")}
     for b in range(B):
         axes = np.array([0.05, 0.04, 0.035]) * rng.uniform(0.85, 1.15, 3)
         tgt, src = sample_pose_pair(rng, K, H, W)
@@ -133,6 +134,8 @@ def make_batch(B, seed=2333, H=480, W=640, n_frames=1, with_depth=True, n_points
             frames["depth_rendered"][f].append(dep_r[None])
             frames["mask_rendered"][f].append((dep_r > 0.2).astype(np.float32)[None])
             frames["src_pose"][f].append(pose_f)
+            # UPDATE_MASK=box_rendered: the observed mask is re-derived from each re-rendered frame
+            frames["mask_observed_frames"][f].append(box_mask(frames["mask_rendered"][f][-1][0])[None])
         out["mask_observed"].append(box_mask(frames["mask_rendered"][0][-1][0])[None])
     res = {k: np.ascontiguousarray(np.stack(v), dtype=np.float32) for k, v in out.items()}
     for k, v in frames.items():
