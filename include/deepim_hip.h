@@ -40,6 +40,8 @@ int deepim_h2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* 
 int deepim_d2h(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* sync */
 int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes);   /* async */
 int deepim_sync(deepim_ctx* ctx);
+/* y[i] += alpha * x[i] — CustomOp.assign(dst, 'add', src) (mx.operator.CustomOp.assign) */
+int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n);
 /* strided channel-slice copy: dst[b, dst_coff:dst_coff+C, :] = src[b, :, :] (MXNet Concat, async) */
 int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff,
                          const float* src, int C, int B, size_t hw);

@@ -109,7 +109,20 @@ __global__ __launch_bounds__(256) void group_pick_kernel(float* __restrict__ out
   }
 }
 
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
+                                                   size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = y[i] + alpha * x[i];
+}
+
 }  // namespace
+
+extern "C" int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, y, x, alpha, n);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int deepim_point_matching_loss(deepim_ctx* ctx, float* loss, float* loss_sum, float* d_est,
                                           const float* est, const float* gt, const float* weights, float normalize,

@@ -15,7 +15,9 @@ f64 = np.float64
 def roundf(x):
     """C roundf / mx.nd.round: half away from zero (NOT numpy's half-to-even)."""
     x = np.asarray(x, dtype=f32)
-    return (np.sign(x) * np.floor(np.abs(x) + f32(0.5))).astype(f32)
+    t = np.trunc(x)
+    frac = np.abs(x - t)          # exact in floating point
+    return np.where(frac >= f32(0.5), t + np.sign(x), t).astype(f32)
 
 
 def _axis_taps(scale, trans, n):

@@ -1,0 +1,103 @@
+"""Host-side logic that needs no GPU: Prop string-kwarg parsing, shape inference, op registry,
+pair sharding and the world_size-2 gloo all-gather of refined poses."""
+import os
+
+import numpy as np
+import pytest
+
+import mx_deepim_amd.operator_py  # noqa: F401  (registers the ops)
+from mx_deepim_amd import mx, parallel
+from mx_deepim_amd.config import default_config
+from mx_deepim_amd.mx.nd import _attr_to_str
+from mx_deepim_amd.symbols import deepIM_flownet
+
+
+def test_registry_matches_reference_op_types():
+    assert mx.operator.registered_ops() == sorted(
+        ["ZoomMask", "ZoomImage", "ZoomImageWithFactor", "ZoomDepth", "ZoomFlow", "ZoomMaskWithFactor", "ZoomTrans",
+         "Transform3D", "FlowUpdater", "GroupPicker"])
+
+
+def test_props_parse_string_kwargs_like_mxnet():
+    cfg = default_config()
+    K = cfg.dataset.INTRINSIC_MATRIX.flatten()
+    p = mx.operator.get_registered("ZoomMask")(K=_attr_to_str(K), height="480", width="640")
+    np.testing.assert_array_equal(p.K, cfg.dataset.INTRINSIC_MATRIX)
+    assert p.list_arguments() == ["mask_observed", "mask_gt_observed", "mask_rendered", "src_pose"]
+    assert p.list_outputs() == ["zoom_mask_observed", "zoom_mask_gt_observed", "zoom_mask_rendered", "zoom_factor"]
+    _, out, aux = p.infer_shape([[4, 1, 480, 640]] * 3 + [[4, 3, 4]])
+    assert out == [[4, 1, 480, 640]] * 3 + [[4, 4]] and aux == []
+    q = mx.operator.get_registered("ZoomImageWithFactor")(pixel_means=_attr_to_str(cfg.network.PIXEL_MEANS.flatten()))
+    np.testing.assert_allclose(q.pixel_means, cfg.network.PIXEL_MEANS[::-1])   # reversal, zoom_image_with_factor.py:80
+    f = mx.operator.get_registered("ZoomFlow")(b_inv_zoom="True")
+    assert f.list_arguments() == ["zoom_factor", "flow"] and f.list_outputs() == ["zoom_flow"]
+    f = mx.operator.get_registered("ZoomFlow")()
+    assert f.list_arguments() == ["zoom_factor", "flow", "flow_weights"]
+    t = mx.operator.get_registered("Transform3D")(T_means="[0.0 0.0 0.0]", T_stds="[1.0 1.0 1.0]", rot_coord="CAMERA")
+    assert t.list_arguments() == ["point_cloud", "rotation", "translation", "pose_src"]
+    with pytest.raises(AssertionError):  # b_project_2d is NOT_IMPLEMENTED in the reference too (transform3d.py:32)
+        mx.operator.get_registered("Transform3D")(T_means="[0 0 0]", T_stds="[1 1 1]", b_project_2d="True").create_operator(
+            None, None, None)
+    g = mx.operator.get_registered("GroupPicker")(group_num="13")
+    assert g.infer_shape([[8, 52], [8]])[1] == [[8, 4]]
+    u = mx.operator.get_registered("FlowUpdater")(K=_attr_to_str(K))
+    assert u.infer_shape([[2, 1, 480, 640]] * 2 + [[2, 3, 4]] * 2)[1] == [[2, 2, 480, 640]] * 2
+
+
+def test_symbol_graph_flags_follow_config():
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    assert net.cin == 8 and not net.with_decoder                      # shipped config: FAST_TEST prunes the decoder
+    shapes = net.arg_shape_dict()
+    assert shapes["flow_conv1_weight"] == (64, 8, 7, 7) and shapes["fc6_weight"] == (256, 81920)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 45096391  # 45.09 M encoder parameters
+    cfg.TEST.FAST_TEST = False
+    net = deepIM_flownet().get_symbol(cfg)
+    assert net.with_mask_head and net.with_flow_head
+    assert net.arg_shape_dict()["deconv4_weight"] == (1026, 256, 4, 4)
+    cfg.network.INPUT_DEPTH = True
+    assert deepIM_flownet().get_symbol(cfg).cin == 10
+    cfg.network.REGRESSOR_NUM = 2
+    with pytest.raises(Exception):
+        deepIM_flownet().get_symbol(cfg)
+    w = deepIM_flownet().get_symbol(default_config()).init_weights(seed=1)
+    assert w["rot_weight"][0].min() >= 0.01 and abs(w["rot_weight"][1:]).max() <= 0.01   # deepIM_flownet.py:795-800
+
+
+def test_shard_bounds_cover_all_pairs():
+    for n, world in ((32, 8), (13, 8), (8, 8), (5, 2), (3, 4)):
+        spans = [parallel.shard_bounds(n, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    batch = {"image_observed": np.zeros((6, 3, 4, 4)), "image_rendered": np.zeros((2, 6, 3, 4, 4)), "K": np.eye(3)}
+    s = parallel.shard_pairs(batch, 4, 1)
+    assert s["image_observed"].shape[0] == 2 and s["image_rendered"].shape[:2] == (2, 2) and s["K"].shape == (3, 3)
+
+
+def _gather_worker(rank, world, port, counts, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = parallel.shard_bounds(sum(counts), world, rank)
+    allp = torch.arange(sum(counts) * 12, dtype=torch.float32).reshape(-1, 3, 4)
+    got = parallel.all_gather_poses(allp[lo:hi].clone(), dist, counts)
+    q.put((rank, bool(torch.equal(got, allp))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [[4, 4], [3, 2]])
+def test_all_gather_poses_gloo_world2(counts):
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + os.getpid() % 2000 + len(set(counts))
+    procs = [ctxm.Process(target=_gather_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

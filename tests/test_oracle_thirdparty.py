@@ -1,0 +1,67 @@
+"""Cross-checks of the oracle's restatement of third-party MXNet operator semantics (unpinned by the
+reference's own tests) against torch-CPU, used here only as an independent second opinion."""
+import numpy as np
+import pytest
+
+from oracle import net as onet
+from oracle import zoom as oz
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+
+def test_sampler_matches_torch_grid_sample():
+    rng = np.random.default_rng(0)
+    H, W = 48, 64
+    img = rng.standard_normal((3, H, W)).astype(np.float32)
+    for wx, wy, tx, ty in [(1, 1, 0, 0), (0.3, 0.3, 0.1, -0.2), (0.17, 0.17, 0.9, 0.8), (2.5, 2.5, -0.3, 0.4)]:
+        got = oz.bilinear_sample(img, np.float32(wx), np.float32(wy), np.float32(tx), np.float32(ty))
+        theta = torch.tensor([[[wx, 0, tx], [0, wy, ty]]], dtype=torch.float32)
+        grid = F.affine_grid(theta, (1, 3, H, W), align_corners=True)
+        ref = F.grid_sample(torch.from_numpy(img)[None], grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        np.testing.assert_allclose(got, ref[0].numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_identity_zoom_indices():
+    idx = oz.sample_indices(np.array([[1, 1, 0, 0]], np.float32), 480, 640)
+    x = np.arange(640)
+    # the f32 grid may land an ulp below the pixel centre: floor index is x or x-1 with weight ≈ 0
+    assert np.all((idx[0, 0, 0] == x) | (idx[0, 0, 0] == x - 1))
+
+
+def test_roundf_is_half_away_from_zero():
+    np.testing.assert_array_equal(oz.roundf(np.array([0.5, 1.5, 2.5, -0.5, -1.5, 0.49999997], np.float32)),
+                                  np.array([1, 2, 3, -1, -2, 0], np.float32))
+
+
+def test_conv_deconv_upsample_fc_match_torch():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 6, 21, 29)).astype(np.float32)
+    for k, s, p in ((7, 2, 3), (5, 2, 2), (3, 1, 1), (3, 2, 1)):
+        w = rng.standard_normal((9, 6, k, k)).astype(np.float32) / (k * 3)
+        b = rng.standard_normal(9).astype(np.float32)
+        ref = F.leaky_relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=s, padding=p), 0.1)
+        np.testing.assert_allclose(onet.conv2d(x, w, b, s, p, 0.1), ref.numpy(), rtol=1e-4, atol=1e-5)
+    wd = rng.standard_normal((6, 4, 4, 4)).astype(np.float32) / 5
+    bd = rng.standard_normal(4).astype(np.float32)
+    full = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wd), torch.from_numpy(bd), stride=2).numpy()
+    np.testing.assert_allclose(onet.deconv4x4s2_crop(x, wd, bd, 40, 56, (1, 1), 1.0), full[:, :, 1:41, 1:57], rtol=1e-4,
+                               atol=1e-5)
+    wu = onet.bilinear_upsample_weights(6)
+    xs = x[:, :, :5, :6]
+    full = F.conv_transpose2d(torch.from_numpy(xs), torch.from_numpy(wu), stride=16, groups=6).numpy()
+    np.testing.assert_allclose(onet.upsample16_crop(xs, wu, 80, 96, (8, 8), 20.0), 20 * full[:, :, 8:88, 8:104],
+                               rtol=1e-4, atol=1e-4)
+    xf = rng.standard_normal((3, 200)).astype(np.float32)
+    wf = rng.standard_normal((7, 200)).astype(np.float32)
+    bf = rng.standard_normal(7).astype(np.float32)
+    np.testing.assert_allclose(onet.fc(xf, wf, bf, 0.1),
+                               F.leaky_relu(F.linear(torch.from_numpy(xf), torch.from_numpy(wf), torch.from_numpy(bf)), 0.1).numpy(),
+                               rtol=1e-4, atol=1e-5)
+
+
+def test_bilinear_init_is_separable_tent():
+    w = onet.bilinear_upsample_weights(2)
+    assert w.shape == (2, 1, 32, 32)
+    k1 = 1 - np.abs(np.arange(32) / 16.0 - (2 * 16 - 1) / 32.0)
+    np.testing.assert_allclose(w[1, 0], np.outer(k1, k1), rtol=1e-6)
