@@ -46,6 +46,9 @@ int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n
 int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff,
                          const float* src, int C, int B, size_t hw);
 void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
+/* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split (conv/deconv results
+ * are then a single k-ordered fmaf chain, bit-identical to the oracle), n = cap. Unknown names fail. */
+int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);
 int deepim_timer_start(deepim_ctx* ctx, int timer_id);

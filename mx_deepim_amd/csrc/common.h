@@ -18,6 +18,7 @@ struct deepim_ctx {
   std::vector<hipEvent_t> timer_start, timer_stop;
   std::vector<hipGraphExec_t> graphs;
   bool capturing;
+  int conv_max_split;  // 0 auto, 1 off, n cap
 };
 
 void deepim_set_error(const char* where, hipError_t e);

@@ -26,10 +26,35 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// (helpers below)
 constexpr int KT = 16;        // K chunk
 constexpr int GRAN = 64;      // weight packing granule (rows)
 constexpr int MODE_CONV = 0;
 constexpr int MODE_DECONV = 1;  // k4 s2 p0 transposed conv, one launch z-slice per output parity
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ds_read2st64_b32: two dwords per lane from addr + OFF*256 bytes (offsets in units of 64 dwords)
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2st64 offset out of range");
+  f32x2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+  return v;
+}
+// wait until at most N LDS reads are outstanding; the fragments are threaded through the asm so the
+// MFMAs that consume them cannot be hoisted above the wait
+template <int N, int TM, int TN>
+__device__ __forceinline__ void lds_wait(f32x2 (&a)[TM], f32x2 (&b)[TN]) {
+  if constexpr (TM == 2 && TN == 2)
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  else if constexpr (TM == 1 && TN == 2)
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  else if constexpr (TM == 1 && TN == 4)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+  else
+    static_assert(TM == 0, "unsupported wave tile");
+}
 
 struct ConvParams {
   const float* in;
@@ -46,6 +71,10 @@ struct ConvParams {
   float slope;
   int crop_y, crop_x;       // deconv crop offsets
   long npix;                // B*Ho*Wo (conv) or pixels per parity class (deconv)
+  int ksplit;               // split-K slices (grid.z = classes * ksplit)
+  int chunks_per_split;
+  float* partial;           // [ksplit][B][Cout][Ho][Wo] raw partial sums when ksplit > 1
+  long partial_stride;
 };
 
 template <int BM, int BN, int MODE>
@@ -53,8 +82,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NG = BM / GRAN;            // weight granules per block
-  constexpr int EB = KT * BN / 256;        // gathered elements per thread per chunk
-  constexpr int KSTEP = 256 / BN;          // k rows covered per pass
+  constexpr int EB = KT * BN / 256;        // gathered elements per thread per chunk (consecutive k rows)
+  constexpr int KS = KT / 2;               // MFMA k-steps per chunk
   __shared__ __attribute__((aligned(16))) float As[2][KT * BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][KT * BN];
 
@@ -64,17 +93,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int mb = blockIdx.y;               // M tile
   const long n0 = (long)blockIdx.x * BN;   // first pixel of the tile
+  int zz = blockIdx.z;
+  const int split = zz % p.ksplit;         // split-K slice
+  zz /= p.ksplit;                          // deconv parity class
 
   // ---- per-thread gather state (fixed for the whole K loop) ----
   const int gp = tid & (BN - 1);
-  const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+  const int krow0 = __builtin_amdgcn_readfirstlane((tid / BN) * EB);
   const long pix = n0 + gp;
-  const float* gbase = p.in;
+  const float* sbase = p.in;  // start of this pixel's sample (always a valid address)
+  int poff = 0;               // element offset of tap (0,0) relative to sbase (may be negative at the border)
   unsigned mky = 0, mkx = 0;
   int par_y = 0, par_x = 0;
   long npix = p.npix;
   if (MODE == MODE_DECONV) {
-    par_y = (blockIdx.z >> 1); par_x = (blockIdx.z & 1);
+    par_y = (zz >> 1); par_x = (zz & 1);
     const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
     npix = (long)p.B * ((p.Ho - oy0 + 1) >> 1) * ((p.Wo - ox0 + 1) >> 1);
   }
@@ -85,7 +118,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       const int r = (int)(pix - (long)n * hw);
       const int ho = r / p.Wo, wo = r - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      gbase = p.in + (long)n * p.Cin * p.H * p.W + (long)hi0 * p.W + wi0;
+      sbase = p.in + (long)n * p.Cin * p.H * p.W;
+      poff = hi0 * p.W + wi0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
@@ -103,7 +137,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       const int y = 2 * qy + oy0 + p.crop_y, x = 2 * qx + ox0 + p.crop_x;  // uncropped coords
       // taps: ky = par_y + 2*jy (jy∈{0,1}) ↔ iy = (y - ky)/2 = (y>>1) - jy ; table kx/ky hold jy/jx
       const int iy0 = (y >> 1), ix0 = (x >> 1);
-      gbase = p.in + (long)n * p.Cin * p.H * p.W + (long)iy0 * p.W + ix0;
+      sbase = p.in + (long)n * p.Cin * p.H * p.W;
+      poff = iy0 * p.W + ix0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (iy0 - j >= 0 && iy0 - j < p.H) mky |= 1u << j;
@@ -112,35 +147,43 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
   }
 
-  const float* wblk = p.wp + ((long)mb * NG) * p.nchunk * (KT * GRAN);
-  if (MODE == MODE_DECONV) wblk += (long)blockIdx.z * p.ngran * p.nchunk * (KT * GRAN);
+  const float* wblk = p.wp + ((long)mb * NG) * p.nchunk * (KT * GRAN) + tid * 4;
+  if (MODE == MODE_DECONV) wblk += (long)zz * p.ngran * p.nchunk * (KT * GRAN);
+  const int kc_begin = split * p.chunks_per_split;
+  const int kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
 
-  float4 areg[NG];
+  // LDS slots this thread fills
+  const int a_st = ((tid * 4) / GRAN) * BM + (tid * 4) % GRAN;
+  const int b_st = krow0 * BN + gp;
+
+  float4 areg0, areg1;
   float breg[EB];
+  unsigned okbits = 0;
 
-  auto load_chunk = [&](int kc) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-      areg[g] = *reinterpret_cast<const float4*>(wblk + ((long)g * p.nchunk + kc) * (KT * GRAN) + tid * 4);
-#pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      const int k = kc * KT + krow0 + e * KSTEP;
-      const int2 t = p.tab[k];
-      const unsigned ky = (unsigned)t.y >> 8, kx = (unsigned)t.y & 255u;
-      const bool ok = ((mky >> ky) & (mkx >> kx) & 1u) != 0;
-      breg[e] = ok ? gbase[t.x] : 0.f;
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int e = tid * 4;
-      const int kk = e / GRAN, mm = e % GRAN;
-      *reinterpret_cast<float4*>(&As[buf][kk * BM + g * GRAN + mm]) = areg[g];
-    }
-#pragma unroll
-    for (int e = 0; e < EB; ++e) Bs[buf][(krow0 + e * KSTEP) * BN + gp] = breg[e];
-  };
+// global → registers for chunk kc: one dwordx4 of packed weights per granule + EB gathered activations.
+// The tap table is wave-uniform (scalar loads); padding is branch-free (clamped address + select).
+#define LOAD_CHUNK(kc)                                                                                  \
+  {                                                                                                     \
+    areg0 = *reinterpret_cast<const float4*>(wblk + (long)(kc) * (KT * GRAN));                         \
+    if (NG == 2) areg1 = *reinterpret_cast<const float4*>(wblk + ((long)p.nchunk + (kc)) * (KT * GRAN)); \
+    const int2* tp = p.tab + (kc) * KT + krow0;                                                         \
+    okbits = 0;                                                                                         \
+    _Pragma("unroll") for (int e = 0; e < EB; ++e) {                                                    \
+      const int2 t = tp[e];                                                                             \
+      const unsigned ky = (unsigned)t.y >> 8, kx = (unsigned)t.y & 255u;                                \
+      const unsigned ok = (mky >> ky) & (mkx >> kx) & 1u;                                               \
+      okbits |= ok << e;                                                                                \
+      breg[e] = sbase[ok ? poff + t.x : 0];                                                             \
+    }                                                                                                   \
+  }
+// registers → LDS; the zero-padding select happens here so the gathers stay in flight under the MFMAs
+#define STORE_CHUNK(buf)                                                                  \
+  {                                                                                       \
+    *reinterpret_cast<float4*>(&As[buf][a_st]) = areg0;                                   \
+    if (NG == 2) *reinterpret_cast<float4*>(&As[buf][a_st + GRAN]) = areg1;               \
+    _Pragma("unroll") for (int e = 0; e < EB; ++e)                                        \
+      Bs[buf][b_st + e * BN] = ((okbits >> e) & 1u) ? breg[e] : 0.f;                      \
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -150,34 +193,51 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
+  const int lrow = lane >> 5, lcol = lane & 31;
+  if (kc_begin < kc_end) {
+    LOAD_CHUNK(kc_begin);
+    STORE_CHUNK(0);
+  }
   __syncthreads();
 
-  const int lrow = lane >> 5, lcol = lane & 31;
-  for (int kc = 0; kc < p.nchunk; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < p.nchunk) load_chunk(kc + 1);
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const int buf = (kc - kc_begin) & 1;
+    const bool more = kc + 1 < kc_end;
+    if (more) LOAD_CHUNK(kc + 1);
     const float* as = &As[buf][lrow * BM + wm0 + lcol];
     const float* bs = &Bs[buf][lrow * BN + wn0 + lcol];
+    // Operand fragments are read per k-step (ds_read2_b32, conflict-free); with 3 resident waves per SIMD
+    // one wave's LDS latency is covered by the other waves' MFMAs.
+    float av[2][TM], bv[2][TN];
 #pragma unroll
-    for (int s = 0; s < KT / 2; ++s) {
-      float a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) av[0][i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[s * 2 * BM + i * 32];
+    for (int j = 0; j < TN; ++j) bv[0][j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[s * 2 * BN + j * 32];
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[(s + 1) & 1][i] = as[(s + 1) * 2 * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[(s + 1) & 1][j] = bs[(s + 1) * 2 * BN + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
     }
-    if (kc + 1 < p.nchunk) store_chunk(buf ^ 1);
+    if (more) STORE_CHUNK(buf ^ 1);
     __syncthreads();
   }
+#undef LOAD_CHUNK
+#undef STORE_CHUNK
 
-  // ---- epilogue: bias + LeakyReLU, NCHW store ----
+  // ---- epilogue: bias + LeakyReLU, NCHW store (or raw partial sums for split-K) ----
+  const bool partial = p.ksplit > 1;
+  float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
+  const int ctotal = partial ? p.Cout : p.out_ctotal;
+  const int coff = partial ? 0 : p.out_coff;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long op = n0 + wn0 + j * 32 + lcol;
@@ -187,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       const int hw = p.Ho * p.Wo;
       const int n = (int)(op / hw);
       const int r = (int)(op - (long)n * hw);
-      obase = ((long)n * p.out_ctotal + p.out_coff) * hw + r;
+      obase = ((long)n * ctotal + coff) * hw + r;
     } else {
       const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
       const int nqy = (p.Ho - oy0 + 1) >> 1, nqx = (p.Wo - ox0 + 1) >> 1;
@@ -195,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       const int n = (int)(op / hwq);
       const int r = (int)(op - (long)n * hwq);
       const int qy = r / nqx, qx = r - qy * nqx;
-      obase = ((long)n * p.out_ctotal + p.out_coff) * p.Ho * p.Wo + (long)(2 * qy + oy0) * p.Wo + (2 * qx + ox0);
+      obase = ((long)n * ctotal + coff) * p.Ho * p.Wo + (long)(2 * qy + oy0) * p.Wo + (2 * qx + ox0);
     }
     const long cstride = (long)p.Ho * p.Wo;
 #pragma unroll
@@ -204,13 +264,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       for (int r = 0; r < 16; ++r) {
         const int co = mb * BM + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
         if (co < p.Cout) {
-          float v = acc[i][j][r] + (p.bias ? p.bias[co] : 0.f);
-          v = v > 0.f ? v : v * p.slope;
-          p.out[obase + co * cstride] = v;
+          float v = acc[i][j][r];
+          if (!partial) {
+            v = v + (p.bias ? p.bias[co] : 0.f);
+            v = v > 0.f ? v : v * p.slope;
+          }
+          outp[obase + co * cstride] = v;
         }
       }
     }
   }
+}
+
+// split-K second pass: out[n][coff+c][hw] = lrelu(Σ_s partial[s][n][c][hw] + bias[c]) in fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
+                                                            const float* __restrict__ bias, long total, long stride,
+                                                            int S, int Cout, int hw, int ctotal, int coff,
+                                                            float slope) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = partial[i];
+  for (int s = 1; s < S; ++s) v += partial[(long)s * stride + i];
+  const int r = (int)(i % hw);
+  const int c = (int)((i / hw) % Cout);
+  const long n = i / ((long)hw * Cout);
+  v = v + (bias ? bias[c] : 0.f);
+  v = v > 0.f ? v : v * slope;
+  out[(n * ctotal + coff + c) * hw + r] = v;
 }
 
 // ------------------------------------------------------------ packing ----
@@ -293,31 +373,50 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
   out[((long)bc * Ho + yo) * Wo + xo] = acc * scale;
 }
 
-struct TileChoice { int bm, bn; };
-TileChoice choose_tile(int Cout, long npix) {
-  // biggest tile that still yields ≥ 2 blocks per CU on 256 CUs; small Cout → BM=64
-  const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-  for (auto& c : cands) {
-    if (c[0] > 64 && Cout <= 64) continue;
-    const long blocks = (long)di_div_up(Cout, c[0]) * di_div_up(npix, c[1]);
-    if (blocks >= 1024) return {c[0], c[1]};
+struct TileChoice { int bm, bn, ksplit; };
+// Tile/split heuristic for 256 CUs × 3 resident blocks: prefer 128x128 (best MFMA density per LDS byte);
+// when that leaves the chip under-filled, split K across grid.z (deterministic two-pass reduction)
+// before shrinking the tile.
+TileChoice choose_tile(int Cout, long npix, int nchunk, int classes) {
+  if (Cout <= 64) {
+    const long blocks = (long)di_div_up(npix, 128) * classes;
+    int ks = 1;
+    if (blocks < 512) ks = (int)min((long)di_div_up(768, blocks), (long)max(1, nchunk / 8));
+    return {64, 128, ks};
   }
-  return {64, 64};
+  const long blocks = (long)di_div_up(Cout, 128) * di_div_up(npix, 128) * classes;
+  int ks = 1;
+  if (blocks < 512) ks = (int)min((long)di_div_up(768, blocks), (long)max(1, nchunk / 8));
+  return {128, 128, ks};
 }
 
 template <int MODE>
-int launch_conv(deepim_ctx* ctx, const ConvParams& p, int gridz) {
-  const TileChoice t = choose_tile(p.Cout, p.npix);
-  dim3 grid(di_div_up(p.npix, t.bn), di_div_up(p.Cout, t.bm), gridz);
-  DI_REQUIRE(grid.y <= 65535 && grid.x > 0, "conv: grid too large");
-  if (t.bm == 128 && t.bn == 128)
+int launch_conv(deepim_ctx* ctx, ConvParams p, int classes) {
+  TileChoice t = choose_tile(p.Cout, p.npix, p.nchunk, classes);
+  if (ctx->conv_max_split > 0 && t.ksplit > ctx->conv_max_split) t.ksplit = ctx->conv_max_split;
+  p.ksplit = t.ksplit;
+  p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
+  p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
+  p.partial = nullptr;
+  p.partial_stride = (long)p.B * p.Cout * p.Ho * p.Wo;
+  if (p.ksplit > 1) {
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)p.ksplit * p.partial_stride * sizeof(float), &scratch);
+    if (rc) return rc;
+    p.partial = (float*)scratch;
+  }
+  dim3 grid(di_div_up(p.npix, t.bn), di_div_up(p.Cout, t.bm), classes * p.ksplit);
+  DI_REQUIRE(grid.y <= 65535 && grid.z <= 65535 && grid.x > 0, "conv: grid too large");
+  if (t.bm == 128)
     hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
-  else if (t.bm == 64 && t.bn == 128)
-    hipLaunchKernelGGL((conv_mfma_kernel<64, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
-  else if (t.bm == 128 && t.bn == 64)
-    hipLaunchKernelGGL((conv_mfma_kernel<128, 64, MODE>), grid, dim3(256), 0, ctx->stream, p);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<64, 64, MODE>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<64, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  if (p.ksplit > 1) {
+    const long total = p.partial_stride;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
+                       p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
+                       p.slope);
+  }
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->capturing = false;
+  c->conv_max_split = 0;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     deepim_set_error("hipStreamCreate", e);
@@ -110,6 +111,15 @@ extern "C" int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal,
                             (size_t)C * hw * sizeof(float), (size_t)C * hw * sizeof(float), (size_t)B,
                             hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
+}
+extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
+  if (strcmp(name, "conv_max_split") == 0) {
+    DI_REQUIRE(value >= 0, "conv_max_split must be >= 0");
+    ctx->conv_max_split = value;
+    return 0;
+  }
+  deepim_set_error_msg("deepim_set_option: unknown option");
+  return -1;
 }
 extern "C" int deepim_sync(deepim_ctx* ctx) {
   DI_CHECK(hipStreamSynchronize(ctx->stream));

@@ -46,6 +46,8 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES)
 def test_conv_bit_exact(ctx, case):
+    """conv_max_split=1: a single k-ordered fmaf chain per output → bit-identical to the oracle."""
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     B, cin, H, W, cout, k, s, p = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
@@ -53,7 +55,11 @@ def test_conv_bit_exact(ctx, case):
     b = rng.standard_normal(cout).astype(np.float32)
     got = _run_conv(ctx, x, w, b, s, p, 0.1)
     ref = onet.conv2d(x, w, b, s, p, 0.1)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     np.testing.assert_array_equal(got, ref)
+    # default policy (auto split-K on under-filled grids): same sum re-associated across K slices
+    got2 = _run_conv(ctx, x, w, b, s, p, 0.1)
+    assert np.abs(got2 - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_conv_matches_torch_cpu(ctx):
@@ -83,6 +89,7 @@ def test_conv_channel_slice_output(ctx):
 @pytest.mark.parametrize("case", [(2, 1024, 8, 10, 512, 15, 20), (2, 1026, 15, 20, 256, 30, 40), (2, 2, 8, 10, 2, 15, 20),
                                   (1, 5, 7, 9, 3, 15, 19)])
 def test_deconv_crop_bit_exact(ctx, case):
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     B, cin, H, W, cout, ho, wo = case
     rng = np.random.default_rng(7 + cin)
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
@@ -93,7 +100,13 @@ def test_deconv_crop_bit_exact(ctx, case):
     out = ctx.empty((B, cout, ho, wo))
     lib.deepim_deconv4x4s2_crop_forward(ctx.handle, out, ctx.array(x), pk, ctx.array(b), B, cin, H, W, cout, ho, wo, 1, 1,
                                         cf(0.1), 0, 0)
-    np.testing.assert_array_equal(out.asnumpy(), onet.deconv4x4s2_crop(x, w, b, ho, wo, (1, 1), 0.1))
+    ref = onet.deconv4x4s2_crop(x, w, b, ho, wo, (1, 1), 0.1)
+    got = out.asnumpy()
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    np.testing.assert_array_equal(got, ref)
+    lib.deepim_deconv4x4s2_crop_forward(ctx.handle, out, ctx.array(x), pk, ctx.array(b), B, cin, H, W, cout, ho, wo, 1, 1,
+                                        cf(0.1), 0, 0)
+    assert np.abs(out.asnumpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_upsample16_crop(ctx):

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import pipeline as opipe
 from mx_deepim_amd.config import default_config
+from mx_deepim_amd.runtime import lib
 from mx_deepim_amd.symbols import deepIM_flownet
 from mx_deepim_amd import synthetic
 
@@ -33,7 +34,9 @@ def test_fast_test_iteration_matches_oracle(ctx, small_batch):
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=7)
     net.bind(ctx, B, params)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)   # single fmaf chain per output → bit-exact convs
     pose = net.refine_iteration(_data(ctx, d)).asnumpy()
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     ref = opipe.refine_iteration(params, _np_data(d), d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds,
                                  cfg.network.ROT_COORD)
     np.testing.assert_array_equal(net.act["zoom_factor"].asnumpy(), ref["zoom_factor"])
@@ -44,6 +47,11 @@ def test_fast_test_iteration_matches_oracle(ctx, small_batch):
     assert np.abs(se3 - ref["se3"]).max() / np.abs(ref["se3"]).max() < 1e-4
     assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
     assert np.all(np.isfinite(pose)) and np.abs(ref["conv6_1"]).max() > 1e-3  # activations did not die
+    # default policy (auto split-K on the small deep layers): same results to fp32 re-association noise
+    pose2 = net.refine_iteration(_data(ctx, d)).asnumpy()
+    c2 = net.act["conv6_1"].asnumpy()
+    assert np.abs(c2 - ref["conv6_1"]).max() <= 1e-5 * np.abs(ref["conv6_1"]).max()
+    assert np.abs(pose2 - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
 
 
 def test_heads_iteration_matches_oracle(ctx, small_batch):
@@ -57,7 +65,9 @@ def test_heads_iteration_matches_oracle(ctx, small_batch):
     assert net.with_mask_head and net.with_flow_head
     params = net.init_weights(cfg, seed=8)
     net.bind(ctx, B, params)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     out = net.forward(_data(ctx, d1))
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     ref = opipe.refine_iteration(params, _np_data(d1), d["K"], MEANS_REV, cfg.dataset.trans_means,
                                  cfg.dataset.trans_stds, cfg.network.ROT_COORD, heads=True,
                                  normalize_flow=cfg.dataset.NORMALIZE_FLOW)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Per-layer timing of the encoder convs (HIP events on the context stream). Dev tool for kernel tuning:
+    python tools/bench_layers.py [--batch 16] [--reps 10]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mx_deepim_amd.config import default_config  # noqa: E402
+from mx_deepim_amd.runtime import Context  # noqa: E402
+from mx_deepim_amd.symbols import deepIM_flownet  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--heads", action="store_true")
+    a = ap.parse_args()
+    ctx = Context.get(0)
+    cfg = default_config()
+    if a.heads:
+        cfg.TEST.FAST_TEST = False
+    net = deepIM_flownet().get_symbol(cfg)
+    net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
+    rng = np.random.default_rng(0)
+    net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
+    net.encoder()
+    ctx.sync()
+    src = net.act["net_input"]
+    tot_ms, tot_fl = 0.0, 0.0
+    for name, cin, h, w, cout, k, s, p in net.enc_geom:
+        t = ctx.timer()
+        net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        t.start()
+        for _ in range(a.reps):
+            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        t.stop()
+        ms = t.elapsed_ms() / a.reps
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        fl = 2.0 * cout * cin * k * k * ho * wo * net.B
+        tot_ms += ms
+        tot_fl += fl
+        print(json.dumps({"layer": name, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                          "M": cout, "N": net.B * ho * wo, "K": cin * k * k}))
+        src = net.act[name]
+    print(json.dumps({"layer": "ENCODER", "ms": round(tot_ms, 4), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}))
+    if a.heads:
+        t = ctx.timer()
+        net.decoder(); net.heads()
+        t.start()
+        for _ in range(a.reps):
+            net.decoder(); net.heads()
+        t.stop()
+        print(json.dumps({"layer": "DECODER+HEADS", "ms": round(t.elapsed_ms() / a.reps, 4)}))
+
+
+if __name__ == "__main__":
+    main()
