@@ -47,7 +47,8 @@ int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_co
                          const float* src, int C, int B, size_t hw);
 void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
 /* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split (conv/deconv results
- * are then a single k-ordered fmaf chain, bit-identical to the oracle), n = cap. Unknown names fail. */
+ * are then a single k-ordered fmaf chain, bit-identical to the oracle), n = cap.
+ * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order. Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);

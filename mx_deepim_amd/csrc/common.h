@@ -19,6 +19,7 @@ struct deepim_ctx {
   std::vector<hipGraphExec_t> graphs;
   bool capturing;
   int conv_max_split;  // 0 auto, 1 off, n cap
+  int conv_xcd_swizzle;  // 1: XCD-aware tile order (default), 0: plain
 };
 
 void deepim_set_error(const char* where, hipError_t e);

@@ -59,7 +59,7 @@ __device__ __forceinline__ void lds_wait(f32x2 (&a)[TM], f32x2 (&b)[TN]) {
 struct ConvParams {
   const float* in;
   const float* wp;     // packed [Mgran][nchunk][KT][GRAN]
-  const int2* tab;     // per k: {element offset ci*H*W + ky*W + kx, (ky<<8)|kx}; padded k → ky = 31
+  const int2* tab;     // per k: {byte offset of tap (ci,ky,kx) from the pixel's tap origin, bit index ky*8+kx}; padded k → bit 63
   const float* bias;
   float* out;
   int B, Cin, H, W;         // input
@@ -75,6 +75,10 @@ struct ConvParams {
   int chunks_per_split;
   float* partial;           // [ksplit][B][Cout][Ho][Wo] raw partial sums when ksplit > 1
   long partial_stride;
+  int swizzle;              // XCD-aware tile order on/off
+  int gx, gy, gz;           // logical grid (pixel tiles, M tiles, classes*ksplit); launched 1-D and XCD-swizzled
+  int pad_bytes;            // buffer-descriptor base shift: (pad*W + pad)*4 so tap origins are >= 0
+  unsigned in_bytes;        // size of the input tensor (must stay < 2 GiB: 0x80000000 is the OOB marker)
 };
 
 template <int BM, int BN, int MODE>
@@ -84,6 +88,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   constexpr int NG = BM / GRAN;            // weight granules per block
   constexpr int EB = KT * BN / 256;        // gathered elements per thread per chunk (consecutive k rows)
   constexpr int KS = KT / 2;               // MFMA k-steps per chunk
+  constexpr int MPS = TM * TN;             // MFMAs per k-step
+  constexpr int Q = KS * MPS;              // issue slots per chunk (one per MFMA)
   __shared__ __attribute__((aligned(16))) float As[2][KT * BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][KT * BN];
 
@@ -91,19 +97,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int mb = blockIdx.y;               // M tile
-  const long n0 = (long)blockIdx.x * BN;   // first pixel of the tile
-  int zz = blockIdx.z;
+  // XCD-aware tile order: hardware sends block b to XCD b % 8; remap so that each XCD works on a
+  // contiguous run of (pixel-tile fastest) virtual ids — neighbours share weights (same M tile / K slice)
+  // and halo rows in that XCD's L2 instead of every XCD streaming every weight slab.
+  int vid;
+  {
+    const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+    vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
+  }
+  const int bx = vid % p.gx;
+  const int mb = (vid / p.gx) % p.gy;      // M tile
+  int zz = vid / (p.gx * p.gy);
+  const long n0 = (long)bx * BN;           // first pixel of the tile
   const int split = zz % p.ksplit;         // split-K slice
   zz /= p.ksplit;                          // deconv parity class
 
   // ---- per-thread gather state (fixed for the whole K loop) ----
+  // voff: byte offset of the pixel's tap origin inside the (shifted) input buffer descriptor, or the
+  // out-of-range marker; m64: bit (ky*8+kx) set when tap (ky,kx) lies inside the image (zero padding).
   const int gp = tid & (BN - 1);
   const int krow0 = __builtin_amdgcn_readfirstlane((tid / BN) * EB);
   const long pix = n0 + gp;
-  const float* sbase = p.in;  // start of this pixel's sample (always a valid address)
-  int poff = 0;               // element offset of tap (0,0) relative to sbase (may be negative at the border)
-  unsigned mky = 0, mkx = 0;
+  int voff = 0;  // < 2^31 always; bit 31 set by GATHER marks an invalid tap (or a thread beyond the last pixel)
+  unsigned long long m64 = 0;
   int par_y = 0, par_x = 0;
   long npix = p.npix;
   if (MODE == MODE_DECONV) {
@@ -112,16 +129,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     npix = (long)p.B * ((p.Ho - oy0 + 1) >> 1) * ((p.Wo - ox0 + 1) >> 1);
   }
   if (pix < npix) {
+    unsigned mky = 0, mkx = 0;
     if (MODE == MODE_CONV) {
       const int hw = p.Ho * p.Wo;
       const int n = (int)(pix / hw);
       const int r = (int)(pix - (long)n * hw);
       const int ho = r / p.Wo, wo = r - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      sbase = p.in + (long)n * p.Cin * p.H * p.W;
-      poff = hi0 * p.W + wi0;
+      voff = (n * p.Cin * p.H * p.W + hi0 * p.W + wi0) * 4 + p.pad_bytes;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 7; ++k) {  // kernels are <= 7x7: row/col 7 stay clear, so bit 63 (padded k) is never valid
         if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
         if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
       }
@@ -135,17 +152,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       const int r = (int)(pix - (long)n * hw);
       const int qy = r / nqx, qx = r - qy * nqx;
       const int y = 2 * qy + oy0 + p.crop_y, x = 2 * qx + ox0 + p.crop_x;  // uncropped coords
-      // taps: ky = par_y + 2*jy (jy∈{0,1}) ↔ iy = (y - ky)/2 = (y>>1) - jy ; table kx/ky hold jy/jx
+      // taps: ky = par_y + 2*jy (jy∈{0,1}) ↔ iy = (y - ky)/2 = (y>>1) - jy ; tap origin = (iy0-1, ix0-1)
       const int iy0 = (y >> 1), ix0 = (x >> 1);
-      sbase = p.in + (long)n * p.Cin * p.H * p.W;
-      poff = iy0 * p.W + ix0;
+      voff = (n * p.Cin * p.H * p.W + (iy0 - 1) * p.W + (ix0 - 1)) * 4 + p.pad_bytes;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (iy0 - j >= 0 && iy0 - j < p.H) mky |= 1u << j;
         if (ix0 - j >= 0 && ix0 - j < p.W) mkx |= 1u << j;
       }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
   }
+  const unsigned nlo = ~(unsigned)m64, nhi = ~(unsigned)(m64 >> 32);
+  // raw buffer over the input, base shifted down by pad_bytes so border tap origins stay non-negative
+  // (only offsets >= pad_bytes, i.e. addresses inside the tensor, are ever dereferenced)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
 
   const float* wblk = p.wp + ((long)mb * NG) * p.nchunk * (KT * GRAN) + tid * 4;
   if (MODE == MODE_DECONV) wblk += (long)zz * p.ngran * p.nchunk * (KT * GRAN);
@@ -156,34 +180,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int a_st = ((tid * 4) / GRAN) * BM + (tid * 4) % GRAN;
   const int b_st = krow0 * BN + gp;
 
-  float4 areg0, areg1;
+  float4 areg0 = make_float4(0, 0, 0, 0), areg1 = areg0;  // named scalars: an indexed array lands in scratch
   float breg[EB];
-  unsigned okbits = 0;
 
-// global → registers for chunk kc: one dwordx4 of packed weights per granule + EB gathered activations.
-// The tap table is wave-uniform (scalar loads); padding is branch-free (clamped address + select).
-#define LOAD_CHUNK(kc)                                                                                  \
-  {                                                                                                     \
-    areg0 = *reinterpret_cast<const float4*>(wblk + (long)(kc) * (KT * GRAN));                         \
-    if (NG == 2) areg1 = *reinterpret_cast<const float4*>(wblk + ((long)p.nchunk + (kc)) * (KT * GRAN)); \
-    const int2* tp = p.tab + (kc) * KT + krow0;                                                         \
-    okbits = 0;                                                                                         \
-    _Pragma("unroll") for (int e = 0; e < EB; ++e) {                                                    \
-      const int2 t = tp[e];                                                                             \
-      const unsigned ky = (unsigned)t.y >> 8, kx = (unsigned)t.y & 255u;                                \
-      const unsigned ok = (mky >> ky) & (mkx >> kx) & 1u;                                               \
-      okbits |= ok << e;                                                                                \
-      breg[e] = sbase[ok ? poff + t.x : 0];                                                             \
-    }                                                                                                   \
+// Zero padding: an out-of-range voffset makes the buffer load return 0.0 without touching memory.
+// Tap validity lives in two 32-bit words of INVERTED bits (nlo: taps 0-31, nhi: 32-63); the tap index is
+// wave-uniform, so the word select is one v_cndmask on an SGPR condition, then bfe + shift-or puts the
+// "invalid" bit into bit 31 of the voffset (>= num_records → hardware returns 0).
+#define GATHER(e, tq)                                                                                  \
+  {                                                                                                    \
+    const int tb = (tq)[e].y;                                                                          \
+    const unsigned word = (tb & 32) ? nhi : nlo;                                                       \
+    const unsigned inv = __builtin_amdgcn_ubfe(word, (unsigned)tb & 31u, 1u);                          \
+    breg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((inv << 31) | (unsigned)voff), (tq)[e].x, 0)); \
   }
-// registers → LDS; the zero-padding select happens here so the gathers stay in flight under the MFMAs
-#define STORE_CHUNK(buf)                                                                  \
-  {                                                                                       \
-    *reinterpret_cast<float4*>(&As[buf][a_st]) = areg0;                                   \
-    if (NG == 2) *reinterpret_cast<float4*>(&As[buf][a_st + GRAN]) = areg1;               \
-    _Pragma("unroll") for (int e = 0; e < EB; ++e)                                        \
-      Bs[buf][b_st + e * BN] = ((okbits >> e) & 1u) ? breg[e] : 0.f;                      \
-  }
+#define BSEL(e) breg[e]
+#define ALOAD0(kc) areg0 = *reinterpret_cast<const float4*>(wblk + (long)(kc) * (KT * GRAN));
+#define ALOAD1(kc) areg1 = *reinterpret_cast<const float4*>(wblk + ((long)p.nchunk + (kc)) * (KT * GRAN));
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -194,44 +207,105 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lrow = lane >> 5, lcol = lane & 31;
+  int2 tq[EB];  // tap-table entries (wave-uniform → SGPRs) of the chunk gathered next, loaded one chunk ahead
+  const int kc_last = kc_end - 1;
   if (kc_begin < kc_end) {
-    LOAD_CHUNK(kc_begin);
-    STORE_CHUNK(0);
+    // chunk kc_begin → LDS[0]; chunk kc_begin+1 → registers (stored during the first loop iteration)
+    const int2* tp0 = p.tab + kc_begin * KT + krow0;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) tq[e] = tp0[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) GATHER(e, tq)
+    ALOAD0(kc_begin)
+    if (NG == 2) ALOAD1(kc_begin)
+    *reinterpret_cast<float4*>(&As[0][a_st]) = areg0;
+    if (NG == 2) *reinterpret_cast<float4*>(&As[0][a_st + GRAN]) = areg1;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) Bs[0][b_st + e * BN] = BSEL(e);
+    const int k1 = min(kc_begin + 1, kc_last);
+    const int2* tp1 = p.tab + k1 * KT + krow0;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) tq[e] = tp1[e];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) GATHER(e, tq)
+    ALOAD0(k1)
+    if (NG == 2) ALOAD1(k1)
+    const int2* tp2 = p.tab + min(kc_begin + 2, kc_last) * KT + krow0;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) tq[e] = tp2[e];
   }
   __syncthreads();
 
+  // Main loop. One issue slot after every MFMA, fenced with sched_barrier(0) so hipcc keeps the order:
+  // the wave's own gather (tap decode + buffer_load), LDS fragment reads and LDS stores are issued in the
+  // shadow of its MFMAs (64 cycles each) instead of before/after the MFMA block.
+  // Software pipeline, two chunks deep with one register set: while chunk kc is multiplied out of
+  // LDS[buf], element e (slot e*Q/EB) first stores the value gathered during chunk kc-1 (it belongs to
+  // chunk kc+1) into LDS[buf^1], then re-issues its gather for chunk kc+2 — a full chunk (≈2000 cycles)
+  // of latency tolerance per load. Fragment reads of k-step s+1 are issued at slot s*MPS.
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const int buf = (kc - kc_begin) & 1;
-    const bool more = kc + 1 < kc_end;
-    if (more) LOAD_CHUNK(kc + 1);
+    const int kg = min(kc + 2, kc_last);                               // chunk gathered in this iteration
+    const int2* tpn = p.tab + min(kc + 3, kc_last) * KT + krow0;       // its successor's tap table
     const float* as = &As[buf][lrow * BM + wm0 + lcol];
     const float* bs = &Bs[buf][lrow * BN + wn0 + lcol];
-    // Operand fragments are read per k-step (ds_read2_b32, conflict-free); with 3 resident waves per SIMD
-    // one wave's LDS latency is covered by the other waves' MFMAs.
+    float* asn = &As[buf ^ 1][a_st];
+    float* bsn = &Bs[buf ^ 1][b_st];
     float av[2][TM], bv[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) av[0][i] = as[i * 32];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[0][j] = bs[j * 32];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[(s + 1) & 1][i] = as[(s + 1) * 2 * BM + i * 32];
+      for (int m = 0; m < MPS; ++m) {
+        const int i = m / TN, j = m % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+        const int q = s * MPS + m;
+        if (m == 0 && s + 1 < KS) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[(s + 1) & 1][j] = bs[(s + 1) * 2 * BN + j * 32];
+          for (int ii = 0; ii < TM; ++ii) av[(s + 1) & 1][ii] = as[(s + 1) * 2 * BM + ii * 32];
+#pragma unroll
+          for (int jj = 0; jj < TN; ++jj) bv[(s + 1) & 1][jj] = bs[(s + 1) * 2 * BN + jj * 32];
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          if (e * Q / EB + (MPS > 1 ? 1 : 0) == q) {
+#ifndef ABL_NOBSTORE
+            bsn[e * BN] = BSEL(e);
+#endif
+#ifndef ABL_NOGATHER
+            GATHER(e, tq)
+#endif
+          }
+        }
+#ifndef ABL_NOA
+        if (q == 2) {
+          *reinterpret_cast<float4*>(asn) = areg0;
+          ALOAD0(kg)
+        }
+        if (NG == 2 && q == 6) {
+          *reinterpret_cast<float4*>(asn + GRAN) = areg1;
+          ALOAD1(kg)
+        }
+#endif
+        if (q == Q - 1) {
+#pragma unroll
+          for (int e = 0; e < EB; ++e) tq[e] = tpn[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
     }
-    if (more) STORE_CHUNK(buf ^ 1);
+#ifndef ABL_NOBARRIER
     __syncthreads();
+#endif
   }
-#undef LOAD_CHUNK
-#undef STORE_CHUNK
+#undef GATHER
+#undef BSEL
+#undef ALOAD0
+#undef ALOAD1
 
   // ---- epilogue: bias + LeakyReLU, NCHW store (or raw partial sums for split-K) ----
   const bool partial = p.ksplit > 1;
@@ -330,16 +404,16 @@ __global__ void pack_deconv_kernel(float* __restrict__ packed, const float* __re
 __global__ void build_conv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int kh, int kw, int H, int W) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
-  if (k >= K) { tab[k] = make_int2(0, (31 << 8)); return; }
+  if (k >= K) { tab[k] = make_int2(0, 63); return; }
   const int kx = k % kw, ky = (k / kw) % kh, ci = k / (kw * kh);
-  tab[k] = make_int2(ci * H * W + ky * W + kx, (ky << 8) | kx);
+  tab[k] = make_int2((ci * H * W + ky * W + kx) * 4, ky * 8 + kx);
 }
 __global__ void build_deconv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int H, int W) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
-  if (k >= K) { tab[k] = make_int2(0, (31 << 8)); return; }
+  if (k >= K) { tab[k] = make_int2(0, 63); return; }
   const int ci = k >> 2, jy = (k >> 1) & 1, jx = k & 1;
-  tab[k] = make_int2(ci * H * W - jy * W - jx, (jy << 8) | jx);
+  tab[k] = make_int2((ci * H * W + (1 - jy) * W + (1 - jx)) * 4, jy * 8 + jx);  // origin = (iy0-1, ix0-1)
 }
 
 // grouped k32 s16 transposed conv (depthwise), cropped, scaled: ≤ 2x2 contributing inputs per output
@@ -405,8 +479,10 @@ int launch_conv(deepim_ctx* ctx, ConvParams p, int classes) {
     if (rc) return rc;
     p.partial = (float*)scratch;
   }
-  dim3 grid(di_div_up(p.npix, t.bn), di_div_up(p.Cout, t.bm), classes * p.ksplit);
-  DI_REQUIRE(grid.y <= 65535 && grid.z <= 65535 && grid.x > 0, "conv: grid too large");
+  p.swizzle = ctx->conv_xcd_swizzle;
+  p.gx = di_div_up(p.npix, t.bn); p.gy = di_div_up(p.Cout, t.bm); p.gz = classes * p.ksplit;
+  DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
+  dim3 grid(p.gx * p.gy * p.gz);
   if (t.bm == 128)
     hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
   else
@@ -488,6 +564,10 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
   p.out_coff = out_coff;
   p.slope = slope; p.crop_y = p.crop_x = 0;
   p.npix = (long)B * p.Ho * p.Wo;
+  p.pad_bytes = (pad * W + pad) * 4;
+  DI_REQUIRE((size_t)B * Cin * H * W * 4 + p.pad_bytes < 0x7fffffffUL, "conv2d: input tensor must be < 2 GiB per launch");
+  DI_REQUIRE(kh <= 7 && kw <= 7, "conv2d: kernel larger than 7 not supported");
+  p.in_bytes = (unsigned)((size_t)B * Cin * H * W * 4);
   int2* tab;
   int rc = get_tab(ctx, MODE_CONV, Cin, kh, kw, H, W, &tab);
   if (rc) return rc;
@@ -526,6 +606,9 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   // every parity class has at most ceil(Ho/2)*ceil(Wo/2) pixels; size the grid for the largest, the
   // kernel masks with its own per-class count
   p.npix = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+  p.pad_bytes = (W + 1) * 4;
+  DI_REQUIRE((size_t)B * Cin * H * W * 4 + p.pad_bytes < 0x7fffffffUL, "deconv: input tensor must be < 2 GiB per launch");
+  p.in_bytes = (unsigned)((size_t)B * Cin * H * W * 4);
   int2* tab;
   int rc = get_tab(ctx, MODE_DECONV, Cin, 4, 4, H, W, &tab);
   if (rc) return rc;

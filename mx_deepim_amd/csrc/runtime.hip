@@ -29,6 +29,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->scratch_bytes = 0;
   c->capturing = false;
   c->conv_max_split = 0;
+  c->conv_xcd_swizzle = 1;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     deepim_set_error("hipStreamCreate", e);
@@ -116,6 +117,10 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv_max_split") == 0) {
     DI_REQUIRE(value >= 0, "conv_max_split must be >= 0");
     ctx->conv_max_split = value;
+    return 0;
+  }
+  if (strcmp(name, "conv_xcd_swizzle") == 0) {
+    ctx->conv_xcd_swizzle = value ? 1 : 0;
     return 0;
   }
   deepim_set_error_msg("deepim_set_option: unknown option");

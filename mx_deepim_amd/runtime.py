@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libdeepim_hip.so")
+LIB_PATH = os.environ.get("DEEPIM_LIB", os.path.join(_HERE, "libdeepim_hip.so"))  # override: dev ablation builds
 HEADER_PATH = os.path.join(_ROOT, "include", "deepim_hip.h")
 
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--heads", action="store_true")
+    ap.add_argument("--swizzle", type=int, default=1)
     a = ap.parse_args()
     ctx = Context.get(0)
     cfg = default_config()
@@ -26,6 +27,8 @@ def main():
         cfg.TEST.FAST_TEST = False
     net = deepIM_flownet().get_symbol(cfg)
     net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
+    from mx_deepim_amd.runtime import lib
+    lib.deepim_set_option(ctx.handle, b"conv_xcd_swizzle", a.swizzle)
     rng = np.random.default_rng(0)
     net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
     net.encoder()
