@@ -12,6 +12,7 @@ N>1: one process per GPU (torch.distributed.run), per-GPU batch fixed (weak scal
 independent; after every refinement iteration the refined poses are all-gathered over RCCL (48 B/pair).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -77,13 +78,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dist = None
+    backend = os.environ.get("DEEPIM_BENCH_BACKEND", "nccl")   # "gloo": CPU-side gather, for single-GPU dry runs
+    ndev = ctypes.c_int(0)
+    lib.load().deepim_device_count(ctypes.byref(ndev))
+    device_id = local_rank % max(1, ndev.value)
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(device_id)
+        dist.init_process_group(backend)
 
-    ctx = Context.get(local_rank)
+    ctx = Context.get(device_id)
     h = ctx.handle
     B, NIT = args.batch, args.iters
     cfg = default_config()
@@ -97,11 +103,11 @@ def main():
     pose_init = ctx.array(batch["src_pose"][0])
     pose_cur = ctx.empty((B, 3, 4))
 
-    gather_in = gather_out = ext_stream = None
+    gather_in = gather_out = None
     if world > 1:
-        gather_in = torch.empty((B, 12), dtype=torch.float32, device="cuda")
-        gather_out = torch.empty((world * B, 12), dtype=torch.float32, device="cuda")
-        ext_stream = torch.cuda.ExternalStream(lib.load().deepim_stream(h))
+        gdev = "cuda" if backend == "nccl" else "cpu"
+        gather_in = torch.empty((B, 12), dtype=torch.float32, device=gdev)
+        gather_out = torch.empty((world * B, 12), dtype=torch.float32, device=gdev)
 
     enc_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
     zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
@@ -124,16 +130,23 @@ def main():
             net.pose_head()
             net.pose_update(pose_cur, pose_cur)   # refined pose becomes the next iteration's src_pose
             if world > 1:                          # every rank/host gets all refined poses
-                lib.deepim_d2d(h, gather_in.data_ptr(), pose_cur, pose_cur.nbytes)
-                with torch.cuda.stream(ext_stream):
+                if backend == "nccl":              # 48 B/pair over RCCL; the two host syncs cost ~20 us of a ~6 ms iteration
+                    lib.deepim_d2d(h, ctypes.c_void_p(gather_in.data_ptr()), pose_cur, pose_cur.nbytes)
+                    ctx.sync()
+                    dist.all_gather_into_tensor(gather_out, gather_in)
+                    torch.cuda.current_stream().synchronize()
+                else:
+                    lib.deepim_d2h(h, ctypes.c_void_p(gather_in.data_ptr()), pose_cur, pose_cur.nbytes)
                     dist.all_gather_into_tensor(gather_out, gather_in)
 
     def fence():
         ctx.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
         ctx.sync()
 
     for _ in range(args.warmup):
@@ -145,12 +158,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # the gather really delivered every rank's poses, in rank order
+        mine = gather_out.reshape(world, B, 12)[rank].cpu().numpy()
+        assert np.array_equal(mine, pose_cur.asnumpy().reshape(B, 12)), "all-gather returned wrong poses"
 
     # sanity: poses finite, zoom status clean
-    import ctypes
     st = ctypes.c_int(0)
     lib.deepim_zoom_status(h, ctypes.byref(st))
     pose_final = pose_cur.asnumpy()
