@@ -178,6 +178,11 @@ def main():
         flops = encoder_flops_per_pair(net.cin) * B
         achieved = flops / (enc_ms * 1e-3) / 1e12
         zoom_bytes = 2 * (net.cin * 480 * 640 * 4) * B   # read + write every zoomed channel once
+        traffic, traffic_src = None, None                # HBM bytes per conv launch group from a recorded PMC pass
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and B == 16:
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         out = {
             "metric": "pose-refinement iters/sec (4-iter loop, 480x640)",
             "value": iters_total / dt,
@@ -192,7 +197,7 @@ def main():
                                                                         "of refined poses per iteration" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (10 encoder launches per iteration)",
                          "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch_group": flops, "ms_per_launch_group": enc_ms},
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
