@@ -199,6 +199,13 @@ int deepim_pose_head_forward(deepim_ctx* ctx, float* se3 /*B,7*/, const float* f
 int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
                         const float* se3, const float* T_means_host, const float* T_stds_host,
                         int rot_coord, int B);
+/* calc_RT_delta (lib/pair_matching/RT_transform.py:16-44, rot_type QUAT) batched: the ground-truth
+ * (rot (B,4) w>=0, trans (B,3)) labels between a source and a target pose — R_inv_transform (:64-71),
+ * T_inv_transform (:105-124), mat2quat (:432-509, largest eigenvector of the 4x4 K matrix; Jacobi sweeps in
+ * float64 here). Used by the loader (data_pair.py:188-195) and the batch updater (:239-246). */
+int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot /*B,4*/, float* trans /*B,3*/, const float* pose_src,
+                         const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
+                         int rot_coord, int B);
 /* Transform3D forward/backward (deepim/operator_py/transform3d.py:34-151) */
 int deepim_transform3d_forward(deepim_ctx* ctx, float* out /*B,3,N*/, const float* points /*B,3,N*/,
                                const float* rotation /*B,4*/, const float* translation /*B,3*/,
@@ -222,6 +229,14 @@ int deepim_point_matching_loss(deepim_ctx* ctx, float* loss /*B,3,N*/, float* lo
 int deepim_flow_loss(deepim_ctx* ctx, float* loss /*n*/, float* loss_sum, float* d_est,
                      const float* est, const float* gt, const float* weights,
                      float normalize_flow, float grad_scale, size_t n);
+/* MXNet L2Normalization, instance mode (deepIM_flownet.py:217 `normalize_quat`): out = x / sqrt(Σx² + eps) */
+int deepim_l2_normalize_forward(deepim_ctx* ctx, float* out, const float* in, int B, int D, float eps);
+int deepim_l2_normalize_backward(deepim_ctx* ctx, float* d_in, const float* d_out, const float* in, int B, int D,
+                                 float eps);
+/* rotation distance loss (deepIM_flownet.py:238-248): loss_b = 1 − (q_gt·q_est)², d_q_est = −2(q_gt·q_est)·q_gt·grad_scale.
+ * The translation distance loss (:250-262) is deepim_point_matching_loss with N = 1, normalize = 1, no weights. */
+int deepim_rot_dist_loss(deepim_ctx* ctx, float* loss /*B*/, float* d_q_est /*B,4 or NULL*/, const float* q_gt,
+                         const float* q_est, float grad_scale, int B);
 /* mask head test path (deepIM_flownet.py:647-666): sigmoid → ZoomMaskWithFactor(inverse)
  * → round. `logits` is the cropped upsampled mask_conv3 output (B,1,H,W). prob optional. */
 int deepim_mask_head_forward(deepim_ctx* ctx, float* mask_pred /*B,1,H,W*/, float* prob /*or NULL*/,

@@ -109,6 +109,37 @@ __global__ __launch_bounds__(256) void group_pick_kernel(float* __restrict__ out
   }
 }
 
+// one thread per row (D is 3 or 4 here)
+__global__ void l2norm_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ d_out,
+                              int B, int D, float eps, int backward) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* x = in + (long)b * D;
+  float ss = 0.f;
+  for (int i = 0; i < D; ++i) ss += x[i] * x[i];
+  const float nrm = sqrtf(ss + eps);
+  if (!backward) {
+    for (int i = 0; i < D; ++i) out[(long)b * D + i] = x[i] / nrm;
+  } else {  // d_x = (d_y − y·Σ(d_y·y)) / norm
+    const float* g = d_out + (long)b * D;
+    float dot = 0.f;
+    for (int i = 0; i < D; ++i) dot += g[i] * (x[i] / nrm);
+    for (int i = 0; i < D; ++i) out[(long)b * D + i] = (g[i] - (x[i] / nrm) * dot) / nrm;
+  }
+}
+
+__global__ void rot_dist_kernel(float* __restrict__ loss, float* __restrict__ d_q, const float* __restrict__ q_gt,
+                                const float* __restrict__ q_est, float grad_scale, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* g = q_gt + b * 4;
+  const float* e = q_est + b * 4;
+  const float dot = ((g[0] * e[0] + g[1] * e[1]) + g[2] * e[2]) + g[3] * e[3];
+  loss[b] = 1.f - dot * dot;
+  if (d_q)
+    for (int i = 0; i < 4; ++i) d_q[b * 4 + i] = -2.f * dot * g[i] * grad_scale;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
                                                    size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -116,6 +147,28 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
 }
 
 }  // namespace
+
+extern "C" int deepim_l2_normalize_forward(deepim_ctx* ctx, float* out, const float* in, int B, int D, float eps) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(l2norm_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, out, in, nullptr, B, D, eps, 0);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int deepim_l2_normalize_backward(deepim_ctx* ctx, float* d_in, const float* d_out, const float* in, int B,
+                                            int D, float eps) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(l2norm_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, d_in, in, d_out, B, D, eps, 1);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int deepim_rot_dist_loss(deepim_ctx* ctx, float* loss, float* d_q_est, const float* q_gt, const float* q_est,
+                                    float grad_scale, int B) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(rot_dist_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, loss, d_q_est, q_gt, q_est,
+                     grad_scale, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n) {
   if (n == 0) return 0;

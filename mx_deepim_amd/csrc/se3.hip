@@ -87,6 +87,103 @@ __global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __rest
   }
 }
 
+// --- calc_RT_delta (ground-truth labels) --------------------------------------------
+// largest eigenvector of a symmetric 4x4 (cyclic Jacobi, float64) — mat2quat, RT_transform.py:485-509
+__device__ void sym4_max_eigvec(double A[4][4], double* vec) {
+  double V[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 4; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; ++i)
+    if (A[i][i] > A[best][best]) best = i;
+  for (int k = 0; k < 4; ++k) vec[k] = V[k][best];
+}
+
+__global__ void calc_rt_delta_kernel(float* __restrict__ rot, float* __restrict__ trans,
+                                     const float* __restrict__ pose_src, const float* __restrict__ pose_tgt, Vec3d mu,
+                                     Vec3d sd, int rc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* S = pose_src + b * 12;
+  const float* T = pose_tgt + b * 12;
+  float Rd[9];
+  double Td[3];
+  if (rc == RC_NAIVE) {  // se3_mul(tgt, se3_inverse(src)), float32 (projection.py)
+    float Ri[9], ti[3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = S[j * 4 + i];
+    for (int i = 0; i < 3; ++i) ti[i] = -1.f * ((Ri[i * 3 + 0] * S[3] + Ri[i * 3 + 1] * S[7]) + Ri[i * 3 + 2] * S[11]);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j)
+        Rd[i * 3 + j] = (T[i * 4 + 0] * Ri[0 * 3 + j] + T[i * 4 + 1] * Ri[1 * 3 + j]) + T[i * 4 + 2] * Ri[2 * 3 + j];
+      Td[i] = (double)(((T[i * 4 + 0] * ti[0] + T[i * 4 + 1] * ti[1]) + T[i * 4 + 2] * ti[2]) + T[i * 4 + 3]);
+    }
+  } else {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        if (rc == RC_MODEL)  // R_src^T · R_tgt
+          Rd[i * 3 + j] = (S[0 * 4 + i] * T[0 * 4 + j] + S[1 * 4 + i] * T[1 * 4 + j]) + S[2 * 4 + i] * T[2 * 4 + j];
+        else                 // R_tgt · R_src^T
+          Rd[i * 3 + j] = (T[i * 4 + 0] * S[j * 4 + 0] + T[i * 4 + 1] * S[j * 4 + 1]) + T[i * 4 + 2] * S[j * 4 + 2];
+      }
+    const float sx = S[3], sy = S[7], sz = S[11], tx = T[3], ty = T[7], tz = T[11];
+    double d[3];
+    if (rc == RC_CAMERA_NEW) {
+      d[0] = (double)((tx - sx) / sz);
+      d[1] = (double)((ty - sy) / sz);
+    } else {
+      d[0] = (double)(tx / tz - sx / sz);
+      d[1] = (double)(ty / tz - sy / sz);
+    }
+    d[2] = (double)logf(sz / tz);
+    for (int i = 0; i < 3; ++i) Td[i] = (d[i] - mu.v[i]) / sd.v[i];
+  }
+  // mat2quat: K from the 3x3 (Q_ab = contribution of input a to output b = M[b][a])
+  const double Qxx = Rd[0], Qyx = Rd[1], Qzx = Rd[2], Qxy = Rd[3], Qyy = Rd[4], Qzy = Rd[5], Qxz = Rd[6], Qyz = Rd[7],
+               Qzz = Rd[8];
+  double K[4][4] = {{Qxx - Qyy - Qzz, Qyx + Qxy, Qzx + Qxz, Qyz - Qzy},
+                    {Qyx + Qxy, Qyy - Qxx - Qzz, Qzy + Qyz, Qzx - Qxz},
+                    {Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, Qxy - Qyx},
+                    {Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz}};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) K[i][j] /= 3.0;
+  double v[4];
+  sym4_max_eigvec(K, v);
+  double q[4] = {v[3], v[0], v[1], v[2]};
+  if (q[0] < 0)
+    for (int i = 0; i < 4; ++i) q[i] = -q[i];
+  for (int i = 0; i < 4; ++i) rot[b * 4 + i] = (float)q[i];
+  for (int i = 0; i < 3; ++i) trans[b * 3 + i] = (float)Td[i];
+}
+
 // --- Transform3D --------------------------------------------------------------
 // quat2mat_forward (transform3d.py:185-212): identity unless |Nq-1| < 1e-2; float64 math, float32 result
 __device__ void t3d_quat2mat(const float* q, float* M) {
@@ -274,6 +371,17 @@ extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pos
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
   hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
                      pose_src, se3, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot, float* trans, const float* pose_src,
+                                    const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
+                                    int rot_coord, int B) {
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "calc_rt_delta: unknown rot_coord");
+  hipLaunchKernelGGL(calc_rt_delta_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rot, trans, pose_src,
+                     pose_tgt, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -63,3 +63,24 @@ def group_picker_backward(out_grad, group_idx, group_num, C):
         g = int(np.squeeze(group_idx[b]))
         g_in[b, cg * g:cg * (g + 1)] = og[b]
     return g_in
+
+
+def l2_normalize(x, eps=1e-10):
+    """MXNet L2Normalization (instance mode): x / sqrt(sum(x^2) + eps) (deepIM_flownet.py:217)."""
+    x = np.asarray(x, f32)
+    nrm = np.sqrt(np.sum(x.astype(np.float64) ** 2, axis=1, keepdims=True) + eps)
+    return (x / nrm).astype(f32)
+
+
+def l2_normalize_backward(d_out, x, eps=1e-10):
+    x, g = np.asarray(x, np.float64), np.asarray(d_out, np.float64)
+    nrm = np.sqrt(np.sum(x ** 2, axis=1, keepdims=True) + eps)
+    y = x / nrm
+    return ((g - y * np.sum(g * y, axis=1, keepdims=True)) / nrm).astype(f32)
+
+
+def rot_dist_loss(q_gt, q_est, grad_scale=1.0):
+    """deepIM_flownet.py:238-248: 1 - (q_gt . q_est)^2 and its gradient w.r.t. q_est (MakeLoss grad_scale)."""
+    q_gt, q_est = np.asarray(q_gt, np.float64), np.asarray(q_est, np.float64)
+    dot = np.sum(q_gt * q_est, axis=1)
+    return (1 - dot ** 2).astype(f32), (-2 * dot[:, None] * q_gt * grad_scale).astype(f32)

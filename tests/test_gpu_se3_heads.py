@@ -106,3 +106,49 @@ def test_group_picker(ctx):
     gin = ctx.empty((B, C))
     lib.deepim_group_picker_backward(ctx.handle, gin, ctx.array(og), ctx.array(idx), G, B, C)
     np.testing.assert_array_equal(gin.asnumpy(), oh.group_picker_backward(og, idx, G, C))
+
+
+@pytest.mark.parametrize("coord", list(COORDS))
+def test_calc_rt_delta(ctx, coord):
+    """Ground-truth labels (calc_RT_delta, rot_type QUAT) vs the oracle, which is pinned to the reference."""
+    rng = np.random.default_rng(6)
+    B = 33
+    src, tgt = _poses(rng, B), _poses(rng, B)
+    mu, sd = np.array([0.01, -0.02, 0.03], np.float32), np.array([0.9, 1.1, 1.2], np.float32)
+    rot, trans = ctx.empty((B, 4)), ctx.empty((B, 3))
+    lib.deepim_calc_rt_delta(ctx.handle, rot, trans, ctx.array(src), ctx.array(tgt), mu, sd, COORDS[coord], B)
+    for b in range(B):
+        q, t = ose3.calc_RT_delta(src[b], tgt[b], mu.astype(np.float64), sd.astype(np.float64), coord, "QUAT")
+        np.testing.assert_allclose(rot.asnumpy()[b], q, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(trans.asnumpy()[b], t, rtol=1e-5, atol=1e-6)
+    # round trip: applying the delta to the source pose reproduces the target (north_star 1e-4 bar)
+    se3 = np.concatenate([rot.asnumpy(), trans.asnumpy()], 1).astype(np.float32)
+    out = ctx.empty((B, 3, 4))
+    lib.deepim_rt_transform(ctx.handle, out, None, ctx.array(src), ctx.array(se3), mu, sd, COORDS[coord], B)
+    np.testing.assert_allclose(out.asnumpy(), tgt, rtol=1e-4, atol=1e-5)
+
+
+def test_l2_normalize_and_rot_dist_loss(ctx):
+    rng = np.random.default_rng(7)
+    B = 19
+    x = rng.standard_normal((B, 4)).astype(np.float32)
+    g = rng.standard_normal((B, 4)).astype(np.float32)
+    out, gin = ctx.empty((B, 4)), ctx.empty((B, 4))
+    lib.deepim_l2_normalize_forward(ctx.handle, out, ctx.array(x), B, 4, cf(1e-10))
+    np.testing.assert_allclose(out.asnumpy(), oh.l2_normalize(x), rtol=1e-6, atol=1e-7)
+    lib.deepim_l2_normalize_backward(ctx.handle, gin, ctx.array(g), ctx.array(x), B, 4, cf(1e-10))
+    np.testing.assert_allclose(gin.asnumpy(), oh.l2_normalize_backward(g, x), rtol=1e-5, atol=1e-6)
+    qg = oh.l2_normalize(rng.standard_normal((B, 4)).astype(np.float32))
+    qe = oh.l2_normalize(x)
+    loss, dq = ctx.empty((B,)), ctx.empty((B, 4))
+    lib.deepim_rot_dist_loss(ctx.handle, loss, dq, ctx.array(qg), ctx.array(qe), cf(0.5), B)
+    rl, rd = oh.rot_dist_loss(qg, qe, 0.5)
+    np.testing.assert_allclose(loss.asnumpy(), rl, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dq.asnumpy(), rd, rtol=1e-5, atol=1e-6)
+    # translation distance loss = point_matching_loss with N=1, normalize 1 (deepIM_flownet.py:250-262)
+    est, gt = rng.standard_normal((B, 3, 1)).astype(np.float32), rng.standard_normal((B, 3, 1)).astype(np.float32)
+    l, s, d = ctx.empty(est.shape), ctx.empty((1,)), ctx.empty(est.shape)
+    lib.deepim_point_matching_loss(ctx.handle, l, s, d, ctx.array(est), ctx.array(gt), None, cf(1.0), 2, cf(3.0), cf(1.0), B, 1)
+    rl2, _, rg2 = oh.point_matching_loss(est, gt, None, 1.0, "smooth_L1", 3.0, 1.0)
+    np.testing.assert_allclose(l.asnumpy(), rl2, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(d.asnumpy(), rg2, rtol=1e-6, atol=1e-7)
