@@ -138,8 +138,9 @@ int deepim_zoom_trans_backward(deepim_ctx* ctx, const float* zoom_factor, const 
                                float* in_grad, int b_inv_zoom, int b_zoom_grad, int B);
 /* Fused front end of the test graph (deepIM_flownet.py:33-62 + :563-622): ZoomMask +
  * ZoomImageWithFactor [+ ZoomDepth] + `/255` + Concat written straight into the
- * conv1 input (B,C,H,W), C = 8 (6 when masks_in_net==0, +2 with depth). Also returns zoom_factor.
- * depth_* may be NULL. */
+ * conv1 input (B,C,H,W), C = 8 (+2 with depth). Also returns zoom_factor. depth_* may be NULL.
+ * With both masks NULL (INPUT_MASK=False, deepIM_flownet.py:594-605) the factor comes from ZoomImage's
+ * non-black-pixel boxes and C = 6 (+2 with depth). */
 int deepim_zoom_concat_forward(deepim_ctx* ctx,
                                const float* image_observed, const float* image_rendered,
                                const float* mask_observed, const float* mask_rendered,

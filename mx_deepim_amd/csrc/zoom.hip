@@ -250,6 +250,61 @@ __global__ __launch_bounds__(256) void resample_kernel(Plan plan, const float* _
   }
 }
 
+// 4 consecutive output pixels per thread (W % 4 == 0): the row taps are shared, the 16 tap loads of a
+// channel are issued together, results leave as one dwordx4 store; 1-D grid over pixel quads so no lane is
+// idle on the 640-wide rows. Same arithmetic, operation by operation, as resample_kernel.
+__global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* __restrict__ zoom_factor, int H, int W,
+                                                        float gx_step, float gy_step) {
+  const int qpr = W >> 2;
+  const int qid = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (qid >= qpr * H) return;
+  const int h = qid / qpr, w0 = (qid - h * qpr) << 2;
+  const Affine a = load_affine(zoom_factor, b, plan.inverse, H, W);
+  Taps t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = make_taps(a, h, w0 + i, H, W, gx_step, gy_step);
+  const long row0 = (long)t[0].y0 * W;
+  const long opix = (long)h * W + w0;
+  const int sy0 = (int)floorf((float)H / 2 - 5), sy1 = (int)ceilf((float)H / 2 + 5);
+  const int sx0 = (int)floorf((float)W / 2 - 5), sx1 = (int)ceilf((float)W / 2 + 5);
+  for (int c = 0; c < plan.n; ++c) {
+    const Chan& ch = plan.ch[c];
+    const float* s = ch.src + (long)b * ch.src_bstride + row0;
+    const int fl = ch.flags;
+    float tl[4], tr[4], bl[4], br[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x0 = t[i].x0;
+      tl[i] = t[i].in00 ? s[x0] : 0.f;
+      tr[i] = t[i].in01 ? s[x0 + 1] : 0.f;
+      bl[i] = t[i].in10 ? s[x0 + W] : 0.f;
+      br[i] = t[i].in11 ? s[x0 + W + 1] : 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ptl = t[i].in00 ? pre_op(tl[i], ch.mean, fl) : 0.f;
+      const float ptr_ = t[i].in01 ? pre_op(tr[i], ch.mean, fl) : 0.f;
+      const float pbl = t[i].in10 ? pre_op(bl[i], ch.mean, fl) : 0.f;
+      const float pbr = t[i].in11 ? pre_op(br[i], ch.mean, fl) : 0.f;
+      float v = blend(ptl, ptr_, pbl, pbr, t[i].wy0, t[i].wx0);
+      if (fl & CF_HIGHLIGHT) {
+        const bool spot = h >= sy0 && h < sy1 && w0 + i >= sx0 && w0 + i < sx1;
+        v = fmaxf(v, ((fl & CF_HIGHLIGHT_RED) && spot) ? 255.f : 0.f);
+      }
+      v = v - ch.mean;
+      if (fl & CF_POST_ROUND) v = roundf(v);
+      if (fl & CF_POST_DIV255) v = v / 255.0f;
+      if (fl & CF_POST_MUL_WX) v = v * a.wx_in;
+      if (fl & CF_POST_DIV_WX) v = v / a.wx_in;
+      if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
+      o[i] = v;
+    }
+    *reinterpret_cast<float4*>(ch.dst + (long)b * ch.dst_bstride + opix) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void indices_kernel(int32_t* __restrict__ idx, const float* __restrict__ zoom_factor,
                                                       int H, int W, float gx_step, float gy_step) {
   const int w = blockIdx.x * 256 + threadIdx.x;
@@ -277,8 +332,16 @@ __global__ void zoom_trans_kernel(float* __restrict__ out, const float* __restri
 int launch_resample(deepim_ctx* ctx, const Plan& plan, const float* zoom_factor, int B, int H, int W) {
   if (B == 0) return 0;
   const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
-  dim3 grid(di_div_up(W, 256), H, B);
-  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, ctx->stream, plan, zoom_factor, H, W, gx, gy);
+  bool vec4 = (W & 3) == 0;
+  for (int c = 0; c < plan.n && vec4; ++c)
+    vec4 = (((size_t)plan.ch[c].dst & 15) == 0) && ((plan.ch[c].dst_bstride & 3) == 0);
+  if (vec4) {
+    dim3 grid(di_div_up((long)(W / 4) * H, 256), B);
+    hipLaunchKernelGGL(resample4_kernel, grid, dim3(256), 0, ctx->stream, plan, zoom_factor, H, W, gx, gy);
+  } else {
+    dim3 grid(di_div_up(W, 256), H, B);
+    hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, ctx->stream, plan, zoom_factor, H, W, gx, gy);
+  }
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -432,12 +495,17 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
                                           const float* src_pose, const float* K_host, const float* pixel_means_host,
                                           float* net_input, float* zoom_factor, int B, int H, int W) {
   if (B == 0) return 0;
-  DI_REQUIRE(mask_observed && mask_rendered, "zoom_concat: masks are required (ZoomMask computes the factor)");
+  DI_REQUIRE((mask_observed == nullptr) == (mask_rendered == nullptr), "zoom_concat: pass both masks or neither");
+  const bool with_mask = mask_observed != nullptr;
   const long p = (long)H * W;
-  const int C = 8 + (depth_observed ? 2 : 0);
-  // test graph: mask_gt_observed ≡ mask_observed (deepIM_flownet.py:564)
-  int rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
-                               src_pose, K_host, B, H, W);
+  const int C = 6 + (with_mask ? 2 : 0) + (depth_observed ? 2 : 0);
+  int rc;
+  if (with_mask)  // ZoomMask; test graph: mask_gt_observed ≡ mask_observed (deepIM_flownet.py:564)
+    rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
+                             src_pose, K_host, B, H, W);
+  else            // ZoomImage: boxes of the non-black pixels (deepIM_flownet.py:594-605, zoom_image.py:31-37)
+    rc = compute_zoom_factor(ctx, zoom_factor, image_observed, image_rendered, BB_IMAGE, BB_IMAGE, pixel_means_host,
+                             src_pose, K_host, B, H, W);
   if (rc) return rc;
   Plan plan; plan.inverse = 0;
   int n = 0;
@@ -449,8 +517,10 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
     plan.ch[n] = make_chan(depth_observed, net_input + n * p, p, db, 0.f, CF_POST_DIV255); ++n;
     plan.ch[n] = make_chan(depth_rendered, net_input + n * p, p, db, 0.f, CF_POST_DIV255); ++n;
   }
-  plan.ch[n] = make_chan(mask_observed, net_input + n * p, p, db, 0.f, CF_POST_ROUND); ++n;
-  plan.ch[n] = make_chan(mask_rendered, net_input + n * p, p, db, 0.f, CF_PRE_BIN02 | CF_POST_ROUND); ++n;
+  if (with_mask) {
+    plan.ch[n] = make_chan(mask_observed, net_input + n * p, p, db, 0.f, CF_POST_ROUND); ++n;
+    plan.ch[n] = make_chan(mask_rendered, net_input + n * p, p, db, 0.f, CF_PRE_BIN02 | CF_POST_ROUND); ++n;
+  }
   plan.n = n;
   return launch_resample(ctx, plan, zoom_factor, B, H, W);
 }

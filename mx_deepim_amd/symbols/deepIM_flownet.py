@@ -216,15 +216,12 @@ class deepIM_flownet(object):
 
     def zoom(self, data):
         A, h = self.act, self.ctx.handle
-        if self.input_mask:
-            lib.deepim_zoom_concat_forward(
-                h, data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
-                data.get("depth_observed") if self.input_depth else None,
-                data.get("depth_rendered") if self.input_depth else None,
-                data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], self.B, self.H, self.W)
-        else:
-            # ZoomImage variant (deepIM_flownet.py:594-605): factor from non-black pixels; /255 + Concat after
-            raise NotImplementedError("INPUT_MASK=False test graph: use operator_py.ZoomImage + conv stack directly")
+        lib.deepim_zoom_concat_forward(
+            h, data["image_observed"], data["image_rendered"],
+            data["mask_observed"] if self.input_mask else None, data["mask_rendered"] if self.input_mask else None,
+            data.get("depth_observed") if self.input_depth else None,
+            data.get("depth_rendered") if self.input_depth else None,
+            data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], self.B, self.H, self.W)
 
     def encoder(self):
         A = self.act

@@ -267,11 +267,15 @@ def net_input(image_observed, image_rendered, mask_observed, mask_rendered, src_
               depth_observed=None, depth_rendered=None):
     """Front end of the test graph (deepIM_flownet.py:563-622 + :33-62): ZoomMask (gt ≡ observed)
     → ZoomImageWithFactor [→ ZoomDepth] → /255 → Concat."""
-    zmo, _, zmr, zf = zoom_mask(mask_observed, mask_observed, mask_rendered, src_pose, K)
-    zio, zir = zoom_image_with_factor(zf, image_observed, image_rendered, pixel_means)
+    if mask_observed is None:   # INPUT_MASK=False: ZoomImage computes the factor (deepIM_flownet.py:594-605)
+        zio, zir, zf = zoom_image(image_observed, image_rendered, src_pose, K, pixel_means)
+    else:
+        zmo, _, zmr, zf = zoom_mask(mask_observed, mask_observed, mask_rendered, src_pose, K)
+        zio, zir = zoom_image_with_factor(zf, image_observed, image_rendered, pixel_means)
     parts = [(zio / f32(255.0)).astype(f32), (zir / f32(255.0)).astype(f32)]
     if depth_observed is not None:
         zdo, zdr = zoom_depth(zf, depth_observed, depth_rendered)
         parts += [(zdo / f32(255.0)).astype(f32), (zdr / f32(255.0)).astype(f32)]
-    parts += [zmo, zmr]
+    if mask_observed is not None:
+        parts += [zmo, zmr]
     return np.concatenate(parts, axis=1), zf

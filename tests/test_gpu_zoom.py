@@ -134,3 +134,28 @@ def test_fused_front_end_equals_separate_ops(ctx, small_batch):
                                    ctx.array(d["src_pose"][0]), d["K"], MEANS_REV, x, zf, B, H, W)
     np.testing.assert_array_equal(zf.asnumpy(), rzf)
     np.testing.assert_array_equal(x.asnumpy(), ref)
+
+
+def test_fused_front_end_without_masks(ctx, small_batch):
+    """INPUT_MASK=False test graph (deepIM_flownet.py:594-605): ZoomImage computes the factor, C = 6."""
+    d = small_batch
+    B, _, H, W = d["image_observed"].shape
+    ref, rzf = oz.net_input(d["image_observed"], d["image_rendered"][0], None, None, d["src_pose"][0], d["K"], MEANS_REV)
+    x, zf = ctx.empty((B, 6, H, W)), ctx.empty((B, 4))
+    lib.deepim_zoom_concat_forward(ctx.handle, ctx.array(d["image_observed"]), ctx.array(d["image_rendered"][0]), None, None,
+                                   None, None, ctx.array(d["src_pose"][0]), d["K"], MEANS_REV, x, zf, B, H, W)
+    np.testing.assert_array_equal(zf.asnumpy(), rzf)
+    np.testing.assert_array_equal(x.asnumpy(), ref)
+
+
+def test_resample_scalar_path_unaligned_width(ctx):
+    """W % 4 != 0 takes the one-pixel-per-thread kernel; same results as the oracle."""
+    rng = np.random.default_rng(8)
+    B, H, W = 2, 30, 42
+    x = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    zf = np.array([[0.5, 0.5, 0.1, -0.2], [1.7, 1.7, -0.3, 0.25]], np.float32)
+    o0, o1 = ctx.empty(x.shape), ctx.empty(x.shape)
+    lib.deepim_zoom_depth_forward(ctx.handle, ctx.array(zf), ctx.array(x), ctx.array(x), o0, o1, B, H, W)
+    r0, _ = oz.zoom_depth(zf, x, x)
+    np.testing.assert_array_equal(o0.asnumpy(), r0)
+    np.testing.assert_array_equal(o1.asnumpy(), r0)
