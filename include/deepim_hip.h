@@ -48,7 +48,10 @@ int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_co
 void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
 /* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split (conv/deconv results
  * are then a single k-ordered fmaf chain, bit-identical to the oracle), n = cap.
- * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order. Unknown names fail. */
+ * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order.
+ * "conv_autotune": 1 (default) = on the first call of a conv geometry, time a few split-K factors and keep
+ * the fastest; 0 = heuristic only ("conv_split_below"/"conv_split_target": split when the grid has fewer
+ * than `below` blocks, aiming at `target`). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);

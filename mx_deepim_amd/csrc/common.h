@@ -7,6 +7,11 @@
 #include <vector>
 #include "../../include/deepim_hip.h"
 
+struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry
+
+struct ConvPlanKey { int mode, B, Cin, H, W, Cout, Ho, Wo, stride, pad, nchunk, below, target; };
+struct ConvPlan { ConvPlanKey key; int ksplit; };  // autotuned split-K factor of one conv geometry
+
 struct deepim_ctx {
   int device;
   hipStream_t stream;
@@ -18,8 +23,12 @@ struct deepim_ctx {
   std::vector<hipEvent_t> timer_start, timer_stop;
   std::vector<hipGraphExec_t> graphs;
   bool capturing;
+  std::vector<ConvTab> conv_tabs;
+  std::vector<ConvPlan> conv_plans;
+  int conv_autotune;  // 1 (default): time split-K candidates on the first call of a geometry
   int conv_max_split;  // 0 auto, 1 off, n cap
   int conv_xcd_swizzle;  // 1: XCD-aware tile order (default), 0: plain
+  int conv_split_below, conv_split_target;  // split K when blocks < below, aiming at ~target blocks
 };
 
 void deepim_set_error(const char* where, hipError_t e);

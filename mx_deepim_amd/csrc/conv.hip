@@ -448,26 +448,21 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
 }
 
 struct TileChoice { int bm, bn, ksplit; };
-// Tile/split heuristic for 256 CUs × 3 resident blocks: prefer 128x128 (best MFMA density per LDS byte);
-// when that leaves the chip under-filled, split K across grid.z (deterministic two-pass reduction)
-// before shrinking the tile.
-TileChoice choose_tile(int Cout, long npix, int nchunk, int classes) {
-  if (Cout <= 64) {
-    const long blocks = (long)di_div_up(npix, 128) * classes;
-    int ks = 1;
-    if (blocks < 512) ks = (int)min((long)di_div_up(768, blocks), (long)max(1, nchunk / 8));
-    return {64, 128, ks};
-  }
-  const long blocks = (long)di_div_up(Cout, 128) * di_div_up(npix, 128) * classes;
+// Tile/split heuristic for 256 CUs × 3 resident blocks: 128x128 (best MFMA density per LDS byte and per
+// gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the chip under-filled, split K
+// across grid.z (deterministic two-pass reduction) before shrinking the tile.
+TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, int classes) {
+  const int below = ctx->conv_split_below, target = ctx->conv_split_target;
+  int bm = 128, bn = 128;
+  if (Cout <= 64) { bm = 64; bn = npix >= 256L * 1024 ? 256 : 128; }
+  const long blocks = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
   int ks = 1;
-  if (blocks < 512) ks = (int)min((long)di_div_up(768, blocks), (long)max(1, nchunk / 8));
-  return {128, 128, ks};
+  if (blocks < below) ks = (int)min((long)di_div_up(target, blocks), (long)max(1, nchunk / 8));
+  return {bm, bn, ks};
 }
 
 template <int MODE>
-int launch_conv(deepim_ctx* ctx, ConvParams p, int classes) {
-  TileChoice t = choose_tile(p.Cout, p.npix, p.nchunk, classes);
-  if (ctx->conv_max_split > 0 && t.ksplit > ctx->conv_max_split) t.ksplit = ctx->conv_max_split;
+int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   p.ksplit = t.ksplit;
   p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
   p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
@@ -485,6 +480,8 @@ int launch_conv(deepim_ctx* ctx, ConvParams p, int classes) {
   dim3 grid(p.gx * p.gy * p.gz);
   if (t.bm == 128)
     hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  else if (t.bn == 256)
+    hipLaunchKernelGGL((conv_mfma_kernel<64, 256, MODE>), grid, dim3(256), 0, ctx->stream, p);
   else
     hipLaunchKernelGGL((conv_mfma_kernel<64, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
   if (p.ksplit > 1) {
@@ -497,19 +494,59 @@ int launch_conv(deepim_ctx* ctx, ConvParams p, int classes) {
   return 0;
 }
 
+// First call of a geometry (outside graph capture): time a few split-K factors around the heuristic with
+// HIP events and remember the fastest. The kernel is idempotent, so the trial launches only rewrite `out`.
+template <int MODE>
+int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
+  TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes);
+  const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
+                           ctx->conv_split_below, ctx->conv_split_target};
+  if (ctx->conv_autotune && ctx->conv_max_split != 1) {
+    bool found = false;
+    for (auto& e : ctx->conv_plans)
+      if (memcmp(&e.key, &key, sizeof(key)) == 0) { t.ksplit = e.ksplit; found = true; break; }
+    if (!found && !ctx->capturing) {
+      const int tiles = di_div_up(p.Cout, t.bm) * di_div_up(p.npix, t.bn) * classes;
+      int cands[12], nc = 0;
+      const int base[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24};
+      for (int c : base)
+        if ((c == 1 || (long)tiles * c <= 4096) && c <= max(1, p.nchunk / 4)) cands[nc++] = c;
+      hipEvent_t e0, e1;
+      DI_CHECK(hipEventCreate(&e0));
+      DI_CHECK(hipEventCreate(&e1));
+      float best = 1e30f;
+      int best_ks = t.ksplit;
+      for (int ci = 0; ci < nc; ++ci) {
+        TileChoice tc = t;
+        tc.ksplit = cands[ci];
+        int rc = launch_one<MODE>(ctx, p, classes, tc);  // warm (also grows the scratch once)
+        if (rc) return rc;
+        DI_CHECK(hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < 3; ++r) launch_one<MODE>(ctx, p, classes, tc);
+        DI_CHECK(hipEventRecord(e1, ctx->stream));
+        DI_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DI_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best * 0.985f) { best = ms; best_ks = cands[ci]; }  // prefer fewer splits on near-ties
+      }
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+      ctx->conv_plans.push_back({key, best_ks});
+      t.ksplit = best_ks;
+    }
+  }
+  if (ctx->conv_max_split > 0 && t.ksplit > ctx->conv_max_split) t.ksplit = ctx->conv_max_split;
+  return launch_one<MODE>(ctx, p, classes, t);
+}
+
 inline int gran_count(int Cout) { return di_div_up(Cout, 128) * 2; }  // whole 128-row tiles → BM=128 never overruns
 inline int chunk_count(int K) { return di_div_up(K, KT); }
 
-// tap tables are tiny; keep them in a per-context cache keyed by geometry
-struct TabKey { int mode, Cin, kh, kw, H, W; };
-struct TabEntry { TabKey key; int2* tab; };
-static std::vector<std::pair<deepim_ctx*, TabEntry>> g_tabs;
-
+// tap tables are tiny; they live in the context (freed by deepim_destroy), keyed by geometry
 int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, int2** out) {
-  for (auto& e : g_tabs) {
-    const TabKey& k = e.second.key;
-    if (e.first == ctx && k.mode == mode && k.Cin == Cin && k.kh == kh && k.kw == kw && k.H == H && k.W == W) {
-      *out = e.second.tab;
+  for (auto& k : ctx->conv_tabs) {
+    if (k.mode == mode && k.Cin == Cin && k.kh == kh && k.kw == kw && k.H == H && k.W == W) {
+      *out = (int2*)k.tab;
       return 0;
     }
   }
@@ -525,7 +562,7 @@ int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, in
     hipLaunchKernelGGL(build_deconv_tab_kernel, dim3(di_div_up(Kpad, 256)), dim3(256), 0, ctx->stream, tab, K, Kpad, H,
                        W);
   DI_LAUNCH_CHECK();
-  g_tabs.push_back({ctx, {{mode, Cin, kh, kw, H, W}, tab}});
+  ctx->conv_tabs.push_back({mode, Cin, kh, kw, H, W, (void*)tab});
   *out = tab;
   return 0;
 }

@@ -30,6 +30,9 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->capturing = false;
   c->conv_max_split = 0;
   c->conv_xcd_swizzle = 1;
+  c->conv_autotune = 1;
+  c->conv_split_below = 512;
+  c->conv_split_target = 768;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     deepim_set_error("hipStreamCreate", e);
@@ -55,6 +58,7 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
   for (auto g : ctx->graphs) hipGraphExecDestroy(g);
   for (auto e : ctx->timer_start) hipEventDestroy(e);
   for (auto e : ctx->timer_stop) hipEventDestroy(e);
+  for (auto& t : ctx->conv_tabs) hipFree(t.tab);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->status) hipFree(ctx->status);
   hipStreamDestroy(ctx->stream);
@@ -119,6 +123,9 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
     ctx->conv_max_split = value;
     return 0;
   }
+  if (strcmp(name, "conv_split_below") == 0) { ctx->conv_split_below = value; return 0; }
+  if (strcmp(name, "conv_split_target") == 0) { ctx->conv_split_target = value > 0 ? value : 1; return 0; }
+  if (strcmp(name, "conv_autotune") == 0) { ctx->conv_autotune = value ? 1 : 0; return 0; }
   if (strcmp(name, "conv_xcd_swizzle") == 0) {
     ctx->conv_xcd_swizzle = value ? 1 : 0;
     return 0;

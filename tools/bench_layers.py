@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--heads", action="store_true")
     ap.add_argument("--swizzle", type=int, default=1)
+    ap.add_argument("--below", type=int, default=512)
+    ap.add_argument("--target", type=int, default=768)
     a = ap.parse_args()
     ctx = Context.get(0)
     cfg = default_config()
@@ -29,6 +31,8 @@ def main():
     net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
     from mx_deepim_amd.runtime import lib
     lib.deepim_set_option(ctx.handle, b"conv_xcd_swizzle", a.swizzle)
+    lib.deepim_set_option(ctx.handle, b"conv_split_below", a.below)
+    lib.deepim_set_option(ctx.handle, b"conv_split_target", a.target)
     rng = np.random.default_rng(0)
     net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
     net.encoder()
