@@ -82,7 +82,7 @@ struct ConvParams {
 };
 
 template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NG = BM / GRAN;            // weight granules per block
