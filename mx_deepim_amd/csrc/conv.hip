@@ -587,7 +587,6 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
                                      const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                      int stride, int pad, float slope, int out_ctotal, int out_coff) {
   if (B == 0) return 0;
-  DI_REQUIRE(kh <= 8 && kw <= 8, "conv2d: kernel larger than 8 not supported");
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
   ConvParams p;
   p.in = in; p.wp = packed_w; p.bias = bias; p.out = out;
