@@ -173,6 +173,18 @@ int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const fl
                           const float* bias, int B, int Cin, int H, int W, int Cout,
                           int kh, int kw, int stride, int pad, float slope,
                           int out_ctotal, int out_coff);
+/* fp16 conv path (BASELINE config 5): NHWC fp16 activations, fp16 weights (packed once), fp16 matrix cores
+ * with fp32 accumulation, bias + LeakyReLU in fp32, NHWC fp16 output. Same layer semantics as
+ * deepim_conv2d_forward (deepIM_flownet.py:63-107); tolerance documented in DESIGN.md (fp16 cannot meet 1e-4).
+ * Cin_pad = Cin rounded up to a multiple of 8 (zero channels); Cout % 4 == 0. */
+int deepim_nchw_f32_to_nhwc_f16(deepim_ctx* ctx, void* out_f16, const float* in, int B, int C, int H, int W, int Cpad);
+int deepim_nhwc_f16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_f16, int B, int C, int H, int W);
+size_t deepim_conv_f16_packed_size(int Cout, int Cin_pad, int kh, int kw);
+int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*Cout,Cin,kh,kw dev f32*/,
+                                 int Cout, int Cin, int Cin_pad, int kh, int kw);
+int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* in_nhwc_f16, const void* packed_w,
+                              const float* bias, int B, int Cin_pad, int H, int W, int Cout, int kh, int kw,
+                              int stride, int pad, float slope);
 /* MXNet Deconvolution k4 s2 p0 (+bias) + Crop(offset 1,1 → Ho,Wo) [+LeakyReLU]
  * (deepIM_flownet.py:127-143,149-165). w layout (Cin,Cout,4,4). */
 size_t deepim_deconv_packed_size(int Cin, int Cout);

@@ -40,6 +40,7 @@ def default_config():
         ROT_TYPE="QUAT",
         ROT_COORD="CAMERA",
         REGRESSOR_NUM=1,
+        FP16_CONV=False,   # BASELINE config 5: fp16 conv path (not a reference key; the reference is fp32 only)
     )
     cfg.train_iter = AttrDict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L1", LW_PM=0.1, LW_FLOW=0.25, LW_MASK=0.03,
                               NUM_3D_SAMPLE=3000, SE3_PM_SL1_SCALAR=1.0)

@@ -73,6 +73,8 @@ class deepIM_flownet(object):
         self.with_flow_head = bool(n.PRED_FLOW) and not cfg.TEST.FAST_TEST
         self.with_decoder = self.with_mask_head or self.with_flow_head
         self.cin = 6 + (2 if self.input_depth else 0) + (2 if self.input_mask else 0)
+        # BASELINE config 5: conv stack on the fp16 matrix cores (NHWC fp16 activations, fp32 accumulate)
+        self.fp16_conv = bool(n.get("FP16_CONV", False))
         self.H, self.W = cfg.SCALES[0]
         self.K = np.ascontiguousarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         # Prop-side channel reversal of the means (zoom_image_with_factor.py:79-81)
@@ -176,6 +178,16 @@ class deepIM_flownet(object):
                 pk = DeviceArray(ctx, (nb // 4,))
                 lib.deepim_conv_pack_weights(h, pk, self.params[name], cout, cin, kh, kw)
             self.packed[base] = pk
+        if self.fp16_conv:   # fp16 weights in MFMA octet order, one-time
+            self.packed_f16 = {}
+            cin = self.cin
+            for name, cout, k, s_, p_ in ENCODER:
+                cpad = (cin + 7) // 8 * 8
+                nb = lib.load().deepim_conv_f16_packed_size(cout, cpad, k, k)
+                pk = DeviceArray(ctx, (nb // 2,), dtype=np.float16)
+                lib.deepim_conv_f16_pack_weights(h, pk, self.params[name + "_weight"], cout, cin, cpad, k, k)
+                self.packed_f16[name] = pk
+                cin = cout
         # activations
         A = self.act
         A["net_input"] = ctx.empty((B, self.cin, H, W))
@@ -186,7 +198,12 @@ class deepIM_flownet(object):
             ho, wo = _out_hw(hh, ww, k, s, p)
             A[name] = ctx.empty((B, cout, ho, wo))
             self.enc_geom.append((name, cin, hh, ww, cout, k, s, p))
+            if self.fp16_conv:
+                A[name + "_h"] = ctx.empty((B, ho, wo, cout), dtype=np.float16)   # NHWC fp16
             hh, ww, cin = ho, wo, cout
+        if self.fp16_conv:
+            self.cin_pad = (self.cin + 7) // 8 * 8
+            A["net_input_h"] = ctx.empty((B, H, W, self.cin_pad), dtype=np.float16)
         A["fc6"], A["fc7"], A["se3"] = ctx.empty((B, 256)), ctx.empty((B, 256)), ctx.empty((B, 7))
         A["pose_est"] = ctx.empty((B, 3, 4))
         if self.with_decoder:
@@ -223,7 +240,22 @@ class deepIM_flownet(object):
             data.get("depth_rendered") if self.input_depth else None,
             data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], self.B, self.H, self.W)
 
+    def encoder_fp16(self):
+        """Same 10 layers on the fp16 matrix cores: NCHW fp32 net input → NHWC fp16 → convs → conv6_1 back to
+        NCHW fp32 for the (fp32) FC head."""
+        A, h, B = self.act, self.ctx.handle, self.B
+        lib.deepim_nchw_f32_to_nhwc_f16(h, A["net_input_h"], A["net_input"], B, self.cin, self.H, self.W, self.cin_pad)
+        src = A["net_input_h"]
+        for name, cin, hh, ww, cout, k, s, p in self.enc_geom:
+            cpad = (cin + 7) // 8 * 8
+            lib.deepim_conv2d_f16_forward(h, A[name + "_h"], src, self.packed_f16[name], self.params[name + "_bias"], B,
+                                          cpad, hh, ww, cout, k, k, s, p, ctypes.c_float(SLOPE))
+            src = A[name + "_h"]
+        lib.deepim_nhwc_f16_to_nchw_f32(h, A["conv6_1"], src, B, 1024, 8, 10)
+
     def encoder(self):
+        if self.fp16_conv:
+            return self.encoder_fp16()
         A = self.act
         src = A["net_input"]
         for name, cin, h, w, cout, k, s, p in self.enc_geom:

@@ -21,6 +21,22 @@ def encoder(params, x):
     return acts
 
 
+def q16(x):
+    """Round to fp16 (RNE) and back — what the fp16 path stores between layers."""
+    return np.asarray(x, f32).astype(np.float16).astype(f32)
+
+
+def encoder_fp16(params, x):
+    """Emulation of the fp16 conv path (BASELINE config 5): fp16-rounded activations and weights, fp32
+    accumulation, bias + LeakyReLU in fp32, fp16-rounded outputs."""
+    acts = {}
+    x = q16(x)
+    for name, s, p in ENCODER:
+        x = q16(net.conv2d(x, q16(params[name + "_weight"]), params[name + "_bias"], s, p, SLOPE))
+        acts[name] = x
+    return acts
+
+
 def pose_head(params, feat, zoom_factor):
     fc6 = net.fc(feat.reshape(feat.shape[0], -1), params["fc6_weight"], params["fc6_bias"], SLOPE)
     fc7 = net.fc(fc6, params["fc7_weight"], params["fc7_bias"], SLOPE)
@@ -64,12 +80,12 @@ def flow_head(params, concat3, zoom_factor, H, W, normalize_flow):
 
 
 def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", heads=False,
-                     normalize_flow=20.0):
+                     normalize_flow=20.0, fp16_conv=False):
     """-> dict with net_input, zoom_factor, encoder activations, se3 (B,7), pose_est (B,3,4 float64)."""
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"))
     out = {"net_input": x, "zoom_factor": zf}
-    acts = encoder(params, x)
+    acts = encoder_fp16(params, x) if fp16_conv else encoder(params, x)
     out.update(acts)
     if heads:
         dec = decoder(params, acts)

@@ -1,0 +1,89 @@
+"""fp16 conv path (BASELINE config 5) on the GPU vs the oracle's fp16 emulation (fp16-rounded operands and
+outputs, fp32 accumulation). Tolerances: one fp16 ulp (2^-11 ≈ 4.9e-4 relative) per layer output; the pose
+lands within 2e-3 of the fp32 path on the synthetic pairs — fp16 cannot meet the fp32 path's 1e-4 bar."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import net as onet
+from oracle import pipeline as opipe
+from mx_deepim_amd.config import default_config
+from mx_deepim_amd.runtime import DeviceArray, lib
+from mx_deepim_amd.symbols import deepIM_flownet
+from mx_deepim_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+cf = ctypes.c_float
+MEANS_REV = np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
+
+
+def _conv_f16(ctx, x, w, b, s, p, slope):
+    B, cin, H, W = x.shape
+    cout, _, k, _ = w.shape
+    cpad = (cin + 7) // 8 * 8
+    xh = ctx.empty((B, H, W, cpad), dtype=np.float16)
+    lib.deepim_nchw_f32_to_nhwc_f16(ctx.handle, xh, ctx.array(x), B, cin, H, W, cpad)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_f16_packed_size(cout, cpad, k, k) // 2,), dtype=np.float16)
+    lib.deepim_conv_f16_pack_weights(ctx.handle, pk, ctx.array(w), cout, cin, cpad, k, k)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    oh = ctx.empty((B, ho, wo, cout), dtype=np.float16)
+    lib.deepim_conv2d_f16_forward(ctx.handle, oh, xh, pk, ctx.array(b), B, cpad, H, W, cout, k, k, s, p, cf(slope))
+    out = ctx.empty((B, cout, ho, wo))
+    lib.deepim_nhwc_f16_to_nchw_f32(ctx.handle, out, oh, B, cout, ho, wo)
+    return out.asnumpy()
+
+
+@pytest.mark.parametrize("case", [(2, 8, 96, 128, 64, 7, 2, 3), (1, 64, 60, 80, 128, 5, 2, 2), (2, 24, 15, 20, 256, 3, 1, 1),
+                                  (2, 5, 9, 11, 68, 3, 1, 1), (1, 128, 30, 40, 512, 3, 2, 1), (3, 1024, 8, 10, 1024, 3, 1, 1)])
+def test_conv_f16_matches_emulation(ctx, case):
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = _conv_f16(ctx, x, w, b, s, p, 0.1)
+    ref = opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w), b, s, p, 0.1))
+    # same operands, fp32 accumulation in a different order, then one fp16 rounding: ≤ 1 fp16 ulp apart
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
+    assert np.mean(got != ref) < 0.02
+
+
+def test_layout_round_trip(ctx):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 5, 7, 9)).astype(np.float32)
+    xh = ctx.empty((2, 7, 9, 8), dtype=np.float16)
+    lib.deepim_nchw_f32_to_nhwc_f16(ctx.handle, xh, ctx.array(x), 2, 5, 7, 9, 8)
+    h = xh.asnumpy()
+    np.testing.assert_array_equal(h[..., :5], x.astype(np.float16).transpose(0, 2, 3, 1))
+    assert not h[..., 5:].any()
+    xh5 = ctx.array(np.ascontiguousarray(h[..., :5]), dtype=np.float16)
+    back = ctx.empty((2, 5, 7, 9))
+    lib.deepim_nhwc_f16_to_nchw_f32(ctx.handle, back, xh5, 2, 5, 7, 9)
+    np.testing.assert_array_equal(back.asnumpy(), x.astype(np.float16).astype(np.float32))
+
+
+def test_fp16_iteration_vs_emulation_and_fp32(ctx, small_batch):
+    d = small_batch
+    B = d["image_observed"].shape[0]
+    cfg = default_config()
+    cfg.network.FP16_CONV = True
+    net = deepIM_flownet().get_symbol(cfg)
+    params = net.init_weights(cfg, seed=7)
+    net.bind(ctx, B, params)
+    data = {k: ctx.array(d[k]) for k in ("image_observed", "mask_observed")}
+    data.update({k: ctx.array(d[k][0]) for k in ("image_rendered", "mask_rendered", "src_pose")})
+    pose = net.refine_iteration(data).asnumpy()
+    npd = {"image_observed": d["image_observed"], "image_rendered": d["image_rendered"][0], "mask_observed": d["mask_observed"],
+           "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0]}
+    args = (params, npd, d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds, cfg.network.ROT_COORD)
+    emu = opipe.refine_iteration(*args, fp16_conv=True)
+    c = net.act["conv6_1"].asnumpy()
+    assert np.abs(c - emu["conv6_1"]).max() <= 5e-3 * np.abs(emu["conv6_1"]).max()
+    assert np.abs(net.act["se3"].asnumpy() - emu["se3"]).max() / np.abs(emu["se3"]).max() < 5e-3
+    assert np.abs(pose - emu["pose_est"]).max() / np.abs(emu["pose_est"]).max() < 2e-3
+    ref32 = opipe.refine_iteration(*args)   # how far fp16 is from the fp32 reference path (documented, not 1e-4)
+    dev = np.abs(pose - ref32["pose_est"]).max() / np.abs(ref32["pose_est"]).max()
+    assert dev < 2e-2, dev
+    print("fp16 vs fp32 pose deviation: %.3g" % dev)
