@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
     ap.add_argument("--iters", type=int, default=4, help="refinement iterations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp16", action="store_true", help="BASELINE config 5 mode: conv stack on the fp16 matrix cores "
+                    "(NOT the headline: reduced precision; reported with dtype f16)")
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
     args = ap.parse_args()
 
@@ -93,6 +95,7 @@ def main():
     h = ctx.handle
     B, NIT = args.batch, args.iters
     cfg = default_config()
+    cfg.network.FP16_CONV = bool(args.fp16)
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=2333)
     net.bind(ctx, B, params)
@@ -178,10 +181,11 @@ def main():
         zoom_ms = float(np.mean([t.elapsed_ms() for row in zoom_timers for t in row]))
         flops = encoder_flops_per_pair(net.cin) * B
         achieved = flops / (enc_ms * 1e-3) / 1e12
+        peak = 2500.0 if args.fp16 else FP32_PEAK_TFLOPS   # dense fp16 MFMA peak, MI355X_MICROARCH.md
         zoom_bytes = 2 * (net.cin * 480 * 640 * 4) * B   # read + write every zoomed channel once
         traffic, traffic_src = None, None                # HBM bytes per conv launch group from a recorded PMC pass
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and B == 16:
+        if os.path.exists(tpath) and B == 16 and not args.fp16:
             tj = json.load(open(tpath))
             traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         out = {
@@ -191,14 +195,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, batch %d per GPU, %d refinement iters, 480x640, "
                                    "FAST_TEST graph (8-ch input), pre-staged rendered frames (render excluded)" % (B, NIT),
                        "pairs_per_gpu": B, "iters": NIT, "parallelism": "pairs sharded across %d GPU(s), RCCL all-gather "
                                                                         "of refined poses per iteration" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (10 encoder launches per iteration)",
-                         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_mfma_kernel") +
+                         " (10 encoder launches per iteration)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch_group": flops, "ms_per_launch_group": enc_ms},
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--heads", action="store_true")
     ap.add_argument("--swizzle", type=int, default=1)
+    ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--below", type=int, default=512)
     ap.add_argument("--target", type=int, default=768)
     a = ap.parse_args()
@@ -27,6 +28,7 @@ def main():
     cfg = default_config()
     if a.heads:
         cfg.TEST.FAST_TEST = False
+    cfg.network.FP16_CONV = a.fp16
     net = deepIM_flownet().get_symbol(cfg)
     net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
     from mx_deepim_amd.runtime import lib
@@ -39,12 +41,22 @@ def main():
     ctx.sync()
     src = net.act["net_input"]
     tot_ms, tot_fl = 0.0, 0.0
+    import ctypes
+    if a.fp16:
+        src = net.act["net_input_h"]
     for name, cin, h, w, cout, k, s, p in net.enc_geom:
         t = ctx.timer()
-        net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        if a.fp16:
+            cpad = (cin + 7) // 8 * 8
+            run = lambda: lib.deepim_conv2d_f16_forward(ctx.handle, net.act[name + "_h"], src, net.packed_f16[name],
+                                                        net.params[name + "_bias"], net.B, cpad, h, w, cout, k, k, s, p,
+                                                        ctypes.c_float(0.1))
+        else:
+            run = lambda: net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        run()
         t.start()
         for _ in range(a.reps):
-            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+            run()
         t.stop()
         ms = t.elapsed_ms() / a.reps
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -53,7 +65,7 @@ def main():
         tot_fl += fl
         print(json.dumps({"layer": name, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                           "M": cout, "N": net.B * ho * wo, "K": cin * k * k}))
-        src = net.act[name]
+        src = net.act[name + "_h"] if a.fp16 else net.act[name]
     print(json.dumps({"layer": "ENCODER", "ms": round(tot_ms, 4), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)}))
     if a.heads:
         t = ctx.timer()
