@@ -41,6 +41,8 @@ struct ConvF16Params {
   int gx, gy;
   int pad_bytes;
   unsigned in_bytes;
+  int ksplit, chunks_per_split;  // split-K across grid slices for under-filled grids
+  float* partial;                // [ksplit][npix][Cout] fp32 partial sums when ksplit > 1
 };
 
 __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
@@ -52,12 +54,13 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
   // XCD-aware tile order (see csrc/conv.hip)
   int vid;
   {
-    const int total = p.gx * p.gy, bid = blockIdx.x;
+    const int total = p.gx * p.gy * p.ksplit, bid = blockIdx.x;
     const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
     vid = xcd * qn + min(xcd, rn) + (bid >> 3);
   }
-  const int bx = vid % p.gx, mb = vid / p.gx;
+  const int bx = vid % p.gx, mb = (vid / p.gx) % p.gy, split = vid / (p.gx * p.gy);
   const long n0 = (long)bx * HBN;
+  const int kc_begin = split * p.chunks_per_split, kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
 
   // per-thread gather state: one pixel, 4 octet rows per chunk
   const int gp = tid & (HBN - 1);
@@ -117,14 +120,14 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  LOAD_CHUNK(0);
+  LOAD_CHUNK(kc_begin);
   STORE_CHUNK(0);
   __syncthreads();
 
   const int lrow = lane >> 5, lcol = lane & 31;
-  for (int kc = 0; kc < p.nchunk; ++kc) {
-    const int buf = kc & 1;
-    const bool more = kc + 1 < p.nchunk;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const int buf = (kc - kc_begin) & 1;
+    const bool more = kc + 1 < kc_end;
     if (more) LOAD_CHUNK(kc + 1);
     const h8* as = &As[buf][lrow * HBM + wm0 + lcol];
     const h8* bs = &Bs[buf][lrow * HBN + wn0 + lcol];
@@ -152,12 +155,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
     const long op = n0 + wn0 + j * 32 + lcol;
     if (op >= p.npix) continue;
     _Float16* orow = p.out + op * p.Cout;
+    float* prow = p.partial ? p.partial + ((long)split * p.npix + op) * p.Cout : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int co0 = mb * HBM + wm0 + i * 32 + 8 * g + 4 * lrow;
-        if (co0 < p.Cout) {
+        if (co0 < p.Cout && prow) {  // split-K: raw fp32 partial sums, reduced by splitk_f16_reduce_kernel
+          *reinterpret_cast<float4*>(prow + co0) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        } else if (co0 < p.Cout) {
           h4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -169,6 +176,19 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
         }
       }
   }
+}
+
+// split-K second pass: out[pix][c] = f16(lrelu(Σ_s partial[s][pix][c] + bias[c])), fixed order
+__global__ __launch_bounds__(256) void splitk_f16_reduce_kernel(_Float16* __restrict__ out, const float* __restrict__ partial,
+                                                                const float* __restrict__ bias, long total, int S,
+                                                                int Cout, float slope) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = partial[i];
+  for (int s = 1; s < S; ++s) v += partial[(long)s * total + i];
+  v = v + (bias ? bias[i % Cout] : 0.f);
+  v = v > 0.f ? v : v * slope;
+  out[i] = (_Float16)v;
 }
 
 // packed[mt][kc][o][m][h] = f16(w[mt*128+m][ci0+h][ky][kx]); k-octet q = kc*8+o → tap = q / (Cin_pad/8)
@@ -296,7 +316,25 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   }
   p.tab = tab;
   p.gx = di_div_up(p.npix, HBN); p.gy = di_div_up(Cout, HBM);
-  hipLaunchKernelGGL(conv_f16_kernel, dim3(p.gx * p.gy), dim3(256), 0, ctx->stream, p);
+  const int blocks = p.gx * p.gy;
+  int ks = 1;
+  if (blocks < 384 && ctx->conv_max_split != 1) ks = min(min(di_div_up(512, blocks), max(1, p.nchunk / 4)), 16);
+  if (ctx->conv_max_split > 1) ks = min(ks, ctx->conv_max_split);
+  p.chunks_per_split = di_div_up(p.nchunk, ks);
+  p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
+  p.partial = nullptr;
+  if (p.ksplit > 1) {
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)p.ksplit * p.npix * Cout * sizeof(float), &scratch);
+    if (rc) return rc;
+    p.partial = (float*)scratch;
+  }
+  hipLaunchKernelGGL(conv_f16_kernel, dim3(blocks * p.ksplit), dim3(256), 0, ctx->stream, p);
+  if (p.ksplit > 1) {
+    const long total = p.npix * Cout;
+    hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out,
+                       p.partial, bias, total, p.ksplit, Cout, slope);
+  }
   DI_LAUNCH_CHECK();
   return 0;
 }
