@@ -1,0 +1,82 @@
+"""Between-iteration batch update on the device — mirror of the pose/flow half of
+lib/pair_matching/batch_updater_py_multi.py (`batchUpdaterPyMulti.forward` :91-328): apply the predicted
+delta (RT_transform :179), re-render, recompute the ground-truth delta labels (calc_RT_delta :239), the
+K·T matrices (:255-259), the ground-truth flow via lib/flow_c (:276-290) and the rendered mask
+(`depth > 0.2`, :261-265), and rewrite the batch.
+
+Everything except the re-render runs as HIP kernels on resident tensors (the reference does it per sample in
+numpy with host round trips). The OpenGL renderer is outside the hot path: pass a
+`render_machine` whose `render_batch(class_index, poses) -> (image_rendered, depth_rendered)` returns device
+arrays already laid out like the network inputs (RGB order, mean-subtracted, NCHW), or pre-stage the frames
+in the batch under "next_image_rendered" / "next_depth_rendered".
+"""
+import ctypes
+
+import numpy as np
+
+from ...config import ROT_COORD_CODE
+from ...runtime import lib
+
+
+class batchUpdaterPyMulti(object):
+    def __init__(self, big_cfg, height, width, render_machine=None):
+        self.big_cfg = big_cfg
+        self.rot_coord = big_cfg.network.ROT_COORD
+        self.K = np.ascontiguousarray(big_cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
+        self.T_means = np.ascontiguousarray(big_cfg.dataset.trans_means, dtype=np.float32)
+        self.T_stds = np.ascontiguousarray(big_cfg.dataset.trans_stds, dtype=np.float32)
+        self.height = height
+        self.width = width
+        self.render_machine = render_machine
+        self.Kinv = np.ascontiguousarray(np.linalg.inv(self.K))   # float32, as np.linalg.inv(np.matrix(K)) gives
+        self._rc = ROT_COORD_CODE[self.rot_coord.lower()]
+
+    def forward(self, data_batch, preds, big_cfg=None):
+        """data_batch: dict name -> DeviceArray with src_pose, tgt_pose (B,3,4) [, depth_gt_observed (B,1,H,W),
+        class_index]; preds: dict with rot_est (B,4), trans_est (B,3) (or se3 (B,7)). Returns the updated batch."""
+        cfg = big_cfg or self.big_cfg
+        src_pose, tgt_pose = data_batch["src_pose"], data_batch["tgt_pose"]
+        ctx, h = src_pose.context, src_pose.context.handle
+        B, H, W = src_pose.shape[0], self.height, self.width
+        if "se3" in preds:
+            se3 = preds["se3"]
+        else:
+            se3 = ctx.empty((B, 7))
+            lib.deepim_copy_channels(h, se3, 7, 0, preds["rot_est"], 4, B, 1)
+            lib.deepim_copy_channels(h, se3, 7, 4, preds["trans_est"], 3, B, 1)
+        # 1. refined pose
+        refined_pose = ctx.empty((B, 3, 4))
+        lib.deepim_rt_transform(h, refined_pose, None, src_pose, se3, self.T_means, self.T_stds, self._rc, B)
+        # 2. re-render at the refined pose (outside the path)
+        if self.render_machine is not None:
+            image_rendered, depth_rendered = self.render_machine.render_batch(data_batch.get("class_index"), refined_pose)
+        else:
+            image_rendered, depth_rendered = data_batch["next_image_rendered"], data_batch["next_depth_rendered"]
+        # 3. residual delta = new labels
+        rot, trans = ctx.empty((B, 4)), ctx.empty((B, 3))
+        lib.deepim_calc_rt_delta(h, rot, trans, refined_pose, tgt_pose, self.T_means, self.T_stds, self._rc, B)
+        update_package = {"image_rendered": image_rendered, "depth_rendered": depth_rendered, "src_pose": refined_pose,
+                          "rot": rot, "trans": trans}
+        # 4./5. K·T and ground-truth flow rendered → observed
+        if cfg.network.PRED_FLOW:
+            KT = ctx.empty((B, 3, 4))
+            lib.deepim_calc_KT(h, KT, refined_pose, tgt_pose, self.K, B)
+            flow, valid = ctx.empty((B, 2, H, W)), ctx.empty((B, 1, H, W))
+            lib.deepim_flow_forward(h, flow, valid, depth_rendered, data_batch["depth_gt_observed"], KT, self.Kinv, B, H, W)
+            flow_weights = ctx.empty((B, 2, H, W))          # np.tile(valid, [1, 2, 1, 1])
+            lib.deepim_copy_channels(h, flow_weights, 2, 0, valid, 1, B, H * W)
+            lib.deepim_copy_channels(h, flow_weights, 2, 1, valid, 1, B, H * W)
+            update_package["flow"] = flow
+            update_package["flow_weights"] = flow_weights
+        # 6. rendered mask
+        if cfg.network.INPUT_MASK:
+            mask = ctx.empty((B, 1, H, W))
+            lib.deepim_depth_to_mask(h, mask, depth_rendered, ctypes.c_float(0.2), B * H * W)
+            update_package["mask_rendered"] = mask
+        return self.update_data_batch(data_batch, update_package)
+
+    def update_data_batch(self, data_batch, update_package):
+        new_batch = dict(data_batch)
+        for name, value in update_package.items():
+            new_batch[name] = value
+        return new_batch

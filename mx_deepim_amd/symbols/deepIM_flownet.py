@@ -319,6 +319,21 @@ class deepIM_flownet(object):
             out["flow_est_crop"] = self.act["flow_est"]
         return out
 
+    def capture_iteration(self, data, pose_out=None):
+        """Record one refinement iteration (all its launches) into a hipGraph and return the graph id. The
+        buffers of `data` / `pose_out` are baked in: refresh their CONTENTS between replays, not the objects.
+        Run `refine_iteration` once eagerly first (tap tables, split-K autotuning, scratch growth)."""
+        gid = ctypes.c_int(-1)
+        lib.deepim_graph_begin(self.ctx.handle)
+        try:
+            self.refine_iteration(data, pose_out)
+        finally:
+            lib.deepim_graph_end(self.ctx.handle, ctypes.byref(gid))
+        return gid.value
+
+    def replay(self, graph_id):
+        lib.deepim_graph_launch(self.ctx.handle, graph_id)
+
     def refine_iteration(self, data, pose_out=None):
         """One pose-refinement iteration for the bound batch: zoom → network → inverse ZoomTrans →
         RT_transform.  `data["src_pose"]` is the current estimate; returns the refined (B,3,4) poses."""

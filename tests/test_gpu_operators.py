@@ -97,3 +97,37 @@ def test_lib_flow_c_and_pair_matching_entries(ctx, small_batch):
     assert np.mean(vis != rvis) < 1e-4
     same = vis == rvis
     np.testing.assert_allclose(fl[same], rfl[same], rtol=1e-4, atol=1e-4)
+
+
+def test_batch_updater_device(ctx, small_batch):
+    """Pose/flow half of batchUpdaterPyMulti.forward on the device vs the oracle composition."""
+    from mx_deepim_amd.config import default_config
+    from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    d = small_batch
+    B = d["image_observed"].shape[0]
+    cfg = default_config()
+    rng = np.random.default_rng(3)
+    rot_est = (rng.standard_normal((B, 4)) * 0.05 + [1, 0, 0, 0]).astype(np.float32)
+    trans_est = (rng.standard_normal((B, 3)) * 0.02).astype(np.float32)
+    upd = batchUpdaterPyMulti(cfg, 480, 640)
+    batch = {"src_pose": ctx.array(d["src_pose"][0]), "tgt_pose": ctx.array(d["pose_tgt"]),
+             "depth_gt_observed": ctx.array(d["depth_gt_observed"]),
+             "next_image_rendered": ctx.array(d["image_rendered"][1]), "next_depth_rendered": ctx.array(d["depth_rendered"][1])}
+    new = upd.forward(batch, {"rot_est": ctx.array(rot_est), "trans_est": ctx.array(trans_est)})
+    mu, sd = cfg.dataset.trans_means, cfg.dataset.trans_stds
+    ref_pose = np.stack([ose3.RT_transform(d["src_pose"][0][b], rot_est[b], trans_est[b], mu, sd, "CAMERA") for b in range(B)])
+    np.testing.assert_allclose(new["src_pose"].asnumpy(), ref_pose, rtol=1e-6, atol=1e-7)
+    pose32 = new["src_pose"].asnumpy()
+    for b in range(B):
+        q, t = ose3.calc_RT_delta(pose32[b], d["pose_tgt"][b], mu, sd, "CAMERA", "QUAT")
+        np.testing.assert_allclose(new["rot"].asnumpy()[b], q, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(new["trans"].asnumpy()[b], t, rtol=1e-5, atol=1e-6)
+    KT = oflow.calc_KT(pose32, d["pose_tgt"], d["K"])
+    rf, rv = oflow.gpu_flow(d["depth_rendered"][1], d["depth_gt_observed"], KT, np.linalg.inv(d["K"]).astype(np.float32))
+    gv = new["flow_weights"].asnumpy()
+    assert np.mean(gv[:, :1] != rv) < 1e-4      # K·T may differ in the last ulp → a threshold tie can flip
+    np.testing.assert_array_equal(gv[:, 0], gv[:, 1])
+    same = np.broadcast_to(gv[:, :1] == rv, rf.shape)
+    np.testing.assert_allclose(new["flow"].asnumpy()[same], rf[same], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(new["mask_rendered"].asnumpy(), (d["depth_rendered"][1] > 0.2).astype(np.float32))
+    assert new["image_rendered"] is batch["next_image_rendered"]

@@ -104,3 +104,27 @@ def test_four_iteration_loop_runs_and_is_deterministic(ctx, small_batch):
     a, b = run(), run()
     np.testing.assert_array_equal(a, b)
     assert np.all(np.isfinite(a))
+
+
+def test_hipgraph_replay_matches_eager(ctx, small_batch):
+    """One refinement iteration captured into a hipGraph and replayed on refreshed inputs == eager launches."""
+    d = small_batch
+    B = d["image_observed"].shape[0]
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    net.bind(ctx, B, net.init_weights(cfg, seed=7))
+    data = _data(ctx, d, 0)
+    pose_out = ctx.empty((B, 3, 4))
+    eager0 = net.refine_iteration(data, pose_out).asnumpy()          # eager first: first-call work happens here
+    gid = net.capture_iteration(data, pose_out)
+    net.replay(gid)
+    np.testing.assert_array_equal(pose_out.asnumpy(), eager0)
+    # refresh the CONTENTS of the captured buffers with frame 1 and replay
+    data["image_rendered"].copyfrom(d["image_rendered"][1])
+    data["mask_rendered"].copyfrom(d["mask_rendered"][1])
+    data["src_pose"].copyfrom(d["src_pose"][1])
+    net.replay(gid)
+    got = pose_out.asnumpy()
+    eager1 = net.refine_iteration(data).asnumpy()
+    np.testing.assert_array_equal(got, eager1)
+    assert not np.array_equal(eager0, eager1)
