@@ -51,15 +51,27 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(float* __restrict__ par
       }
     }
   }
+  // Butterfly reduce-scatter over the wavefront: 64 per-lane partial sums (4 rows x 16 batch rows) → after
+  // 6 exchange steps lane l holds the wave total of value l. 63 shuffles instead of 64 x 6.
+  float v[FC_RW * FC_BT];
 #pragma unroll
   for (int r = 0; r < FC_RW; ++r)
 #pragma unroll
-    for (int b = 0; b < FC_BT; ++b) {
-      float v = acc[r][b];
+    for (int b = 0; b < FC_BT; ++b) v[r * FC_BT + b] = acc[r][b];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0 && o0 + r < O && b < nb) partial[((long)s * B + (b0 + b)) * O + o0 + r] = v;
+  for (int off = 32, n = 32; off > 0; off >>= 1, n >>= 1) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float keep = hi ? v[i + n] : v[i];
+      const float send = hi ? v[i] : v[i + n];
+      v[i] = keep + __shfl_xor(send, off, 64);
     }
+  }
+  {
+    const int r = lane >> 4, b = lane & 15;
+    if (o0 + r < O && b < nb) partial[((long)s * B + (b0 + b)) * O + o0 + r] = v[0];
+  }
 }
 
 __global__ __launch_bounds__(256) void fc_finalize_kernel(float* __restrict__ out, const float* __restrict__ partial,
