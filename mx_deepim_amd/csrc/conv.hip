@@ -270,27 +270,20 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
           for (int jj = 0; jj < TN; ++jj) bv[(s + 1) & 1][jj] = bs[(s + 1) * 2 * BN + jj * 32];
         }
+        // one event per slot where the chunk has room (Q >= 4*EB): reads 4s, store(e) 4e+1, gather(e) 4e+2,
+        // weight slabs: store 3 / 11, load 7 / 15 — every slot stays well inside the 64-cycle MFMA shadow
+        constexpr bool ROOMY = Q >= 4 * EB;
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-          if (e * Q / EB + (MPS > 1 ? 1 : 0) == q) {
-#ifndef ABL_NOBSTORE
-            bsn[e * BN] = BSEL(e);
-#endif
-#ifndef ABL_NOGATHER
-            GATHER(e, tq)
-#endif
-          }
+          const int qs = ROOMY ? 4 * e + 1 : e * Q / EB + (MPS > 1 ? 1 : 0);
+          const int qg = ROOMY ? 4 * e + 2 : qs;
+          if (qs == q) bsn[e * BN] = BSEL(e);
+          if (qg == q) GATHER(e, tq)
         }
-#ifndef ABL_NOA
-        if (q == 2) {
-          *reinterpret_cast<float4*>(asn) = areg0;
-          ALOAD0(kg)
-        }
-        if (NG == 2 && q == 6) {
-          *reinterpret_cast<float4*>(asn + GRAN) = areg1;
-          ALOAD1(kg)
-        }
-#endif
+        if (q == (ROOMY ? 3 : 2)) *reinterpret_cast<float4*>(asn) = areg0;
+        if (q == (ROOMY ? 7 : 2)) ALOAD0(kg)
+        if (NG == 2 && q == (ROOMY ? 11 : 6)) *reinterpret_cast<float4*>(asn + GRAN) = areg1;
+        if (NG == 2 && q == (ROOMY ? 15 : 6)) ALOAD1(kg)
         if (q == Q - 1) {
 #pragma unroll
           for (int e = 0; e < EB; ++e) tq[e] = tpn[e];
