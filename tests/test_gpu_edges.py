@@ -136,5 +136,6 @@ def test_two_contexts_on_one_device_are_independent():
     x = np.arange(12, dtype=np.float32)
     da, db = a.array(x), b.array(x * 2)
     np.testing.assert_array_equal(da.asnumpy() * 2, db.asnumpy())
+    del db                              # arrays of a context must go before the context does
     lib.deepim_destroy(b.handle)
     np.testing.assert_array_equal(da.asnumpy(), x)
