@@ -51,7 +51,8 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order.
  * "conv_autotune": 1 (default) = on the first call of a conv geometry, time a few split-K factors and keep
  * the fastest; 0 = heuristic only ("conv_split_below"/"conv_split_target": split when the grid has fewer
- * than `below` blocks, aiming at `target`). Unknown names fail. */
+ * than `below` blocks, aiming at `target`). "conv_tile256": 1 = 256x128 tiles on 512-thread blocks when
+ * Cout % 256 == 0 (default 0: measured no faster than 128x128). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);

@@ -81,12 +81,13 @@ struct ConvParams {
   unsigned in_bytes;        // size of the input tensor (must stay < 2 GiB: 0x80000000 is the OOB marker)
 };
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
-  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+template <int BM, int BN, int MODE, int NT = 256>
+__global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
+  constexpr int WM = BM / (NT / 128), WN = BN / 2;  // wave tile: waves form a (NT/128) x 2 grid over the block tile
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NG = BM / GRAN;            // weight granules per block
-  constexpr int EB = KT * BN / 256;        // gathered elements per thread per chunk (consecutive k rows)
+  constexpr int NGT = NG * 256 / NT;       // ... of which each thread copies this many (one dwordx4 each)
+  constexpr int EB = KT * BN / NT;         // gathered elements per thread per chunk (consecutive k rows)
   constexpr int KS = KT / 2;               // MFMA k-steps per chunk
   constexpr int MPS = TM * TN;             // MFMAs per k-step
   constexpr int Q = KS * MPS;              // issue slots per chunk (one per MFMA)
@@ -171,13 +172,14 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
 
-  const float* wblk = p.wp + ((long)mb * NG) * p.nchunk * (KT * GRAN) + tid * 4;
+  const int gt0 = (tid >> 8) * NGT, ta = tid & 255;   // this thread's first granule and its dwordx4 slot in the slab
+  const float* wblk = p.wp + ((long)mb * NG + gt0) * p.nchunk * (KT * GRAN) + ta * 4;
   if (MODE == MODE_DECONV) wblk += (long)zz * p.ngran * p.nchunk * (KT * GRAN);
   const int kc_begin = split * p.chunks_per_split;
   const int kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
 
   // LDS slots this thread fills
-  const int a_st = ((tid * 4) / GRAN) * BM + (tid * 4) % GRAN;
+  const int a_st = ((ta * 4) / GRAN) * BM + gt0 * GRAN + (ta * 4) % GRAN;
   const int b_st = krow0 * BN + gp;
 
   float4 areg0 = make_float4(0, 0, 0, 0), areg1 = areg0;  // named scalars: an indexed array lands in scratch
@@ -217,9 +219,9 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
     for (int e = 0; e < EB; ++e) GATHER(e, tq)
     ALOAD0(kc_begin)
-    if (NG == 2) ALOAD1(kc_begin)
+    if (NGT == 2) ALOAD1(kc_begin)
     *reinterpret_cast<float4*>(&As[0][a_st]) = areg0;
-    if (NG == 2) *reinterpret_cast<float4*>(&As[0][a_st + GRAN]) = areg1;
+    if (NGT == 2) *reinterpret_cast<float4*>(&As[0][a_st + GRAN]) = areg1;
 #pragma unroll
     for (int e = 0; e < EB; ++e) Bs[0][b_st + e * BN] = BSEL(e);
     const int k1 = min(kc_begin + 1, kc_last);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
     for (int e = 0; e < EB; ++e) GATHER(e, tq)
     ALOAD0(k1)
-    if (NG == 2) ALOAD1(k1)
+    if (NGT == 2) ALOAD1(k1)
     const int2* tp2 = p.tab + min(kc_begin + 2, kc_last) * KT + krow0;
 #pragma unroll
     for (int e = 0; e < EB; ++e) tq[e] = tp2[e];
@@ -282,8 +284,8 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(ConvParams p) {
         }
         if (q == (ROOMY ? 3 : 2)) *reinterpret_cast<float4*>(asn) = areg0;
         if (q == (ROOMY ? 7 : 2)) ALOAD0(kg)
-        if (NG == 2 && q == (ROOMY ? 11 : 6)) *reinterpret_cast<float4*>(asn + GRAN) = areg1;
-        if (NG == 2 && q == (ROOMY ? 15 : 6)) ALOAD1(kg)
+        if (NGT == 2 && q == (ROOMY ? 11 : 6)) *reinterpret_cast<float4*>(asn + GRAN) = areg1;
+        if (NGT == 2 && q == (ROOMY ? 15 : 6)) ALOAD1(kg)
         if (q == Q - 1) {
 #pragma unroll
           for (int e = 0; e < EB; ++e) tq[e] = tpn[e];
@@ -448,6 +450,7 @@ TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, i
   const int below = ctx->conv_split_below, target = ctx->conv_split_target;
   int bm = 128, bn = 128;
   if (Cout <= 64) { bm = 64; bn = npix >= 256L * 1024 ? 256 : 128; }
+  else if (ctx->conv_tile256 && Cout % 256 == 0) bm = 256;   // 8-wave block: every gathered activation feeds 256 channels
   const long blocks = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
   int ks = 1;
   if (blocks < below) ks = (int)min((long)di_div_up(target, blocks), (long)max(1, nchunk / 8));
@@ -471,7 +474,9 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   p.gx = di_div_up(p.npix, t.bn); p.gy = di_div_up(p.Cout, t.bm); p.gz = classes * p.ksplit;
   DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
   dim3 grid(p.gx * p.gy * p.gz);
-  if (t.bm == 128)
+  if (t.bm == 256)
+    hipLaunchKernelGGL((conv_mfma_kernel<256, 128, MODE, 512>), grid, dim3(512), 0, ctx->stream, p);
+  else if (t.bm == 128)
     hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
   else if (t.bn == 256)
     hipLaunchKernelGGL((conv_mfma_kernel<64, 256, MODE>), grid, dim3(256), 0, ctx->stream, p);
@@ -493,7 +498,7 @@ template <int MODE>
 int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
   TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes);
   const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
-                           ctx->conv_split_below, ctx->conv_split_target};
+                           ctx->conv_split_below * 2 + ctx->conv_tile256, ctx->conv_split_target};
   if (ctx->conv_autotune && ctx->conv_max_split != 1) {
     bool found = false;
     for (auto& e : ctx->conv_plans)

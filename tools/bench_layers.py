@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--heads", action="store_true")
     ap.add_argument("--swizzle", type=int, default=1)
     ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--tile256", type=int, default=0)
     ap.add_argument("--below", type=int, default=512)
     ap.add_argument("--target", type=int, default=768)
     a = ap.parse_args()
@@ -33,6 +34,7 @@ def main():
     net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
     from mx_deepim_amd.runtime import lib
     lib.deepim_set_option(ctx.handle, b"conv_xcd_swizzle", a.swizzle)
+    lib.deepim_set_option(ctx.handle, b"conv_tile256", a.tile256)
     lib.deepim_set_option(ctx.handle, b"conv_split_below", a.below)
     lib.deepim_set_option(ctx.handle, b"conv_split_target", a.target)
     rng = np.random.default_rng(0)
