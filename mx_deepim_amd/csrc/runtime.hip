@@ -70,6 +70,8 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
 int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->scratch_bytes) {
     DI_REQUIRE(!ctx->capturing, "scratch growth during graph capture; run the sequence once eagerly first");
+    DI_REQUIRE(ctx->graphs.empty(), "scratch growth would invalidate captured graphs (they hold the old pointer); "
+                                    "run the largest workload eagerly before capturing");
     DI_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) DI_CHECK(hipFree(ctx->scratch));
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
