@@ -18,6 +18,7 @@ struct deepim_ctx {
   // small device scratch shared by the ops (bbox words, zoom factors, split-K partials)
   void* scratch;
   size_t scratch_bytes;
+  std::vector<void*> retired_scratch;  // outgrown scratch buffers still referenced by captured graphs
   int* status;  // persistent device status word (bit0: empty observed mask/image in a zoom op)
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;

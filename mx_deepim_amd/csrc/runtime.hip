@@ -60,6 +60,7 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
   for (auto e : ctx->timer_start) hipEventDestroy(e);
   for (auto e : ctx->timer_stop) hipEventDestroy(e);
   for (auto& t : ctx->conv_tabs) hipFree(t.tab);
+  for (auto p : ctx->retired_scratch) hipFree(p);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->status) hipFree(ctx->status);
   hipStreamDestroy(ctx->stream);
@@ -70,10 +71,12 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
 int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->scratch_bytes) {
     DI_REQUIRE(!ctx->capturing, "scratch growth during graph capture; run the sequence once eagerly first");
-    DI_REQUIRE(ctx->graphs.empty(), "scratch growth would invalidate captured graphs (they hold the old pointer); "
-                                    "run the largest workload eagerly before capturing");
     DI_CHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->scratch) DI_CHECK(hipFree(ctx->scratch));
+    if (ctx->scratch) {
+      // captured graphs hold the old pointer: retire it (freed at destroy) instead of freeing it under them
+      if (!ctx->graphs.empty()) ctx->retired_scratch.push_back(ctx->scratch);
+      else DI_CHECK(hipFree(ctx->scratch));
+    }
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
     DI_CHECK(hipMalloc(&ctx->scratch, want));
     ctx->scratch_bytes = want;
