@@ -223,6 +223,13 @@ int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, co
 int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot /*B,4*/, float* trans /*B,3*/, const float* pose_src,
                          const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
                          int rot_coord, int B);
+/* Pose-error metrics of lib/utils/pose_error.py (used by the evaluate_pose functions of LM6D_REFINE.py:278-512 and by
+ * tester.py:401): per pair out[b] = { re (:118-124, geodesic angle in degrees; == calc_rt_dist_m's rd_deg),
+ * te (:127-145, ||t_gt - t_est||), add (:55-69), adi (:72-88, nearest-neighbour mean, brute force instead of a
+ * KD-tree), arp_2d (:36-52, mean reprojection distance in pixels) }. points: (B,3,N) model points or, with
+ * points_shared != 0, one (3,N) set for all pairs. float64 accumulation, float32 results (B,5). */
+int deepim_pose_error(deepim_ctx* ctx, float* out /*B,5*/, const float* pose_est, const float* pose_gt,
+                      const float* points, int points_shared, const float* K_host, int B, int N);
 /* Transform3D forward/backward (deepim/operator_py/transform3d.py:34-151) */
 int deepim_transform3d_forward(deepim_ctx* ctx, float* out /*B,3,N*/, const float* points /*B,3,N*/,
                                const float* rotation /*B,4*/, const float* translation /*B,3*/,

@@ -351,6 +351,91 @@ __global__ __launch_bounds__(256) void t3d_backward_kernel(float* __restrict__ d
   dq[3] = (float)((double)Ns * zD - (double)z * share);
 }
 
+// --- pose-error metrics (lib/utils/pose_error.py) ------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// one block per pair; est/gt transformed points staged in LDS tiles for the brute-force nearest neighbour
+constexpr int PE_TILE = 1024;
+__global__ __launch_bounds__(256) void pose_error_kernel(float* __restrict__ out, const float* __restrict__ pose_est,
+                                                         const float* __restrict__ pose_gt, const float* __restrict__ pts,
+                                                         long pts_bstride, Mat3 K, int N) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* E = pose_est + b * 12;
+  const float* G = pose_gt + b * 12;
+  const float* p = pts + (long)b * pts_bstride;
+  __shared__ float est_tile[3][PE_TILE];
+  __shared__ double red[4][3];
+  double Ed[12], Gd[12];
+  for (int i = 0; i < 12; ++i) { Ed[i] = E[i]; Gd[i] = G[i]; }
+  double s_add = 0.0, s_adi = 0.0, s_arp = 0.0;
+  for (int n0 = 0; n0 < N; n0 += 256) {   // every thread owns one gt point per pass
+    const int n = n0 + tid;
+    double ge[3] = {0, 0, 0};
+    double best = 1e300;
+    if (n < N) {
+      const double x = p[n], y = p[N + n], z = p[2 * N + n];
+      double ee[3];
+      for (int i = 0; i < 3; ++i) {
+        ee[i] = Ed[i * 4] * x + Ed[i * 4 + 1] * y + Ed[i * 4 + 2] * z + Ed[i * 4 + 3];
+        ge[i] = Gd[i * 4] * x + Gd[i * 4 + 1] * y + Gd[i * 4 + 2] * z + Gd[i * 4 + 3];
+      }
+      s_add += sqrt((ee[0] - ge[0]) * (ee[0] - ge[0]) + (ee[1] - ge[1]) * (ee[1] - ge[1]) + (ee[2] - ge[2]) * (ee[2] - ge[2]));
+      double pe[3], pg[3];
+      for (int i = 0; i < 3; ++i) {
+        pe[i] = (double)K.v[i * 3] * ee[0] + (double)K.v[i * 3 + 1] * ee[1] + (double)K.v[i * 3 + 2] * ee[2];
+        pg[i] = (double)K.v[i * 3] * ge[0] + (double)K.v[i * 3 + 1] * ge[1] + (double)K.v[i * 3 + 2] * ge[2];
+      }
+      const double du = pe[0] / pe[2] - pg[0] / pg[2], dv = pe[1] / pe[2] - pg[1] / pg[2];
+      s_arp += sqrt(du * du + dv * dv);
+    }
+    // nearest est point for this gt point: sweep all est points through LDS (float32 staging, float64 distance)
+    for (int m0 = 0; m0 < N; m0 += PE_TILE) {
+      __syncthreads();
+      for (int m = tid; m < PE_TILE; m += 256) {
+        const int mm = m0 + m;
+        if (mm < N) {
+          const double x = p[mm], y = p[N + mm], z = p[2 * N + mm];
+          for (int i = 0; i < 3; ++i)
+            est_tile[i][m] = (float)(Ed[i * 4] * x + Ed[i * 4 + 1] * y + Ed[i * 4 + 2] * z + Ed[i * 4 + 3]);
+        }
+      }
+      __syncthreads();
+      if (n < N) {
+        const int cnt = min(PE_TILE, N - m0);
+        for (int m = 0; m < cnt; ++m) {
+          const double dx = (double)est_tile[0][m] - ge[0], dy = (double)est_tile[1][m] - ge[1], dz = (double)est_tile[2][m] - ge[2];
+          best = fmin(best, dx * dx + dy * dy + dz * dz);
+        }
+      }
+    }
+    if (n < N) s_adi += sqrt(best);
+  }
+  double v[3] = {wave_sum_d(s_add), wave_sum_d(s_adi), wave_sum_d(s_arp)};
+  __syncthreads();
+  if (lane == 0) for (int i = 0; i < 3; ++i) red[wave][i] = v[i];
+  __syncthreads();
+  if (tid == 0) {
+    double tot[3];
+    for (int i = 0; i < 3; ++i) tot[i] = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) / N;
+    // re: angle of R_est^T R_gt; te: ||t_gt - t_est||
+    double tr = 0.0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) tr += Ed[j * 4 + i] * Gd[j * 4 + i];
+    const double c = fmin(1.0, fmax(-1.0, (tr - 1.0) * 0.5));
+    const double dtx = Gd[3] - Ed[3], dty = Gd[7] - Ed[7], dtz = Gd[11] - Ed[11];
+    float* o = out + b * 5;
+    o[0] = (float)(acos(c) * 180.0 / 3.141592653589793);
+    o[1] = (float)sqrt(dtx * dtx + dty * dty + dtz * dtz);
+    o[2] = (float)tot[0];
+    o[3] = (float)tot[1];
+    o[4] = (float)tot[2];
+  }
+}
+
 Vec3d vec3d_from(const float* h, double dflt) {
   Vec3d v;
   for (int i = 0; i < 3; ++i) v.v[i] = h ? (double)h[i] : dflt;
@@ -382,6 +467,18 @@ extern "C" int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot, float* trans, c
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "calc_rt_delta: unknown rot_coord");
   hipLaunchKernelGGL(calc_rt_delta_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rot, trans, pose_src,
                      pose_tgt, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_pose_error(deepim_ctx* ctx, float* out, const float* pose_est, const float* pose_gt,
+                                 const float* points, int points_shared, const float* K_host, int B, int N) {
+  if (B == 0) return 0;
+  DI_REQUIRE(N > 0, "pose_error: need at least one model point");
+  Mat3 K;
+  for (int i = 0; i < 9; ++i) K.v[i] = K_host[i];
+  hipLaunchKernelGGL(pose_error_kernel, dim3(B), dim3(256), 0, ctx->stream, out, pose_est, pose_gt, points,
+                     points_shared ? 0L : (long)3 * N, K, N);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -106,3 +106,32 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def pose_error_golden():
+    """tests/golden/pose_error_golden.npz: re / te / add / adi / arp_2d of lib/utils/pose_error.py on 6 seeded
+    pose pairs with 700 model points each (run: python -c "import make_golden as m; m.pose_error_golden()")."""
+    from math import cos, sin
+    sys.path.insert(0, REF)
+    from lib.utils import pose_error as PE
+    rng = np.random.default_rng(77)
+    B, N = 6, 700
+    K = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1]])
+    pts = (rng.standard_normal((B, N, 3)) * 0.04).astype(np.float32)
+    gt = np.stack([rand_pose(rng) for _ in range(B)]).astype(np.float32)
+    est = gt.copy()
+    for b in range(B):
+        a = rng.normal(0, 0.1, 3)
+        Rz = np.array([[cos(a[2]), -sin(a[2]), 0], [sin(a[2]), cos(a[2]), 0], [0, 0, 1]])
+        Ry = np.array([[cos(a[1]), 0, sin(a[1])], [0, 1, 0], [-sin(a[1]), 0, cos(a[1])]])
+        est[b, :, :3] = (Rz @ Ry @ gt[b, :, :3].astype(np.float64)).astype(np.float32)
+        est[b, :, 3] += rng.normal(0, 0.01, 3).astype(np.float32)
+    out = np.zeros((B, 5))
+    for b in range(B):
+        Re, te, Rg, tg = (est[b, :, :3].astype(np.float64), est[b, :, 3].astype(np.float64),
+                          gt[b, :, :3].astype(np.float64), gt[b, :, 3].astype(np.float64))
+        P = pts[b].astype(np.float64)
+        out[b] = [PE.re(Re, Rg), PE.te(te, tg), PE.add(Re, te, Rg, tg, P), PE.adi(Re, te, Rg, tg, P),
+                  PE.arp_2d(Re, te, Rg, tg, P, K)]
+    np.savez_compressed(os.path.join(HERE, "pose_error_golden.npz"), pose_est=est, pose_gt=gt,
+                        points=pts.transpose(0, 2, 1).copy(), K=K.astype(np.float32), metrics=out)

@@ -152,3 +152,20 @@ def test_l2_normalize_and_rot_dist_loss(ctx):
     rl2, _, rg2 = oh.point_matching_loss(est, gt, None, 1.0, "smooth_L1", 3.0, 1.0)
     np.testing.assert_allclose(l.asnumpy(), rl2, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(d.asnumpy(), rg2, rtol=1e-6, atol=1e-7)
+
+
+def test_pose_error_metrics_match_reference(ctx):
+    """re / te / ADD / ADI / 2-D reprojection error vs the reference's own lib/utils/pose_error.py
+    (golden vectors generated from /root/reference, tests/golden/make_golden.py:pose_error_golden)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_error_golden.npz"))
+    B, _, N = g["points"].shape
+    out = ctx.empty((B, 5))
+    lib.deepim_pose_error(ctx.handle, out, ctx.array(g["pose_est"]), ctx.array(g["pose_gt"]), ctx.array(g["points"]), 0,
+                          np.ascontiguousarray(g["K"]), B, N)
+    np.testing.assert_allclose(out.asnumpy(), g["metrics"], rtol=2e-4, atol=1e-6)
+    # shared point set + identical poses → all metrics zero
+    lib.deepim_pose_error(ctx.handle, out, ctx.array(g["pose_gt"]), ctx.array(g["pose_gt"]), ctx.array(g["points"][0]), 1,
+                          np.ascontiguousarray(g["K"]), B, N)
+    z = out.asnumpy()
+    assert np.abs(z[:, 1:]).max() < 1e-6 and z[:, 0].max() < 0.05   # acos near 1: float32 rotation matrices are not exactly orthonormal
