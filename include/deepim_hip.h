@@ -275,6 +275,25 @@ int deepim_group_picker_forward(deepim_ctx* ctx, float* out /*B,C/G*/, const flo
 int deepim_group_picker_backward(deepim_ctx* ctx, float* in_grad /*B,C*/, const float* out_grad,
                                  const float* group_idx, int group_num, int B, int C);
 
+/* ------------------------------------- R-group: re-render between iterations -- */
+/* Replaces Render_Py.render (lib/render_glumpy/render_py_multi.py:101-129: OpenGL draw + glReadPixels +
+ * depth linearisation) and the tensor packing that follows it in the batch updater
+ * (lib/pair_matching/batch_updater_py_multi.py:117-133) for a whole batch of poses of ONE mesh, on the device.
+ * Camera model of :132-147 (a pixel is covered when its index lies inside the triangle projected with K),
+ * GL_LESS depth test, no culling, fragments outside (zNear, zFar) dropped; triangles with a vertex at or behind
+ * zNear are dropped whole instead of clipped.
+ *   image  (B,3,H,W) device: RGB − pixel_means (pixel_means_host in tensor channel order, NULL = 0); background = −means
+ *   depth  (B,1,H,W) device: metric z, 0 = background
+ *   vertices (V,3) device, model frame; faces (F,3) int32 device; poses (B,3,4) device [R|t]
+ *   texture != NULL: (tex_h,tex_w,3) device, values on the 0..255 scale, row 0 ↔ v = 0, sampled GL_LINEAR/clamp;
+ *                    vertex_attr = (V,2) uv.   texture == NULL: vertex_attr = (V,3) RGB on the 0..255 scale.
+ *   K_host: 9 floats, row-major intrinsics. */
+int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth, const float* vertices,
+                          const float* vertex_attr, const int32_t* faces, const float* texture,
+                          int tex_h, int tex_w, const float* poses, const float* K_host,
+                          const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
+                          float zfar);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+// GPU rasteriser for the step BETWEEN refinement iterations: replaces the OpenGL off-screen
+// render + glReadPixels of lib/render_glumpy/render_py_multi.py:101-129 so the render-and-compare loop never
+// leaves the device. Same camera model: u0 = cx + 0.5 with GL pixel centres at +0.5 (:132-147) means a camera
+// point projects to pixel-INDEX coordinates u = fx·X/Z + cx, v = fy·Y/Z + cy and a pixel is covered when its
+// index (i, j) lies inside the projected triangle; depth test GL_LESS, no face culling, no blending (:93-95);
+// depth read-back is linearised to metric z (:126-128) — here z is kept metric throughout; colour is the
+// texture (GL_LINEAR, clamp) at perspective-correct uv, or perspective-correct vertex colours.
+// OpenGL's exact rasterisation (sub-pixel snapping, 24-bit depth) cannot run here: PARITY UNPINNED, restated as
+// standard top-left-rule rasterisation; the tests check it against a CPU restatement and an analytic ray cast.
+//
+// Three kernels, all per-pair batched:
+//   project:  one thread per (pair, vertex): camera transform + projection → (u, v, Z)
+//   raster:   one thread per (pair, triangle): walks the triangle's clipped bounding box, interpolates 1/Z
+//             (affine in screen space, like GL's z) and resolves visibility with ONE 64-bit atomicMin per
+//             covered pixel on the key (float_bits(Z) << 32 | triangle id) — first triangle wins exact ties
+//   resolve:  one thread per pixel: re-derives the barycentrics of the winning triangle, shades, writes the
+//             network tensors directly: image (B,3,H,W) RGB mean-subtracted, depth (B,1,H,W), 0 = background
+#include "common.h"
+
+namespace {
+
+struct PV { float u, v, z; };
+
+__global__ __launch_bounds__(256) void project_kernel(PV* __restrict__ pv, const float* __restrict__ verts,
+                                                      const float* __restrict__ poses, Mat3 K, int V) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= V) return;
+  const float* P = poses + b * 12;
+  const float x = verts[i * 3], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
+  const float X = ((P[0] * x + P[1] * y) + P[2] * z) + P[3];
+  const float Y = ((P[4] * x + P[5] * y) + P[6] * z) + P[7];
+  const float Z = ((P[8] * x + P[9] * y) + P[10] * z) + P[11];
+  PV o;
+  o.u = K.v[0] * X / Z + K.v[2];
+  o.v = K.v[4] * Y / Z + K.v[5];
+  o.z = Z;
+  pv[(long)b * V + i] = o;
+}
+
+// edge function of pixel (px,py) against edge a→b; > 0 on the interior side for the orientation used below
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+// top-left rule (image coordinates, y down) for an edge with direction (dx,dy) of a triangle oriented so that edge_fn
+// is positive inside: the top edge runs left→right, left edges run upwards
+__device__ __forceinline__ bool top_left(float dx, float dy) { return (dy == 0.f && dx > 0.f) || dy < 0.f; }
+
+struct Tri { float ax, ay, az, bx, by, bz, cx, cy, cz; bool ok; };
+
+__device__ __forceinline__ Tri load_tri(const PV* __restrict__ pv, const int* __restrict__ faces, int f, float znear,
+                                        int& ia, int& ib, int& ic) {
+  ia = faces[f * 3]; ib = faces[f * 3 + 1]; ic = faces[f * 3 + 2];
+  PV a = pv[ia], b = pv[ib], c = pv[ic];
+  Tri t;
+  t.ok = a.z > znear && b.z > znear && c.z > znear;  // triangles crossing the near plane are dropped, not clipped
+  const float area = edge_fn(a.u, a.v, b.u, b.v, c.u, c.v);
+  if (area == 0.f || !(area == area)) t.ok = false;
+  if (area < 0.f) { PV tmp = b; b = c; c = tmp; const int ti = ib; ib = ic; ic = ti; }  // no culling: orient positively
+  t.ax = a.u; t.ay = a.v; t.az = a.z; t.bx = b.u; t.by = b.v; t.bz = b.z; t.cx = c.u; t.cy = c.v; t.cz = c.z;
+  return t;
+}
+
+// barycentric weights of pixel (x,y) (w0 ↔ a, w1 ↔ b, w2 ↔ c) and coverage under the top-left rule
+__device__ __forceinline__ bool cover(const Tri& t, float x, float y, float& w0, float& w1, float& w2) {
+  w0 = edge_fn(t.bx, t.by, t.cx, t.cy, x, y);
+  w1 = edge_fn(t.cx, t.cy, t.ax, t.ay, x, y);
+  w2 = edge_fn(t.ax, t.ay, t.bx, t.by, x, y);
+  const bool i0 = w0 > 0.f || (w0 == 0.f && top_left(t.cx - t.bx, t.cy - t.by));
+  const bool i1 = w1 > 0.f || (w1 == 0.f && top_left(t.ax - t.cx, t.ay - t.cy));
+  const bool i2 = w2 > 0.f || (w2 == 0.f && top_left(t.bx - t.ax, t.by - t.ay));
+  return i0 && i1 && i2;
+}
+
+__device__ __forceinline__ float pixel_depth(const Tri& t, float w0, float w1, float w2) {
+  const float sum = (w0 + w1) + w2;
+  const float inv = ((w0 / t.az + w1 / t.bz) + w2 / t.cz) / sum;  // 1/Z is affine in screen space
+  return 1.0f / inv;
+}
+
+__global__ __launch_bounds__(256) void raster_kernel(unsigned long long* __restrict__ zbuf, const PV* __restrict__ pv_all,
+                                                     const int* __restrict__ faces, int V, int F, int H, int W,
+                                                     float znear, float zfar) {
+  const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  int ia, ib, ic;
+  const Tri t = load_tri(pv_all + (long)b * V, faces, f, znear, ia, ib, ic);
+  if (!t.ok) return;
+  const float minx = fminf(t.ax, fminf(t.bx, t.cx)), maxx = fmaxf(t.ax, fmaxf(t.bx, t.cx));
+  const float miny = fminf(t.ay, fminf(t.by, t.cy)), maxy = fmaxf(t.ay, fmaxf(t.by, t.cy));
+  if (!(maxx >= 0.f && minx <= (float)(W - 1) && maxy >= 0.f && miny <= (float)(H - 1))) return;
+  const int x0 = max(0, (int)ceilf(minx)), x1 = min(W - 1, (int)floorf(maxx));
+  const int y0 = max(0, (int)ceilf(miny)), y1 = min(H - 1, (int)floorf(maxy));
+  unsigned long long* zb = zbuf + (long)b * H * W;
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      float w0, w1, w2;
+      if (!cover(t, (float)x, (float)y, w0, w1, w2)) continue;
+      const float z = pixel_depth(t, w0, w1, w2);
+      if (!(z > znear && z < zfar)) continue;  // GL clips fragments outside [zNear, zFar]
+      const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)f;
+      atomicMin(zb + (long)y * W + x, key);
+    }
+}
+
+__device__ __forceinline__ float tex_bilinear(const float* __restrict__ tex, int TH, int TW, int c, float u, float v) {
+  // GL_LINEAR with clamp-to-edge; texel centres at (i + 0.5) / size; v = 0 is the FIRST row of `tex`
+  const float x = u * TW - 0.5f, y = v * TH - 0.5f;
+  const float xf = floorf(x), yf = floorf(y);
+  const float fx = x - xf, fy = y - yf;
+  const int x0 = min(max((int)xf, 0), TW - 1), x1 = min(max((int)xf + 1, 0), TW - 1);
+  const int y0 = min(max((int)yf, 0), TH - 1), y1 = min(max((int)yf + 1, 0), TH - 1);
+  const float t00 = tex[(y0 * TW + x0) * 3 + c], t01 = tex[(y0 * TW + x1) * 3 + c];
+  const float t10 = tex[(y1 * TW + x0) * 3 + c], t11 = tex[(y1 * TW + x1) * 3 + c];
+  const float top = t00 + (t01 - t00) * fx, bot = t10 + (t11 - t10) * fx;
+  return top + (bot - top) * fy;
+}
+
+// attr: per-vertex attributes — 3 floats RGB (0..255) when tex == nullptr, else 2 floats uv
+__global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image, float* __restrict__ depth,
+                                                      const unsigned long long* __restrict__ zbuf,
+                                                      const PV* __restrict__ pv_all, const int* __restrict__ faces,
+                                                      const float* __restrict__ attr, const float* __restrict__ tex,
+                                                      int TH, int TW, Vec3 means, int V, int H, int W, float znear) {
+  const int b = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const long plane = (long)H * W;
+  if (p >= plane) return;
+  const unsigned long long key = zbuf[(long)b * plane + p];
+  float rgb[3] = {0.f, 0.f, 0.f};
+  float z = 0.f;
+  if (key != ~0ull) {
+    const int f = (int)(unsigned)(key & 0xffffffffu);
+    z = __uint_as_float((unsigned)(key >> 32));
+    int ia, ib, ic;
+    const Tri t = load_tri(pv_all + (long)b * V, faces, f, znear, ia, ib, ic);
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    float w0, w1, w2;
+    cover(t, (float)x, (float)y, w0, w1, w2);
+    // perspective-correct weights
+    const float q0 = w0 / t.az, q1 = w1 / t.bz, q2 = w2 / t.cz;
+    const float qs = (q0 + q1) + q2;
+    if (tex == nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        rgb[c] = ((q0 * attr[ia * 3 + c] + q1 * attr[ib * 3 + c]) + q2 * attr[ic * 3 + c]) / qs;
+    } else {
+      const float u = ((q0 * attr[ia * 2] + q1 * attr[ib * 2]) + q2 * attr[ic * 2]) / qs;
+      const float v = ((q0 * attr[ia * 2 + 1] + q1 * attr[ib * 2 + 1]) + q2 * attr[ic * 2 + 1]) / qs;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] = tex_bilinear(tex, TH, TW, c, u, v);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) image[((long)b * 3 + c) * plane + p] = rgb[c] - means.v[c];
+  depth[(long)b * plane + p] = z;
+}
+
+}  // namespace
+
+extern "C" int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth, const float* vertices,
+                                     const float* vertex_attr, const int32_t* faces, const float* texture,
+                                     int tex_h, int tex_w, const float* poses, const float* K_host,
+                                     const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
+                                     float zfar) {
+  if (B == 0) return 0;
+  DI_REQUIRE(V > 0 && F > 0 && H > 0 && W > 0, "render: empty mesh or image");
+  DI_REQUIRE(znear > 0.f && zfar > znear, "render: need 0 < zNear < zFar");
+  const size_t zbytes = (size_t)B * H * W * sizeof(unsigned long long);
+  const size_t pbytes = (size_t)B * V * sizeof(PV);
+  void* scratch;
+  int rc = deepim_scratch(ctx, zbytes + pbytes + 64, &scratch);
+  if (rc) return rc;
+  unsigned long long* zbuf = (unsigned long long*)scratch;
+  PV* pv = (PV*)((char*)scratch + zbytes);
+  Mat3 K;
+  for (int i = 0; i < 9; ++i) K.v[i] = K_host[i];
+  Vec3 means = {{0, 0, 0}};
+  if (pixel_means_host) for (int i = 0; i < 3; ++i) means.v[i] = pixel_means_host[i];
+  DI_CHECK(hipMemsetAsync(zbuf, 0xff, zbytes, ctx->stream));
+  hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V);
+  hipLaunchKernelGGL(raster_kernel, dim3(di_div_up(F, 256), B), dim3(256), 0, ctx->stream, zbuf, pv, (const int*)faces, V,
+                     F, H, W, znear, zfar);
+  hipLaunchKernelGGL(resolve_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, image, depth, zbuf,
+                     pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear);
+  DI_LAUNCH_CHECK();
+  return 0;
+}

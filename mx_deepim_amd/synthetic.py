@@ -78,6 +78,37 @@ def raycast_ellipsoid(pose, axes, K=K_LINEMOD, H=480, W=640):
     return rgb, depth
 
 
+def ellipsoid_mesh(axes, n_lat=48, n_lon=96):
+    """Triangulated ellipsoid for the rasteriser tests / bench (LINEMOD 'ape' has ~5.8k vertices, ~11.7k faces;
+    the default gives 4.7k / 9.0k). Returns dict(vertices (V,3), faces (F,3) int32, uv (V,2), colors (V,3) 0..255)."""
+    th = np.linspace(0.0, np.pi, n_lat + 1)                 # polar
+    ph = np.linspace(0.0, 2 * np.pi, n_lon + 1)             # azimuth, seam duplicated so uv stays continuous
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    unit = np.stack([np.sin(T) * np.cos(P), np.sin(T) * np.sin(P), np.cos(T)], -1).reshape(-1, 3)
+    vertices = (unit * np.asarray(axes, np.float64)).astype(np.float32)
+    uv = np.stack([P / (2 * np.pi), T / np.pi], -1).reshape(-1, 2).astype(np.float32)
+    colors = np.floor(255 * (0.5 + 0.5 * np.sin(np.stack([9 * unit[:, 0] + 2 * unit[:, 1], 7 * unit[:, 1] - 3 * unit[:, 2],
+                                                           11 * unit[:, 2] + 5 * unit[:, 0]], -1)))).astype(np.float32)
+    faces = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * (n_lon + 1) + j, i * (n_lon + 1) + j + 1
+            c, d = a + n_lon + 1, b + n_lon + 1
+            if i > 0:
+                faces.append([a, c, b])
+            if i < n_lat - 1:
+                faces.append([b, c, d])
+    return {"vertices": vertices, "faces": np.asarray(faces, np.int32), "uv": uv, "colors": colors}
+
+
+def procedural_texture(h=256, w=512, seed=7):
+    """(h,w,3) float32 texture on the 0..255 scale (integer-valued like a PNG), row 0 = v 0."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    base = np.stack([0.5 + 0.5 * np.sin(18 * x + 5 * y), 0.5 + 0.5 * np.sin(13 * y - 4 * x), 0.5 + 0.5 * np.sin(23 * x * y + 1)], -1)
+    return np.floor(np.clip(255 * base + rng.uniform(-12, 12, (h, w, 3)), 0, 255)).astype(np.float32)
+
+
 def to_tensor(rgb, means=PIXEL_MEANS):
     """HxWx3 RGB floats -> (3,H,W) tensor the way lib/utils/image.py:583-594 builds it from a BGR image:
     tensor[i] = bgr[..., 2-i] - pixel_means[2-i], i.e. RGB channel order with the config means REVERSED

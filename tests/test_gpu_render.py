@@ -1,0 +1,189 @@
+"""R-group parity on the GPU: the HIP rasteriser (C ABI `deepim_render_forward`, `Render_Py`) against
+oracle/render.py, plus an analytic ray-cast cross-check and the closed render→warp→update loop."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import render as orender
+from mx_deepim_amd.runtime import lib
+from mx_deepim_amd import synthetic
+from mx_deepim_amd.config import default_config
+from mx_deepim_amd.lib.render_glumpy.render_py_multi import Render_Py
+from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+
+pytestmark = pytest.mark.gpu
+cf = ctypes.c_float
+K = synthetic.K_LINEMOD
+AXES = [0.05, 0.04, 0.035]
+
+
+def _poses(B, seed=0):
+    rng = np.random.default_rng(seed)
+    return np.stack([synthetic.sample_pose_pair(rng)[1] for _ in range(B)]).astype(np.float32)
+
+
+def _gpu_render(ctx, mesh, poses, H, W, texture=None, means=None, Kmat=K, znear=0.25, zfar=6.0):
+    B = len(poses)
+    attr = mesh["uv"] if texture is not None else mesh["colors"]
+    img, dep = ctx.empty((B, 3, H, W)), ctx.empty((B, 1, H, W))
+    tex = None if texture is None else ctx.array(texture)
+    th, tw = (0, 0) if texture is None else texture.shape[:2]
+    lib.deepim_render_forward(ctx.handle, img, dep, ctx.array(mesh["vertices"]), ctx.array(attr),
+                              ctx.array(mesh["faces"], dtype=np.int32), tex, th, tw, ctx.array(poses),
+                              np.ascontiguousarray(Kmat, np.float32), means, len(mesh["vertices"]), len(mesh["faces"]), B, H, W,
+                              cf(znear), cf(zfar))
+    return img.asnumpy(), dep.asnumpy()
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_render_matches_oracle(ctx, textured):
+    mesh = synthetic.ellipsoid_mesh(AXES, 24, 48)
+    tex = synthetic.procedural_texture(64, 128) if textured else None
+    poses = _poses(3, seed=11)
+    means = synthetic.PIXEL_MEANS[::-1].copy()
+    img, dep = _gpu_render(ctx, mesh, poses, 480, 640, texture=tex, means=means)
+    for b in range(len(poses)):
+        ri, rd = orender.render(mesh["vertices"], mesh["uv"] if textured else mesh["colors"], mesh["faces"], poses[b], K, 480, 640,
+                                texture=tex, pixel_means=means)
+        assert np.array_equal(dep[b, 0] > 0, rd > 0)                       # coverage: index work, exact
+        np.testing.assert_array_equal(dep[b, 0], rd)                       # same fp32 expression order
+        np.testing.assert_allclose(img[b], ri, rtol=0, atol=1e-3)          # 0..255 scale
+        assert (rd > 0).sum() > 1000
+
+
+def test_render_against_analytic_raycast(ctx):
+    mesh = synthetic.ellipsoid_mesh(AXES, 96, 192)
+    poses = _poses(2, seed=5)
+    _, dep = _gpu_render(ctx, mesh, poses, 480, 640)
+    for b in range(2):
+        _, ref = synthetic.raycast_ellipsoid(poses[b], AXES)
+        both = (dep[b, 0] > 0) & (ref > 0)
+        assert ((dep[b, 0] > 0) != (ref > 0)).sum() <= 0.02 * (ref > 0).sum()   # silhouette: inscribed polyhedron
+        assert np.abs(dep[b, 0] - ref)[both].max() < 2e-3
+        assert np.median(np.abs(dep[b, 0] - ref)[both]) < 5e-5
+
+
+def test_fill_rule_covers_shared_edges_once(ctx):
+    # a fronto-parallel quad whose corners project onto integer pixels: every pixel of [x0,x1) x [y0,y1) is owned by
+    # exactly one of the two triangles (top-left rule), none on the right/bottom edge
+    Kq = np.array([[128, 0, 0], [0, 128, 0], [0, 0, 1]], np.float32)   # powers of two: the projections are exact
+    z = 2.0
+    x0, x1, y0, y1 = 4, 20, 3, 15
+    verts = np.array([[x0 * z / 128, y0 * z / 128, z], [x1 * z / 128, y0 * z / 128, z], [x1 * z / 128, y1 * z / 128, z],
+                      [x0 * z / 128, y1 * z / 128, z]], np.float32)
+    mesh = {"vertices": verts, "faces": np.array([[0, 1, 2], [0, 2, 3]], np.int32),
+            "colors": np.array([[255, 0, 0]] * 4, np.float32)}
+    pose = np.eye(4, dtype=np.float32)[None, :3]
+    img, dep = _gpu_render(ctx, mesh, pose, 24, 32, Kmat=Kq)
+    cov = dep[0, 0] > 0
+    expect = np.zeros((24, 32), bool)
+    expect[y0:y1, x0:x1] = True
+    assert np.array_equal(cov, expect)
+    ri, rd = orender.render(mesh["vertices"], mesh["colors"], mesh["faces"], pose[0], Kq, 24, 32)
+    np.testing.assert_array_equal(dep[0, 0], rd)
+    np.testing.assert_allclose(img[0], ri, atol=1e-4)
+
+
+def test_depth_test_and_ties(ctx):
+    Kq = np.array([[100, 0, 16], [0, 100, 12], [0, 0, 1]], np.float32)
+    def tri(z, c):
+        return [[-0.2 * z, -0.2 * z, z], [0.2 * z, -0.2 * z, z], [0.0, 0.2 * z, z]], [c] * 3
+    v0, c0 = tri(2.0, [10, 20, 30])       # far, drawn first
+    v1, c1 = tri(1.0, [200, 100, 50])     # near, same image footprint
+    v2, c2 = tri(1.0, [1, 2, 3])          # exact depth tie with v1, drawn later: must lose
+    mesh = {"vertices": np.array(v0 + v1 + v2, np.float32), "faces": np.arange(9, dtype=np.int32).reshape(3, 3),
+            "colors": np.array(c0 + c1 + c2, np.float32)}
+    pose = np.eye(4, dtype=np.float32)[None, :3]
+    img, dep = _gpu_render(ctx, mesh, pose, 24, 32, Kmat=Kq)
+    cov = dep[0, 0] > 0
+    assert cov.sum() > 100
+    assert np.all(dep[0, 0][cov] == 1.0)
+    np.testing.assert_allclose(img[0][:, cov], np.array([200, 100, 50], np.float32)[:, None] * np.ones(cov.sum(), np.float32), atol=1e-3)
+
+
+def test_render_edges(ctx):
+    mesh = synthetic.ellipsoid_mesh(AXES, 12, 24)
+    # behind the camera / beyond zFar / inside zNear → background only, image = −means
+    bad = np.stack([np.concatenate([np.eye(3), [[0], [0], [z]]], 1) for z in (-1.0, 7.0, 0.2)]).astype(np.float32)
+    means = np.array([1, 2, 3], np.float32)
+    img, dep = _gpu_render(ctx, mesh, bad, 60, 80, means=means)
+    assert not dep.any()
+    assert np.all(img == -means[None, :, None, None])
+    # half outside the frame: still matches the oracle
+    pose = np.concatenate([np.eye(3), [[-0.33], [0.25], [0.6]]], 1).astype(np.float32)[None]
+    img, dep = _gpu_render(ctx, mesh, pose, 480, 640)
+    ri, rd = orender.render(mesh["vertices"], mesh["colors"], mesh["faces"], pose[0], K, 480, 640)
+    assert 0 < (rd > 0).sum()
+    assert (rd[:, 0] > 0).any() or (rd[-1] > 0).any()
+    np.testing.assert_array_equal(dep[0, 0], rd)
+    # degenerate (zero-area) faces are ignored; B = 0 is a no-op
+    deg = dict(mesh, faces=np.concatenate([mesh["faces"], [[0, 0, 1], [5, 5, 5]]]).astype(np.int32))
+    _, dep2 = _gpu_render(ctx, deg, pose, 480, 640)
+    np.testing.assert_array_equal(dep2, dep)
+    lib.deepim_render_forward(ctx.handle, None, None, None, None, None, None, 0, 0, None, np.eye(3, dtype=np.float32), None,
+                              1, 1, 0, 8, 8, cf(0.25), cf(6.0))
+    with pytest.raises(RuntimeError):
+        lib.deepim_render_forward(ctx.handle, None, None, None, None, None, None, 0, 0, None, np.eye(3, dtype=np.float32),
+                                  None, 1, 1, 1, 8, 8, cf(0.0), cf(6.0))
+
+
+def test_render_py_reference_api_and_batch(ctx):
+    meshes = {"ape": dict(synthetic.ellipsoid_mesh(AXES, 24, 48), texture=synthetic.procedural_texture(64, 128)),
+              "can": synthetic.ellipsoid_mesh([0.07, 0.05, 0.05], 16, 32)}
+    meshes["ape"].pop("colors")
+    meshes["can"].pop("uv")
+    means = synthetic.PIXEL_MEANS[::-1].copy()
+    rm = Render_Py("unused", ["ape", "can"], K, 640, 480, 0.25, 6.0, meshes=meshes, ctx=ctx, pixel_means=means)
+    poses = _poses(5, seed=3)
+    # reference call: quaternion + translation → (H,W,3) BGR 0..255, (H,W) depth
+    from oracle import se3 as ose3
+    q = ose3.mat2quat(poses[0, :, :3])
+    bgr, depth = rm.render(0, q, poses[0, :, 3])
+    assert bgr.shape == (480, 640, 3) and depth.shape == (480, 640)
+    m = meshes["ape"]
+    pose_q = np.concatenate([ose3.quat2mat(q), poses[0, :, 3:4]], 1).astype(np.float32)
+    ri, rd = orender.render(m["vertices"], m["uv"], m["faces"], pose_q, K, 480, 640, texture=m["texture"])
+    np.testing.assert_array_equal(depth, rd)
+    np.testing.assert_allclose(bgr, ri[::-1].transpose(1, 2, 0), atol=1e-3)
+    bgr2, depth2 = rm.render(0, pose_q[:, :3], pose_q[:, 3], r_type="mat")
+    np.testing.assert_array_equal(depth2, depth)
+    # mixed-class batch
+    ids = np.array([0, 0, 1, 0, 1])
+    img, dep = rm.render_batch(ids, ctx.array(poses))
+    img, dep = img.asnumpy(), dep.asnumpy()
+    for b in range(5):
+        m = meshes[["ape", "can"][ids[b]]]
+        ri, rd = orender.render(m["vertices"], m.get("uv", m.get("colors")), m["faces"], poses[b], K, 480, 640,
+                                texture=m.get("texture"), pixel_means=means)
+        np.testing.assert_array_equal(dep[b, 0], rd)
+        np.testing.assert_allclose(img[b], ri, atol=1e-3)
+
+
+def test_updater_closes_the_loop_on_device(ctx, small_batch):
+    """batchUpdaterPyMulti with the HIP render machine: refined pose → re-render → labels, flow, mask without the
+    host (batch_updater_py_multi.py:91-328 of the reference)."""
+    cfg = default_config()
+    B, H, W = 2, 480, 640
+    mesh = synthetic.ellipsoid_mesh(AXES, 24, 48)
+    mesh.pop("uv")
+    means = synthetic.PIXEL_MEANS[::-1].copy()
+    rm = Render_Py("unused", ["obj"], K, W, H, meshes={"obj": mesh}, ctx=ctx, pixel_means=means)
+    upd = batchUpdaterPyMulti(cfg, H, W, render_machine=rm)
+    rng = np.random.default_rng(4)
+    se3 = np.concatenate([[[1, 0.02, -0.01, 0.03]] * B, rng.standard_normal((B, 3)) * 0.05], 1).astype(np.float32)
+    batch = {"src_pose": ctx.array(small_batch["src_pose"][0]), "tgt_pose": ctx.array(small_batch["pose_tgt"]),
+             "depth_gt_observed": ctx.array(small_batch["depth_gt_observed"]), "class_index": np.zeros(B)}
+    new = upd.forward(batch, {"se3": ctx.array(se3)})
+    refined = new["src_pose"].asnumpy()
+    dep = new["depth_rendered"].asnumpy()
+    for b in range(B):
+        ri, rd = orender.render(mesh["vertices"], mesh["colors"], mesh["faces"], refined[b], K, H, W, pixel_means=means)
+        np.testing.assert_array_equal(dep[b, 0], rd)
+        np.testing.assert_allclose(new["image_rendered"].asnumpy()[b], ri, atol=1e-3)
+    np.testing.assert_array_equal(new["mask_rendered"].asnumpy(), (dep > 0.2).astype(np.float32))
+    from oracle import flow as oflow
+    KT = oflow.calc_KT(refined, small_batch["pose_tgt"], K)
+    rf, rv = oflow.gpu_flow(dep, small_batch["depth_gt_observed"], KT, np.linalg.inv(K))
+    np.testing.assert_allclose(new["flow"].asnumpy(), rf, atol=1e-4)
+    assert (new["flow_weights"].asnumpy()[:, 0] != rv[:, 0]).mean() < 1e-4
