@@ -4,9 +4,10 @@
 Workload (BASELINE.json configs[1]): LINEMOD-'ape'-like pairs, batch 16 per GPU, 4 refinement
 iterations, 480x640, fp32.  One *step* = one pass of the hot path over one batch = the 4-iteration loop
 over the 16 pairs (64 pose-refinement iterations): zoom → FlowNetS encoder → fc6/fc7 → rot/trans +
-inverse ZoomTrans → RT_transform, the refined pose feeding the next iteration's ZoomMask.  The OpenGL
-re-render between iterations is outside the path: iterations 2-4 consume pre-staged
-synthetic rendered frames already resident in HBM.  Inputs are resident in HBM before the timed region.
+inverse ZoomTrans → RT_transform → re-render at the refined pose (HIP rasteriser standing in for the reference's
+OpenGL window) + rendered-mask / observed-mask update (deepim/core/tester.py:420-455), the new frame
+feeding the next iteration's ZoomMask.  `--prestaged` skips the re-render and feeds pre-staged frames instead.
+Inputs are resident in HBM before the timed region.
 
 N>1: one process per GPU (torch.distributed.run), per-GPU batch fixed (weak scaling), pairs are
 independent; after every refinement iteration the refined poses are all-gathered over RCCL (48 B/pair).
@@ -27,6 +28,8 @@ from mx_deepim_amd import synthetic  # noqa: E402
 from mx_deepim_amd.config import default_config  # noqa: E402
 from mx_deepim_amd.runtime import Context, lib  # noqa: E402
 from mx_deepim_amd.symbols import deepIM_flownet  # noqa: E402
+from mx_deepim_amd.lib.render_glumpy.render_py_multi import Render_Py  # noqa: E402
+from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import update_test_batch  # noqa: E402
 from mx_deepim_amd.symbols.deepIM_flownet import ENCODER  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
@@ -73,6 +76,8 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5 mode: conv stack on the fp16 matrix cores "
                     "(NOT the headline: reduced precision; reported with dtype f16)")
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
+    ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
+                    "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +103,9 @@ def main():
     cfg.network.FP16_CONV = bool(args.fp16)
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=2333)
+    # random-init translation head: damp it so 4 closed-loop iterations keep the object inside the frame
+    params["trans_weight"] = params["trans_weight"] * np.float32(0.02)
+    params["trans_bias"] = params["trans_bias"] * np.float32(0.02)
     net.bind(ctx, B, params)
     batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=NIT, with_depth=False)
     image_observed = ctx.array(batch["image_observed"])
@@ -105,6 +113,13 @@ def main():
                "mask_observed": ctx.array(batch["mask_observed_frames"][f])} for f in range(NIT)]
     pose_init = ctx.array(batch["src_pose"][0])
     pose_cur = ctx.empty((B, 3, 4))
+    # closed loop (tester.py:420-455): re-render at the refined pose on the device between iterations
+    mesh = dict(synthetic.ellipsoid_mesh([0.05, 0.04, 0.035]), texture=synthetic.procedural_texture())
+    mesh.pop("colors")
+    render_machine = Render_Py("synthetic", ["ellipsoid"], batch["K"], 640, 480, 0.25, 6.0,
+                               meshes={"ellipsoid": mesh}, ctx=ctx, pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
+    rbuf = {"image_rendered": ctx.empty((B, 3, 480, 640)), "depth_rendered": ctx.empty((B, 1, 480, 640))}
+    mask_pp = [ctx.empty((B, 1, 480, 640)) for _ in range(2)]
 
     gather_in = gather_out = None
     if world > 1:
@@ -114,12 +129,15 @@ def main():
 
     enc_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
     zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
+    render_timers = [[ctx.timer() for _ in range(NIT - 1)] for _ in range(args.steps)]
 
-    def step(timers=None, ztimers=None):
+    def step(timers=None, ztimers=None, rtimers=None):
         lib.deepim_d2d(h, pose_cur, pose_init, pose_cur.nbytes)
+        data = {"image_observed": image_observed, "src_pose": pose_cur}
+        data.update(frames[0])
         for it in range(NIT):
-            data = {"image_observed": image_observed, "src_pose": pose_cur}
-            data.update(frames[it])
+            if args.prestaged:
+                data.update(frames[it])
             if ztimers:
                 ztimers[it].start()
             net.zoom(data)
@@ -141,6 +159,13 @@ def main():
                 else:
                     lib.deepim_d2h(h, ctypes.c_void_p(gather_in.data_ptr()), pose_cur, pose_cur.nbytes)
                     dist.all_gather_into_tensor(gather_out, gather_in)
+            if it < NIT - 1 and not args.prestaged:
+                if rtimers:
+                    rtimers[it].start()
+                data = update_test_batch(cfg, data, render_machine, pose_cur,
+                                         out=dict(rbuf, mask_rendered=mask_pp[it % 2]))
+                if rtimers:
+                    rtimers[it].stop()
 
     def fence():
         ctx.sync()
@@ -158,7 +183,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(enc_timers[s], zoom_timers[s])
+        step(enc_timers[s], zoom_timers[s], render_timers[s])
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -197,7 +222,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, batch %d per GPU, %d refinement iters, 480x640, "
-                                   "FAST_TEST graph (8-ch input), pre-staged rendered frames (render excluded)" % (B, NIT),
+                                   "FAST_TEST graph (8-ch input), %s" % (B, NIT, "pre-staged rendered frames (render excluded)"
+                                   if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "iters": NIT, "parallelism": "pairs sharded across %d GPU(s), RCCL all-gather "
                                                                         "of refined poses per iteration" % world},
             "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_mfma_kernel") +
@@ -209,6 +235,8 @@ def main():
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms},
         }
+        if not args.prestaged and NIT > 1:
+            out["render_ms"] = float(np.mean([t.elapsed_ms() for row in render_timers for t in row]))
         if args.layers:
             out["layers"] = layer_timings(ctx, net)
         if world == 1 and not args.no_cpu_baseline:

@@ -80,3 +80,40 @@ class batchUpdaterPyMulti(object):
         for name, value in update_package.items():
             new_batch[name] = value
         return new_batch
+
+
+def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None, out=None):
+    """Test-loop update between refinement iterations — mirror of deepim/core/tester.py:420-455: re-render at the
+    refined pose, mask_rendered = depth > 0.2, and (TEST.UPDATE_MASK == "box_rendered") mask_observed = the mask_rendered
+    the PREVIOUS iteration saw. All on the device; `out` may carry preallocated image_rendered / depth_rendered /
+    mask_rendered arrays (the arrays of `data` itself are never overwritten, so the swap needs no copy)."""
+    ctx = refined_pose.context
+    B, H, W = refined_pose.shape[0], render_machine.height, render_machine.width
+    out = out or {}
+    image = out.get("image_rendered") or ctx.empty((B, 3, H, W))
+    depth = out.get("depth_rendered") or ctx.empty((B, 1, H, W))
+    new = dict(data)
+    if class_index is None or np.ndim(class_index) == 0:
+        render_machine.render_into(image, depth, 0 if class_index is None else int(class_index), refined_pose)
+    else:
+        ids = np.asarray(class_index).astype(np.int64).reshape(B)
+        b0 = 0
+        while b0 < B:
+            b1 = b0 + 1
+            while b1 < B and ids[b1] == ids[b0]:
+                b1 += 1
+            render_machine.render_into(image[b0:b1], depth[b0:b1], ids[b0], refined_pose[b0:b1])
+            b0 = b1
+    new["image_rendered"], new["src_pose"] = image, refined_pose
+    if cfg.network.INPUT_DEPTH:
+        new["depth_rendered"] = depth
+    if cfg.network.INPUT_MASK:
+        mask = out.get("mask_rendered") or ctx.empty((B, 1, H, W))
+        lib.deepim_depth_to_mask(ctx.handle, mask, depth, ctypes.c_float(0.2), B * H * W)
+        new["mask_rendered"] = mask
+        if cfg.network.PRED_MASK:
+            if cfg.TEST.UPDATE_MASK == "box_rendered":
+                new["mask_observed"] = data["mask_rendered"]
+            elif cfg.TEST.UPDATE_MASK != "init":
+                raise Exception("Unknown UPDATE_MASK type: {}".format(cfg.TEST.UPDATE_MASK))
+    return new
