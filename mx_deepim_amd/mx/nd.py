@@ -18,6 +18,17 @@ def zeros(shape, ctx=None, dtype=np.float32):
     return (ctx or Context.get(0)).zeros(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
 
 
+def load(fname):
+    """`mx.nd.load`: NDArray-list file -> dict (or list) of host arrays; see lib/utils/ndarray_file.py."""
+    from ..lib.utils import ndarray_file
+    return ndarray_file.load(fname)
+
+
+def save(fname, data):
+    from ..lib.utils import ndarray_file
+    ndarray_file.save(fname, data)
+
+
 def _attr_to_str(v):
     """MXNet passes every Custom attr as a string; numpy arrays print as '[a b c]' and the Props parse
     them with np.fromstring(s[1:-1], sep=' ') (zoom_mask.py:125)."""

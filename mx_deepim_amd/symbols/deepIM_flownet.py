@@ -130,7 +130,16 @@ class deepIM_flownet(object):
         (deepIM_flownet.py:795-803), bilinear upsampling kernels (:808-822)."""
         rng = np.random.default_rng(seed)
         arg_params = {} if arg_params is None else arg_params
-        for name, shape in self.arg_shape_dict().items():
+        shapes = self.arg_shape_dict()
+        w1 = arg_params.get("flow_conv1_weight")
+        if w1 is not None and w1.shape[1] < shapes["flow_conv1_weight"][1]:
+            # an RGB-pair (6-channel FlowNet) checkpoint under a graph with depth / mask inputs: the extra input
+            # channels start from zero weights (deepIM_flownet.py:759-773)
+            w1 = np.asarray(w1.asnumpy() if hasattr(w1, "asnumpy") else w1, dtype=np.float32)
+            extra = shapes["flow_conv1_weight"][1] - w1.shape[1]
+            arg_params["flow_conv1_weight"] = np.concatenate(
+                [w1, np.zeros((w1.shape[0], extra) + w1.shape[2:], np.float32)], axis=1)
+        for name, shape in shapes.items():
             if name in arg_params:
                 continue
             if name.endswith("upsampling_weight"):
