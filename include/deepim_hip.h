@@ -46,8 +46,11 @@ int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n
 int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff,
                          const float* src, int C, int B, size_t hw);
 void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
-/* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split (conv/deconv results
- * are then a single k-ordered fmaf chain, bit-identical to the oracle), n = cap.
+/* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split AND canonical order
+ * (conv/deconv results are then a single (ci,ky,kx)-ordered fmaf chain, bit-identical to the oracle), n = cap.
+ * "conv_direct": 1 (default) = 128x128-tiled convs with even Cin run on the LDS-free register-fed kernel, whose
+ * fmaf chain runs over (ci/2,ky,kx,ci%2) (differs from the canonical order in the last bits; the oracle has the
+ * matching order switch); it steps aside when conv_max_split == 1; 2 = use it even then; 0 = never.
  * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order.
  * "conv_autotune": 1 (default) = on the first call of a conv geometry, time a few split-K factors and keep
  * the fastest; 0 = heuristic only ("conv_split_below"/"conv_split_target": split when the grid has fewer

@@ -26,6 +26,7 @@ struct deepim_ctx {
   bool capturing;
   std::vector<ConvTab> conv_tabs;
   std::vector<ConvPlan> conv_plans;
+  int conv_direct;    // LDS-free register-fed kernel for 128x128-tiled convs: 0 off, 1 (default) unless conv_max_split == 1, 2 always
   int conv_tile256;   // 1: 256x128 tiles (512-thread blocks) when Cout % 256 == 0 (default 0)
   int conv_autotune;  // 1 (default): time split-K candidates on the first call of a geometry
   int conv_max_split;  // 0 auto, 1 off, n cap

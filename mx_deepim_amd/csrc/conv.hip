@@ -31,8 +31,10 @@ constexpr int KT = 16;        // K chunk
 constexpr int GRAN = 64;      // weight packing granule (rows)
 constexpr int MODE_CONV = 0;
 constexpr int MODE_DECONV = 1;  // k4 s2 p0 transposed conv, one launch z-slice per output parity
+constexpr int MODE_DIRECT_TAB = 3;  // tap-table flavour of the LDS-free kernel (conv_tabs key only; 2 is taken by conv_f16.hip)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // ds_read2st64_b32: two dwords per lane from addr + OFF*256 bytes (offsets in units of 64 dwords)
 template <int O0, int O1>
@@ -79,6 +81,9 @@ struct ConvParams {
   int gx, gy, gz;           // logical grid (pixel tiles, M tiles, classes*ksplit); launched 1-D and XCD-swizzled
   int pad_bytes;            // buffer-descriptor base shift: (pad*W + pad)*4 so tap origins are >= 0
   unsigned in_bytes;        // size of the input tensor (must stay < 2 GiB: 0x80000000 is the OOB marker)
+  const float* wd;          // direct-kernel weights [Cout/32][k-pair][2][32] (second half of the packed buffer)
+  const int2* tab2;         // direct-kernel tap table, one entry per k-pair (ci2,ky,kx): {byte offset of channel 2*ci2, bit}
+  unsigned wd_bytes;
 };
 
 template <int BM, int BN, int MODE, int NT = 256>
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
     for (int k = 0; k < 8; ++k)
       if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
   }
-  const unsigned nlo = ~(unsigned)m64, nhi = ~(unsigned)(m64 >> 32);
+  const unsigned long long ninv64 = ~m64;   // inverted validity bits; shifted by the s_load-ed tap index (no SALU in between)
   // raw buffer over the input, base shifted down by pad_bytes so border tap origins stay non-negative
   // (only offsets >= pad_bytes, i.e. addresses inside the tensor, are ever dereferenced)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -186,14 +191,12 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
   float breg[EB];
 
 // Zero padding: an out-of-range voffset makes the buffer load return 0.0 without touching memory.
-// Tap validity lives in two 32-bit words of INVERTED bits (nlo: taps 0-31, nhi: 32-63); the tap index is
-// wave-uniform, so the word select is one v_cndmask on an SGPR condition, then bfe + shift-or puts the
-// "invalid" bit into bit 31 of the voffset (>= num_records → hardware returns 0).
+// Tap validity lives in a 64-bit word of INVERTED bits; the wave-uniform tap index comes straight from the scalar
+// cache into a 64-bit VALU shift (no SALU-produced operand: see tools/mfma_issue_probe.hip), then shift-or puts
+// the "invalid" bit into bit 31 of the voffset (>= num_records → hardware returns 0).
 #define GATHER(e, tq)                                                                                  \
   {                                                                                                    \
-    const int tb = (tq)[e].y;                                                                          \
-    const unsigned word = (tb & 32) ? nhi : nlo;                                                       \
-    const unsigned inv = __builtin_amdgcn_ubfe(word, (unsigned)tb & 31u, 1u);                          \
+    const unsigned inv = (unsigned)(ninv64 >> (tq)[e].y);                                              \
     breg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((inv << 31) | (unsigned)voff), (tq)[e].x, 0)); \
   }
 #define BSEL(e) breg[e]
@@ -345,6 +348,194 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-free variant for the encoder convolutions (MODE_CONV, even Cin): every wave feeds its MFMAs straight from
+// registers loaded with coalesced buffer loads — no LDS staging, no block barrier, four fully independent waves per
+// block that only share L1/L2 lines.
+//   * K order is (ci/2, ky, kx, ci%2): the two k of one v_mfma_f32_32x32x2_f32 are the SAME tap of two adjacent input
+//     channels, so lanes 32-63 (k+1) differ from lanes 0-31 (k) by a constant plane stride folded into their voffset
+//     and share the padding-validity bit — the per-load address math is the same 3 VALU as in the LDS kernel.
+//   * A operand: weights pre-packed [Cout/32][k-pair/4][lane][4] → one b128 load per 4 k-steps, 1 KB contiguous per wave.
+//   * B operand: lane j of a half-wave reads pixel j of 32 consecutive output pixels at one tap: 128 B (stride 1) or
+//     256 B (stride 2) runs; neighbouring taps and the sibling wave re-hit the same lines in L1.
+//   * software pipeline: a ring of 4 k-steps of B operands in registers, loads issued 3 k-steps (12 MFMAs) ahead;
+//     A operands double-buffered per half chunk; at most one load per MFMA issue slot (20 loads per 32 MFMAs).
+// The accumulation order per output is the fmaf chain over that K order (results differ from the (ci,ky,kx) kernel in
+// the last bits; the oracle has the matching order switch).
+constexpr int DK = 8;  // k-pairs per chunk: the same 16-wide K chunks the split-K plumbing counts in
+#ifndef DIRECT_RING
+#define DIRECT_RING 4   // operand ring (k-steps); loads run DIRECT_RING-1 k-steps ahead of the MFMAs
+#endif
+#ifndef DIRECT_OCC
+#define DIRECT_OCC 3
+#endif
+constexpr int DR = DIRECT_RING, DPD = DR - 1;
+static_assert(DK % DR == 0 && DPD < DK, "ring must divide the chunk");
+
+// (Tried: single-wave workgroups, one 64x64 quadrant each, for 4x finer tail granularity — 60 TF, half the rate.)
+__global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  int vid;
+  {
+    const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+    vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
+  }
+  const int bx = vid % p.gx;
+  const int mb = (vid / p.gx) % p.gy;
+  const int split = vid / (p.gx * p.gy);
+  const long n0 = (long)bx * BN;
+  const int lrow = lane >> 5, lcol = lane & 31;
+  const long npix = p.npix;
+
+  int voff[TN];
+  unsigned long long ninv[TN];   // inverted tap-validity bits (bit ky*8+kx)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long pix = n0 + wn0 + j * 32 + lcol;
+    unsigned long long m64 = 0;
+    voff[j] = 0;
+    if (pix < npix) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int r = (int)(pix - (long)n * hw);
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      voff[j] = ((n * p.Cin + lrow) * p.H * p.W + hi0 * p.W + wi0) * 4 + p.pad_bytes;
+      unsigned mky = 0, mkx = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
+        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+    }
+    ninv[j] = ~m64;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
+  const int npair = p.nchunk * DK;
+  int wvo[TM];   // A operand: [32-row tile][4 k-steps][lane][4] → one b128 load per tile per 4 k-steps, 1 KB contiguous per wave
+#pragma unroll
+  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * 4 + (wm0 >> 5) + i) * (npair / 4)) * 64 + lane) * 16;
+
+  const int kc_begin = split * p.chunks_per_split;
+  const int kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float rb[DR][TN];
+  float4 aq[2][TM];   // A operands of the two 4-k-step halves of a chunk
+// The tap bit index goes from the scalar cache straight into the VALU shift: a VALU op that reads an SGPR produced by
+// an SALU op (s_and / s_bitcmp+s_cselect) inside the MFMA shadow stalls the SIMD's issue (tools/mfma_issue_probe.hip:
+// 155 → 115-120 TF), SGPRs written by s_load do not.
+#define DLOADB(slot, j, ent)                                                                            \
+  {                                                                                                     \
+    const unsigned inv = (unsigned)(ninv[j] >> (ent).y);                                                \
+    rb[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((inv << 31) | (unsigned)voff[j]), (ent).x, 0)); \
+  }
+#define DLOADA(buf, i, hc) \
+  aq[buf][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, wvo[i], (hc) * 1024, 0));
+#define ASEL(u, i) (((u) & 3) == 0 ? aq[((u) >> 2) & 1][i].x : ((u) & 3) == 1 ? aq[((u) >> 2) & 1][i].y : \
+                    ((u) & 3) == 2 ? aq[((u) >> 2) & 1][i].z : aq[((u) >> 2) & 1][i].w)
+
+  if (kc_begin < kc_end) {
+    // tap-table entries travel through the scalar cache: 8 entries (16 dwords) per chunk, fetched one chunk ahead.
+    // (inline asm: after an `asm volatile` hipcc no longer proves the table unclobbered and would fall back to
+    // vector loads + waterfall loops)
+    const int g0 = kc_begin * DK;
+    i32x16 tq, tn;
+    {
+      const int2* t0 = p.tab2 + g0;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tn) : "s"(t0));
+#pragma unroll
+      for (int u = 0; u < DPD; ++u) {
+        const int2 ent = make_int2(tn[2 * u], tn[2 * u + 1]);
+        DLOADB(u, 0, ent) DLOADB(u, 1, ent)
+      }
+      DLOADA(0, 0, g0 / 4) DLOADA(0, 1, g0 / 4)
+      const int2* t1 = p.tab2 + g0 + DPD;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tq) : "s"(t1));
+    }
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      const int g = kc * DK;
+      const int2* t2 = p.tab2 + g + DK + DPD;   // entries of the loads the NEXT chunk issues (table is padded past the end)
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(tn) : "s"(t2));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < DK; ++u) {
+        const int sl = u % DR, ld = (u + DPD) % DR;
+        const int2 ent = make_int2(tq[2 * u], tq[2 * u + 1]);
+        // the empty asm pins each MFMA inside its slot (a pure intrinsic would otherwise sink past the fences)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 0), rb[sl][0], acc[0][0], 0, 0, 0);
+        asm volatile("" : "+v"(acc[0][0]));
+        DLOADB(ld, 0, ent)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 0), rb[sl][1], acc[0][1], 0, 0, 0);
+        asm volatile("" : "+v"(acc[0][1]));
+        DLOADB(ld, 1, ent)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 1), rb[sl][0], acc[1][0], 0, 0, 0);
+        asm volatile("" : "+v"(acc[1][0]));
+        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 0, (g + u) / 4 + 1)   // next half's weights, 4 k-steps ahead
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 1), rb[sl][1], acc[1][1], 0, 0, 0);
+        asm volatile("" : "+v"(acc[1][1]));
+        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 1, (g + u) / 4 + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tn));
+      tq = tn;
+    }
+  }
+#undef DLOADA
+#undef ASEL
+#undef DLOADB
+
+  const bool partial = p.ksplit > 1;
+  float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
+  const int ctotal = partial ? p.Cout : p.out_ctotal;
+  const int coff = partial ? 0 : p.out_coff;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = n0 + wn0 + j * 32 + lcol;
+    if (op >= npix) continue;
+    const int hw = p.Ho * p.Wo;
+    const int n = (int)(op / hw);
+    const int r0 = (int)(op - (long)n * hw);
+    const long obase = ((long)n * ctotal + coff) * hw + r0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * BM + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (co < p.Cout) {
+          float v = acc[i][j][r];
+          if (!partial) {
+            v = v + (p.bias ? p.bias[co] : 0.f);
+            v = v > 0.f ? v : v * p.slope;
+          }
+          outp[obase + (long)co * hw] = v;
+        }
+      }
+    }
+  }
+}
+
 // split-K second pass: out[n][coff+c][hw] = lrelu(Σ_s partial[s][n][c][hw] + bias[c]) in fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                             const float* __restrict__ bias, long total, long stride,
@@ -394,6 +585,25 @@ __global__ void pack_deconv_kernel(float* __restrict__ packed, const float* __re
     v = w[(((long)ci * Cout + co) * 4 + (py + 2 * jy)) * 4 + (px + 2 * jx)];
   }
   packed[i] = v;
+}
+
+// direct layout: packed[mt][g/4][lane = h*32 + r][g%4] = w[mt*32 + r][2*ci2 + h][ky][kx], g = (ci2*kh + ky)*kw + kx, zero padded
+__global__ void pack_direct_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, int khw,
+                                   int npair, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i & 3), r = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1);
+  const int g = (int)((i >> 8) % (npair / 4)) * 4 + q;
+  const int mt = (int)(i / (64L * npair));
+  const int co = mt * 32 + r, ci = 2 * (g / khw) + h, t = g % khw;
+  packed[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * khw + t] : 0.f;
+}
+__global__ void build_direct_tab_kernel(int2* __restrict__ tab, int npair_real, int n, int kh, int kw, int H, int W) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  if (g >= npair_real) { tab[g] = make_int2(0, 63); return; }
+  const int kx = g % kw, ky = (g / kw) % kh, ci2 = g / (kw * kh);
+  tab[g] = make_int2((2 * ci2 * H * W + ky * W + kx) * 4, ky * 8 + kx);
 }
 
 __global__ void build_conv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int kh, int kw, int H, int W) {
@@ -474,7 +684,9 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   p.gx = di_div_up(p.npix, t.bn); p.gy = di_div_up(p.Cout, t.bm); p.gz = classes * p.ksplit;
   DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
   dim3 grid(p.gx * p.gy * p.gz);
-  if (t.bm == 256)
+  if (MODE == MODE_CONV && t.bm == 128 && t.bn == 128 && p.tab2 != nullptr)
+    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, ctx->stream, p);
+  else if (t.bm == 256)
     hipLaunchKernelGGL((conv_mfma_kernel<256, 128, MODE, 512>), grid, dim3(512), 0, ctx->stream, p);
   else if (t.bm == 128)
     hipLaunchKernelGGL((conv_mfma_kernel<128, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
@@ -498,7 +710,7 @@ template <int MODE>
 int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
   TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes);
   const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
-                           ctx->conv_split_below * 2 + ctx->conv_tile256, ctx->conv_split_target};
+                           ctx->conv_split_below * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0), ctx->conv_split_target};
   if (ctx->conv_autotune && ctx->conv_max_split != 1) {
     bool found = false;
     for (auto& e : ctx->conv_plans)
@@ -549,11 +761,14 @@ int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, in
     }
   }
   DI_REQUIRE(!ctx->capturing, "conv tap table built during graph capture; run the sequence once eagerly first");
-  const int K = mode == MODE_CONV ? Cin * kh * kw : Cin * 4;
+  const int K = mode == MODE_DECONV ? Cin * 4 : Cin * kh * kw;
   const int Kpad = chunk_count(K) * KT;
   int2* tab;
-  DI_CHECK(hipMalloc((void**)&tab, (size_t)Kpad * sizeof(int2)));
-  if (mode == MODE_CONV)
+  DI_CHECK(hipMalloc((void**)&tab, (size_t)(Kpad + 32) * sizeof(int2)));
+  if (mode == MODE_DIRECT_TAB)   // one entry per k-pair, padded past the end for the kernel's read-ahead
+    hipLaunchKernelGGL(build_direct_tab_kernel, dim3(di_div_up(Kpad / 2 + 16, 256)), dim3(256), 0, ctx->stream, tab, K / 2,
+                       Kpad / 2 + 16, kh, kw, H, W);
+  else if (mode == MODE_CONV)
     hipLaunchKernelGGL(build_conv_tab_kernel, dim3(di_div_up(Kpad, 256)), dim3(256), 0, ctx->stream, tab, K, Kpad, kh,
                        kw, H, W);
   else
@@ -567,8 +782,12 @@ int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, in
 
 }  // namespace
 
+// the packed buffer holds two layouts back to back, each gran·nchunk·1024 floats: [granule][chunk][16][64] for the
+// LDS kernel, then [32-row tile][k-pair][2][32] for the LDS-free kernel
+inline size_t packed_half(int Cout, int K) { return (size_t)gran_count(Cout) * chunk_count(K) * KT * GRAN; }
+
 extern "C" size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw) {
-  return (size_t)gran_count(Cout) * chunk_count(Cin * kh * kw) * KT * GRAN * sizeof(float);
+  return 2 * packed_half(Cout, Cin * kh * kw) * sizeof(float);
 }
 
 extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh,
@@ -577,6 +796,8 @@ extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const 
   const long total = (long)gran_count(Cout) * nchunk * KT * GRAN;
   hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
                      nchunk, total);
+  hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
+                     Cin, kh * kw, nchunk * (KT / 2), total);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -606,6 +827,20 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
   int rc = get_tab(ctx, MODE_CONV, Cin, kh, kw, H, W, &tab);
   if (rc) return rc;
   p.tab = tab;
+  p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
+  // LDS-free kernel: 128x128-tiled layers with even Cin. conv_max_split = 1 asks for the canonical single
+  // (ci,ky,kx)-ordered chain per output, which only the LDS kernel provides; conv_direct = 2 forces the LDS-free kernel
+  // regardless (its chain runs over (ci/2,ky,kx,ci%2)).
+  const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
+  if (direct && (Cin & 1) == 0 && Cout > 64) {
+    const size_t half = packed_half(Cout, Cin * kh * kw);
+    int2* tab2;
+    rc = get_tab(ctx, MODE_DIRECT_TAB, Cin, kh, kw, H, W, &tab2);
+    if (rc) return rc;
+    p.tab2 = tab2;
+    p.wd = packed_w + half;
+    p.wd_bytes = (unsigned)(half * sizeof(float));
+  }
   return launch_conv<MODE_CONV>(ctx, p, 1);
 }
 
@@ -647,6 +882,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   int rc = get_tab(ctx, MODE_DECONV, Cin, 4, 4, H, W, &tab);
   if (rc) return rc;
   p.tab = tab;
+  p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
   return launch_conv<MODE_DECONV>(ctx, p, 4);
 }
 

@@ -4,9 +4,9 @@
  * Follows the layer definitions wired at deepim/symbols/deepIM_flownet.py:63-167 (conv stack),
  * :176-200/:317-340 (heads + k32 s16 grouped upsampling) and MXNet 1.2's documented operator
  * definitions (third-party, not vendored: PARITY UNPINNED by reference tests; cross-checked
- * against torch-CPU in tests/).  Accumulation is a float32 fmaf chain in (ci,ky,kx) order per
- * output element — the same order the MI355X fp32-MFMA kernel uses, so conv/deconv parity is
- * checked bit-for-bit.
+ * against torch-CPU in tests/).  Accumulation is a float32 fmaf chain per output element in the
+ * order the MI355X fp32-MFMA kernels use — (ci,ky,kx), or channel-pair-interleaved on request — so
+ * conv/deconv parity is checked bit-for-bit.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -14,39 +14,50 @@
 
 static inline float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-/* out (B,Cout,Ho,Wo) */
-void oracle_conv2d(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
-                   int Cout, int kh, int kw, int stride, int pad, float slope) {
+/* out (B,Cout,Ho,Wo).  pair_order = 0: the chain runs over k = (ci,ky,kx), ci slowest (the natural MXNet weight order);
+ * pair_order = 1: over (ci/2, ky, kx, ci%2) — adjacent input channels interleaved per tap, the order of the LDS-free
+ * MI355X kernel (needs even Cin).  fp32 addition is not associative and the reference's own order (cuDNN / MKL-DNN
+ * under MXNet) is unspecified, so both are equally faithful restatements; each kernel is checked bit-for-bit against
+ * the order it implements and to 1e-5 against the other. */
+void oracle_conv2d_order(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
+                         int Cout, int kh, int kw, int stride, int pad, float slope, int pair_order) {
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  const int khw = kh * kw, K = Cin * khw;
 #pragma omp parallel for collapse(2) schedule(dynamic)
   for (int n = 0; n < B; ++n)
     for (int co = 0; co < Cout; ++co) {
       float* acc = out + ((size_t)n * Cout + co) * Ho * Wo;
       memset(acc, 0, sizeof(float) * Ho * Wo);
-      for (int ci = 0; ci < Cin; ++ci) {
+      for (int s = 0; s < K; ++s) {
+        int ci, t;
+        if (pair_order) { const int g = s >> 1; ci = 2 * (g / khw) + (s & 1); t = g % khw; }
+        else { ci = s / khw; t = s % khw; }
+        const int ky = t / kw, kx = t % kw;
         const float* ip = in + ((size_t)n * Cin + ci) * H * W;
-        for (int ky = 0; ky < kh; ++ky)
-          for (int kx = 0; kx < kw; ++kx) {
-            const float wv = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
-            int wo_lo = 0, wo_hi = Wo;
-            while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
-            while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
-            for (int ho = 0; ho < Ho; ++ho) {
-              const int hi = ho * stride - pad + ky;
-              if (hi < 0 || hi >= H) continue;
-              const float* row = ip + (size_t)hi * W - pad + kx;
-              float* arow = acc + (size_t)ho * Wo;
-              if (stride == 1) {
-                for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo], arow[wo]);
-              } else {
-                for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo * stride], arow[wo]);
-              }
-            }
+        const float wv = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
+        int wo_lo = 0, wo_hi = Wo;
+        while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
+        while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
+        for (int ho = 0; ho < Ho; ++ho) {
+          const int hi = ho * stride - pad + ky;
+          if (hi < 0 || hi >= H) continue;
+          const float* row = ip + (size_t)hi * W - pad + kx;
+          float* arow = acc + (size_t)ho * Wo;
+          if (stride == 1) {
+            for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo], arow[wo]);
+          } else {
+            for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo * stride], arow[wo]);
           }
+        }
       }
       const float bv = bias ? bias[co] : 0.f;
       for (int i = 0; i < Ho * Wo; ++i) acc[i] = lrelu(acc[i] + bv, slope);
     }
+}
+
+void oracle_conv2d(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
+                   int Cout, int kh, int kw, int stride, int pad, float slope) {
+  oracle_conv2d_order(out, in, w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, 0);
 }
 
 /* MXNet Deconvolution k4 s2 p0, w (Cin,Cout,4,4), cropped at (crop_y,crop_x) to (Ho,Wo). */

@@ -33,13 +33,16 @@ def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=f32)
 
 
-def conv2d(x, w, b, stride, pad, slope=1.0):
+def conv2d(x, w, b, stride, pad, slope=1.0, pair_order=False):
+    """pair_order: accumulate over (ci/2, ky, kx, ci%2) instead of (ci, ky, kx) — see net.c."""
     x, w, b = _c(x), _c(w), _c(b)
     B, Cin, H, W = x.shape
     Cout, _, kh, kw = w.shape
+    assert not pair_order or Cin % 2 == 0
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     out = np.empty((B, Cout, Ho, Wo), f32)
-    _lib().oracle_conv2d(_p(out), _p(x), _p(w), _p(b), B, Cin, H, W, Cout, kh, kw, stride, pad, ctypes.c_float(slope))
+    _lib().oracle_conv2d_order(_p(out), _p(x), _p(w), _p(b), B, Cin, H, W, Cout, kh, kw, stride, pad, ctypes.c_float(slope),
+                               int(bool(pair_order)))
     return out
 
 

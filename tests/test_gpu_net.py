@@ -62,6 +62,50 @@ def test_conv_bit_exact(ctx, case):
     assert np.abs(got2 - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+DIRECT_CASES = [
+    (2, 64, 60, 80, 128, 5, 2, 2),     # conv2 geometry (5x5 stride 2)
+    (1, 128, 30, 40, 256, 5, 2, 2),    # conv3
+    (2, 256, 15, 20, 256, 3, 1, 1),    # conv3_1 (3x3 stride 1), ragged last pixel tile
+    (1, 512, 8, 10, 1024, 3, 2, 1),    # conv6: 20 output pixels in a 128-pixel tile
+    (1, 6, 9, 11, 70, 3, 1, 1),        # K = 54 pads to 64; Cout not a multiple of 32
+    (3, 10, 17, 13, 96, 7, 2, 3),      # 7x7 taps use validity bits ≥ 32
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES)
+def test_conv_direct_kernel_bit_exact(ctx, case):
+    """The LDS-free kernel (conv_direct=2: also without split-K) accumulates over (ci/2,ky,kx,ci%2): bit-identical to
+    the oracle run in that order, and within fp32 re-association distance of the canonical order."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    lib.deepim_set_option(ctx.handle, b"conv_direct", 2)
+    try:
+        got = _run_conv(ctx, x, w, b, s, p, 0.1)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+        lib.deepim_set_option(ctx.handle, b"conv_direct", 1)
+    ref_pair = onet.conv2d(x, w, b, s, p, 0.1, pair_order=True)
+    ref = onet.conv2d(x, w, b, s, p, 0.1)
+    np.testing.assert_array_equal(got, ref_pair)
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # default policy: LDS-free kernel + auto split-K
+    got2 = _run_conv(ctx, x, w, b, s, p, 0.1)
+    assert np.abs(got2 - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # conv_direct = 0 falls back to the LDS kernel (canonical order when not split)
+    lib.deepim_set_option(ctx.handle, b"conv_direct", 0)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    try:
+        got3 = _run_conv(ctx, x, w, b, s, p, 0.1)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+        lib.deepim_set_option(ctx.handle, b"conv_direct", 1)
+    np.testing.assert_array_equal(got3, ref)
+
+
 def test_conv_matches_torch_cpu(ctx):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)

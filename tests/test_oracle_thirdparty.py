@@ -65,3 +65,21 @@ def test_bilinear_init_is_separable_tent():
     assert w.shape == (2, 1, 32, 32)
     k1 = 1 - np.abs(np.arange(32) / 16.0 - (2 * 16 - 1) / 32.0)
     np.testing.assert_allclose(w[1, 0], np.outer(k1, k1), rtol=1e-6)
+
+
+def test_conv_order_switch_matches_torch_and_itself():
+    """Both accumulation orders of the conv restatement are the same convolution (torch as second opinion); they differ
+    from each other only by fp32 re-association, and coincide exactly when every product is exact."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 6, 13, 17)).astype(np.float32)
+    w = (rng.standard_normal((5, 6, 3, 3)) / 7).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    ref = F.leaky_relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=2, padding=1), 0.1).numpy()
+    a = onet.conv2d(x, w, b, 2, 1, 0.1)
+    p = onet.conv2d(x, w, b, 2, 1, 0.1, pair_order=True)
+    np.testing.assert_allclose(a, ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(p, ref, rtol=1e-4, atol=1e-5)
+    assert np.abs(a - p).max() < 1e-5
+    xi = rng.integers(-3, 4, x.shape).astype(np.float32)     # small integers: every partial sum is exact in fp32
+    wi = rng.integers(-3, 4, w.shape).astype(np.float32)
+    np.testing.assert_array_equal(onet.conv2d(xi, wi, None, 1, 1, 1.0), onet.conv2d(xi, wi, None, 1, 1, 1.0, pair_order=True))

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--tile256", type=int, default=0)
     ap.add_argument("--below", type=int, default=512)
     ap.add_argument("--target", type=int, default=768)
+    ap.add_argument("--direct", type=int, default=0, help="1: LDS-free register-fed conv kernel")
+    ap.add_argument("--maxsplit", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="compare every layer against the LDS kernel (split-K off)")
     a = ap.parse_args()
     ctx = Context.get(0)
     cfg = default_config()
@@ -37,6 +40,25 @@ def main():
     lib.deepim_set_option(ctx.handle, b"conv_tile256", a.tile256)
     lib.deepim_set_option(ctx.handle, b"conv_split_below", a.below)
     lib.deepim_set_option(ctx.handle, b"conv_split_target", a.target)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", a.maxsplit)
+    if a.check and not a.fp16:
+        rng = np.random.default_rng(0)
+        net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+        lib.deepim_set_option(ctx.handle, b"conv_direct", 0)
+        net.encoder()
+        ref = {g[0]: net.act[g[0]].asnumpy() for g in net.enc_geom}
+        lib.deepim_set_option(ctx.handle, b"conv_direct", 1)
+        src = net.act["net_input"]
+        for name, cin, h, w, cout, k, s, p in net.enc_geom:
+            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+            got = net.act[name].asnumpy()
+            err = float(np.abs(got - ref[name]).max() / max(1e-30, np.abs(ref[name]).max()))
+            print(json.dumps({"check": name, "rel_err_vs_lds_kernel": err, "bitwise_equal": bool(np.array_equal(got, ref[name]))}))
+            net.act[name].copyfrom(ref[name])     # keep the chain on reference inputs
+            src = net.act[name]
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", a.maxsplit)
+    lib.deepim_set_option(ctx.handle, b"conv_direct", a.direct)
     rng = np.random.default_rng(0)
     net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
     net.encoder()
