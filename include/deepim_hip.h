@@ -51,6 +51,10 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * "conv_direct": 1 (default) = 128x128-tiled convs with even Cin run on the LDS-free register-fed kernel, whose
  * fmaf chain runs over (ci/2,ky,kx,ci%2) (differs from the canonical order in the last bits; the oracle has the
  * matching order switch); it steps aside when conv_max_split == 1; 2 = use it even then; 0 = never.
+ * "conv_tail_split": 1 = the autotuner may cut only the tiles of the under-filled last round of a launch into K
+ * slices (default 0: a pair's summation order would depend on its position in the batch); "conv_tail_slots": round
+ * size in 128x128 blocks (default 1024 = 256 CUs x 4); "conv_force_plan": dev knob, n > 0 uniform split-K,
+ * n < 0 tail split with -n slices, 0 = heuristic/autotuner.
  * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order.
  * "conv_autotune": 1 (default) = on the first call of a conv geometry, time a few split-K factors and keep
  * the fastest; 0 = heuristic only ("conv_split_below"/"conv_split_target": split when the grid has fewer

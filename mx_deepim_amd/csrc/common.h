@@ -27,6 +27,9 @@ struct deepim_ctx {
   std::vector<ConvTab> conv_tabs;
   std::vector<ConvPlan> conv_plans;
   int conv_direct;    // LDS-free register-fed kernel for 128x128-tiled convs: 0 off, 1 (default) unless conv_max_split == 1, 2 always
+  int conv_tail_split;  // 1: let the autotuner consider tail splits (default 0, see launch_conv)
+  int conv_force_plan;  // dev: 0 = off, n > 0 = uniform split-K n, n < 0 = tail split with -n slices
+  int conv_tail_slots;  // resident 128x128 blocks of the LDS-free kernel on the whole chip (256 CUs x 4): round size for the tail split
   int conv_tile256;   // 1: 256x128 tiles (512-thread blocks) when Cout % 256 == 0 (default 0)
   int conv_autotune;  // 1 (default): time split-K candidates on the first call of a geometry
   int conv_max_split;  // 0 auto, 1 off, n cap

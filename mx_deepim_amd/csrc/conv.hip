@@ -21,6 +21,7 @@
 //     output may be a channel slice of a wider tensor (free Concat).
 // Roofline: MFMA-bound (arithmetic intensity ≈ 300 FLOP/B).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -84,6 +85,10 @@ struct ConvParams {
   const float* wd;          // direct-kernel weights [Cout/32][k-pair][2][32] (second half of the packed buffer)
   const int2* tab2;         // direct-kernel tap table, one entry per k-pair (ci2,ky,kx): {byte offset of channel 2*ci2, bit}
   unsigned wd_bytes;
+  // tail split (LDS-free kernel): tiles [0, n_full) run their whole K range; each of the R = tiles - n_full tiles that
+  // would form the under-filled last round is cut into tail_s K slices (tile-local partials → tail_reduce_kernel)
+  int n_full, tail_s, tail_cps, n_tail_pad;
+  float* tail_partial;      // [tail_s][R][128 co][128 px]
 };
 
 template <int BM, int BN, int MODE, int NT = 256>
@@ -374,21 +379,37 @@ constexpr int DR = DIRECT_RING, DPD = DR - 1;
 static_assert(DK % DR == 0 && DPD < DK, "ring must divide the chunk");
 
 // (Tried: single-wave workgroups, one 64x64 quadrant each, for 4x finer tail granularity — 60 TF, half the rate.)
+// WMW = wave rows: 2 → waves 2x2 over a 128x128 tile; 1 → waves 1x4 over a 64x256 tile (Cout <= 64: conv1)
+template <int WMW>
 __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int BM = 64 * WMW, BN = 64 * (4 / WMW), TM = 2, TN = 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  int vid;
-  {
+  const int wm0 = WMW == 2 ? (wave >> 1) * 64 : 0, wn0 = WMW == 2 ? (wave & 1) * 64 : wave * 64;
+  int vid, split, tail_item = -1;
+  if (p.tail_s > 0) {
+    // every XCD (block b → XCD b % 8) first walks its eighth of the full tiles, then its eighth of the tail items,
+    // so the short items are dispatched last on all XCDs and fill the round the full tiles leave under-used
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int fq = p.n_full >> 3, tq8 = p.n_tail_pad >> 3;
+    if (idx < fq) {
+      vid = xcd * fq + idx;
+      split = 0;
+    } else {
+      tail_item = xcd * tq8 + (idx - fq);
+      if (tail_item >= (p.gx * p.gy - p.n_full) * p.tail_s) return;
+      vid = p.n_full + tail_item / p.tail_s;
+      split = tail_item % p.tail_s;
+    }
+  } else {
     const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
     const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
     vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
+    split = vid / (p.gx * p.gy);
   }
   const int bx = vid % p.gx;
   const int mb = (vid / p.gx) % p.gy;
-  const int split = vid / (p.gx * p.gy);
   const long n0 = (long)bx * BN;
   const int lrow = lane >> 5, lcol = lane & 31;
   const long npix = p.npix;
@@ -425,10 +446,16 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
   const int npair = p.nchunk * DK;
   int wvo[TM];   // A operand: [32-row tile][4 k-steps][lane][4] → one b128 load per tile per 4 k-steps, 1 KB contiguous per wave
 #pragma unroll
-  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * 4 + (wm0 >> 5) + i) * (npair / 4)) * 64 + lane) * 16;
+  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * (BM / 32) + (wm0 >> 5) + i) * (npair / 4)) * 64 + lane) * 16;
 
-  const int kc_begin = split * p.chunks_per_split;
-  const int kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
+  int kc_begin = split * p.chunks_per_split;
+  int kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
+  if (p.tail_s > 0) {
+    kc_begin = tail_item < 0 ? 0 : split * p.tail_cps;
+    kc_end = tail_item < 0 ? p.nchunk : min(p.nchunk, kc_begin + p.tail_cps);
+  }
+  kc_begin = __builtin_amdgcn_readfirstlane(kc_begin);   // block-uniform by construction; keeps the table pointers in SGPRs
+  kc_end = __builtin_amdgcn_readfirstlane(kc_end);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -506,6 +533,18 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 #undef ASEL
 #undef DLOADB
 
+  if (tail_item >= 0) {   // raw partial sums, tile-local layout [slice][remainder tile][co 128][px 128]
+    const int R = p.gx * p.gy - p.n_full;
+    float* tp = p.tail_partial + ((long)split * R + (vid - p.n_full)) * (BM * BN);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tp[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * BN + wn0 + j * 32 + lcol] = acc[i][j][r];
+    return;
+  }
   const bool partial = p.ksplit > 1;
   float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
   const int ctotal = partial ? p.Cout : p.out_ctotal;
@@ -551,6 +590,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
   v = v + (bias ? bias[c] : 0.f);
   v = v > 0.f ? v : v * slope;
   out[(n * ctotal + coff + c) * hw + r] = v;
+}
+
+// tail-split second pass: one block per remainder tile; out = lrelu(Σ_slice partial + bias), slices in fixed order
+__global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
+                                                          const float* __restrict__ bias, int n_full, int R, int S,
+                                                          int gx, int Cout, long npix, int hw, int ctotal, int coff,
+                                                          float slope) {
+  const int rt = blockIdx.x, vid = n_full + rt;
+  const int bx = vid % gx, mb = vid / gx;
+  const float* pp = partial + (long)rt * 16384;
+  for (int e = threadIdx.x; e < 16384; e += 256) {
+    const int co = mb * 128 + (e >> 7);
+    const long pix = (long)bx * 128 + (e & 127);
+    if (co >= Cout || pix >= npix) continue;
+    float v = pp[e];
+    for (int s = 1; s < S; ++s) v += pp[(long)s * R * 16384 + e];
+    v = v + (bias ? bias[co] : 0.f);
+    v = v > 0.f ? v : v * slope;
+    const long n = pix / hw;
+    const int r = (int)(pix - n * hw);
+    out[(n * ctotal + coff + co) * hw + r] = v;
+  }
 }
 
 // ------------------------------------------------------------ packing ----
@@ -652,7 +713,7 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
   out[((long)bc * Ho + yo) * Wo + xo] = acc * scale;
 }
 
-struct TileChoice { int bm, bn, ksplit; };
+struct TileChoice { int bm, bn, ksplit, tail_s; };
 // Tile/split heuristic for 256 CUs × 3 resident blocks: 128x128 (best MFMA density per LDS byte and per
 // gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the chip under-filled, split K
 // across grid.z (deterministic two-pass reduction) before shrinking the tile.
@@ -664,7 +725,7 @@ TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, i
   const long blocks = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
   int ks = 1;
   if (blocks < below) ks = (int)min((long)di_div_up(target, blocks), (long)max(1, nchunk / 8));
-  return {bm, bn, ks};
+  return {bm, bn, ks, 0};
 }
 
 template <int MODE>
@@ -682,10 +743,33 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   }
   p.swizzle = ctx->conv_xcd_swizzle;
   p.gx = di_div_up(p.npix, t.bn); p.gy = di_div_up(p.Cout, t.bm); p.gz = classes * p.ksplit;
+  p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
+  const bool direct_ok = MODE == MODE_CONV && t.bm == 128 && t.bn == 128 && p.tab2 != nullptr;
+  if (direct_ok && t.tail_s > 1 && t.ksplit == 1) {
+    const int tiles = p.gx * p.gy, slots = ctx->conv_tail_slots;
+    const int n_full = tiles / slots * slots, R = tiles - n_full;
+    if (n_full > 0 && R > 0) {
+      p.n_full = n_full;
+      p.tail_cps = di_div_up(p.nchunk, t.tail_s);
+      p.tail_s = di_div_up(p.nchunk, p.tail_cps);
+      p.n_tail_pad = di_div_up(R * p.tail_s, 8) * 8;
+      void* scratch;
+      int rc = deepim_scratch(ctx, (size_t)R * p.tail_s * 16384 * sizeof(float), &scratch);
+      if (rc) return rc;
+      p.tail_partial = (float*)scratch;
+      hipLaunchKernelGGL(conv_direct_kernel<2>, dim3(p.n_full + p.n_tail_pad), dim3(256), 0, ctx->stream, p);
+      hipLaunchKernelGGL(tail_reduce_kernel, dim3(R), dim3(256), 0, ctx->stream, p.out, p.tail_partial, p.bias, n_full, R,
+                         p.tail_s, p.gx, p.Cout, p.npix, p.Ho * p.Wo, p.out_ctotal, p.out_coff, p.slope);
+      DI_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
   dim3 grid(p.gx * p.gy * p.gz);
-  if (MODE == MODE_CONV && t.bm == 128 && t.bn == 128 && p.tab2 != nullptr)
-    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, ctx->stream, p);
+  if (direct_ok)
+    hipLaunchKernelGGL(conv_direct_kernel<2>, grid, dim3(256), 0, ctx->stream, p);
+  else if (MODE == MODE_CONV && t.bm == 64 && t.bn == 256 && p.tab2 != nullptr)
+    hipLaunchKernelGGL(conv_direct_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
   else if (t.bm == 256)
     hipLaunchKernelGGL((conv_mfma_kernel<256, 128, MODE, 512>), grid, dim3(512), 0, ctx->stream, p);
   else if (t.bm == 128)
@@ -710,17 +794,35 @@ template <int MODE>
 int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
   TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes);
   const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
-                           ctx->conv_split_below * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0), ctx->conv_split_target};
+                           ctx->conv_split_below * 16 + ctx->conv_tail_split * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0),
+                           ctx->conv_split_target};
   if (ctx->conv_autotune && ctx->conv_max_split != 1) {
     bool found = false;
     for (auto& e : ctx->conv_plans)
-      if (memcmp(&e.key, &key, sizeof(key)) == 0) { t.ksplit = e.ksplit; found = true; break; }
+      if (memcmp(&e.key, &key, sizeof(key)) == 0) {   // plan value: > 0 uniform split-K factor, < 0 tail split with -value slices
+        t.ksplit = e.ksplit > 0 ? e.ksplit : 1;
+        t.tail_s = e.ksplit < 0 ? -e.ksplit : 0;
+        found = true;
+        break;
+      }
     if (!found && !ctx->capturing) {
       const int tiles = di_div_up(p.Cout, t.bm) * di_div_up(p.npix, t.bn) * classes;
-      int cands[12], nc = 0;
+      int cands[16], nc = 0;
       const int base[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24};
       for (int c : base)
         if ((c == 1 || (long)tiles * c <= 4096) && c <= max(1, p.nchunk / 4)) cands[nc++] = c;
+      // tail split (LDS-free kernel only, opt-in): cut just the tiles of the under-filled last round, so that their
+      // slices about fill one round of the chip; candidates are encoded as negative values. Off by default: measured
+      // +2.8 % on conv2, ±1 % elsewhere, and a pair's summation order then depends on its position in the batch
+      // (results stop being bit-identical under a permutation of the pairs).
+      if (ctx->conv_tail_split && MODE == MODE_CONV && t.bm == 128 && t.bn == 128 && p.tab2 != nullptr && classes == 1) {
+        const int slots = ctx->conv_tail_slots, R = tiles % slots;
+        if (tiles >= slots && R > 0) {
+          const int s0 = min(slots / R, max(1, p.nchunk / 4));
+          for (int sN : {s0, s0 - 1, s0 * 2})
+            if (sN >= 2 && sN <= max(1, p.nchunk / 4) && nc < 16) cands[nc++] = -sN;
+        }
+      }
       hipEvent_t e0, e1;
       DI_CHECK(hipEventCreate(&e0));
       DI_CHECK(hipEventCreate(&e1));
@@ -728,7 +830,8 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
       int best_ks = t.ksplit;
       for (int ci = 0; ci < nc; ++ci) {
         TileChoice tc = t;
-        tc.ksplit = cands[ci];
+        tc.ksplit = cands[ci] > 0 ? cands[ci] : 1;
+        tc.tail_s = cands[ci] < 0 ? -cands[ci] : 0;
         int rc = launch_one<MODE>(ctx, p, classes, tc);  // warm (also grows the scratch once)
         if (rc) return rc;
         DI_CHECK(hipEventRecord(e0, ctx->stream));
@@ -741,11 +844,20 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
       }
       hipEventDestroy(e0);
       hipEventDestroy(e1);
+      if (getenv("DEEPIM_CONV_VERBOSE"))
+        fprintf(stderr, "[deepim] conv plan B=%d Cin=%d %dx%d Cout=%d s%d: %d tiles, %s %d (%.3f ms)\n", p.B, p.Cin, p.H, p.W,
+                p.Cout, p.stride, tiles, best_ks < 0 ? "tail split" : "split-K", best_ks < 0 ? -best_ks : best_ks, best / 3);
       ctx->conv_plans.push_back({key, best_ks});
-      t.ksplit = best_ks;
+      t.ksplit = best_ks > 0 ? best_ks : 1;
+      t.tail_s = best_ks < 0 ? -best_ks : 0;
     }
   }
+  if (ctx->conv_force_plan != 0) {   // dev knob: bypass heuristic and autotuner (> 0 uniform split-K, < 0 tail split)
+    t.ksplit = ctx->conv_force_plan > 0 ? ctx->conv_force_plan : 1;
+    t.tail_s = ctx->conv_force_plan < 0 ? -ctx->conv_force_plan : 0;
+  }
   if (ctx->conv_max_split > 0 && t.ksplit > ctx->conv_max_split) t.ksplit = ctx->conv_max_split;
+  if (ctx->conv_max_split > 0 && t.tail_s > ctx->conv_max_split) t.tail_s = ctx->conv_max_split > 1 ? ctx->conv_max_split : 0;
   return launch_one<MODE>(ctx, p, classes, t);
 }
 
@@ -832,7 +944,7 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
   // (ci,ky,kx)-ordered chain per output, which only the LDS kernel provides; conv_direct = 2 forces the LDS-free kernel
   // regardless (its chain runs over (ci/2,ky,kx,ci%2)).
   const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
-  if (direct && (Cin & 1) == 0 && Cout > 64) {
+  if (direct && (Cin & 1) == 0 && (Cout > 64 || p.npix >= 256L * 1024)) {   // the tile shapes the LDS-free kernel has
     const size_t half = packed_half(Cout, Cin * kh * kw);
     int2* tab2;
     rc = get_tab(ctx, MODE_DIRECT_TAB, Cin, kh, kw, H, W, &tab2);

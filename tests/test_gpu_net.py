@@ -106,6 +106,26 @@ def test_conv_direct_kernel_bit_exact(ctx, case):
     np.testing.assert_array_equal(got3, ref)
 
 
+def test_conv_tail_split_plan(ctx):
+    """Opt-in tail split of the LDS-free kernel: 1030 tiles with a round size of 256 → 1024 full tiles + 6 tiles cut
+    into K slices and summed by tail_reduce_kernel in slice order. Same sums re-associated: ≤1e-5 of the oracle."""
+    rng = np.random.default_rng(5)
+    B, cin, H, W, cout = 1, 32, 206, 320, 256          # npix = 65920 → 515 pixel tiles x 2 M tiles
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = onet.conv2d(x, w, b, 1, 1, 0.1)
+    lib.deepim_set_option(ctx.handle, b"conv_tail_slots", 256)
+    try:
+        for plan in (-2, -3, -4, -18):
+            lib.deepim_set_option(ctx.handle, b"conv_force_plan", plan)
+            got = _run_conv(ctx, x, w, b, 1, 1, 0.1)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), plan
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_force_plan", 0)
+        lib.deepim_set_option(ctx.handle, b"conv_tail_slots", 1024)
+
+
 def test_conv_matches_torch_cpu(ctx):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)

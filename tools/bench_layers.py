@@ -48,15 +48,17 @@ def main():
         lib.deepim_set_option(ctx.handle, b"conv_direct", 0)
         net.encoder()
         ref = {g[0]: net.act[g[0]].asnumpy() for g in net.enc_geom}
-        lib.deepim_set_option(ctx.handle, b"conv_direct", 1)
-        src = net.act["net_input"]
-        for name, cin, h, w, cout, k, s, p in net.enc_geom:
-            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
-            got = net.act[name].asnumpy()
-            err = float(np.abs(got - ref[name]).max() / max(1e-30, np.abs(ref[name]).max()))
-            print(json.dumps({"check": name, "rel_err_vs_lds_kernel": err, "bitwise_equal": bool(np.array_equal(got, ref[name]))}))
-            net.act[name].copyfrom(ref[name])     # keep the chain on reference inputs
-            src = net.act[name]
+        for mode, ms in (("direct, no split", 1), ("default policy", 0)):
+            lib.deepim_set_option(ctx.handle, b"conv_direct", 2 if ms else 1)
+            lib.deepim_set_option(ctx.handle, b"conv_max_split", ms)
+            src = net.act["net_input"]
+            for name, cin, h, w, cout, k, s, p in net.enc_geom:
+                net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+                got = net.act[name].asnumpy()
+                err = float(np.abs(got - ref[name]).max() / max(1e-30, np.abs(ref[name]).max()))
+                print(json.dumps({"check": name, "mode": mode, "rel_err_vs_lds_kernel": err}))
+                net.act[name].copyfrom(ref[name])     # keep the chain on reference inputs
+                src = net.act[name]
         lib.deepim_set_option(ctx.handle, b"conv_max_split", a.maxsplit)
     lib.deepim_set_option(ctx.handle, b"conv_direct", a.direct)
     rng = np.random.default_rng(0)
