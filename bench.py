@@ -119,7 +119,8 @@ def main():
     render_machine = Render_Py("synthetic", ["ellipsoid"], batch["K"], 640, 480, 0.25, 6.0,
                                meshes={"ellipsoid": mesh}, ctx=ctx, pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
     rbuf = {"image_rendered": ctx.empty((B, 3, 480, 640)), "depth_rendered": ctx.empty((B, 1, 480, 640))}
-    mask_pp = [ctx.empty((B, 1, 480, 640)) for _ in range(2)]
+    rbuf["mask_rendered"] = ctx.empty((B, 1, 480, 640))
+    rbuf["mask_observed"] = ctx.empty((B, 1, 480, 640))
 
     gather_in = gather_out = None
     if world > 1:
@@ -162,8 +163,7 @@ def main():
             if it < NIT - 1 and not args.prestaged:
                 if rtimers:
                     rtimers[it].start()
-                data = update_test_batch(cfg, data, render_machine, pose_cur,
-                                         out=dict(rbuf, mask_rendered=mask_pp[it % 2]))
+                data = update_test_batch(cfg, data, render_machine, pose_cur, out=rbuf)
                 if rtimers:
                     rtimers[it].stop()
 

@@ -105,6 +105,11 @@ int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow /*B,2,H,W*/, float*
 int deepim_calc_KT(deepim_ctx* ctx, float* KT /*B,3,4*/, const float* pose_src,
                    const float* pose_tgt, const float* K_host, int B);
 int deepim_depth_to_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n);
+/* "box_rendered" / "box_observed" rectangle of a mask (lib/pair_matching/data_pair.py:94-116, the INIT_MASK twin at
+ * lib/utils/image.py:355-374): 1 inside [y_start:y_end, x_start:x_end] with start/end = first/last row and column holding a
+ * non-zero — numpy slices, so the last row and column stay 0. An empty mask gives zeros and sets bit 1 of the status word
+ * (deepim_zoom_status) where the reference raises. mask, box: (B,1,H,W) device. */
+int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float* mask, int B, int H, int W);
 
 /* --------------------------------------------------- Z-group: zoom / warp -- */
 /* zoom_mask.py:29-112 `ZoomMaskOperator.forward`.

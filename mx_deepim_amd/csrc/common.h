@@ -7,6 +7,8 @@
 #include <vector>
 #include "../../include/deepim_hip.h"
 
+constexpr int DI_MAX_BOX_SAMPLES = 4096;
+
 struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry
 
 struct ConvPlanKey { int mode, B, Cin, H, W, Cout, Ho, Wo, stride, pad, nchunk, below, target; };
@@ -19,7 +21,9 @@ struct deepim_ctx {
   void* scratch;
   size_t scratch_bytes;
   std::vector<void*> retired_scratch;  // outgrown scratch buffers still referenced by captured graphs
-  int* status;  // persistent device status word (bit0: empty observed mask/image in a zoom op)
+  int* status;  // persistent device status word (bit0: empty observed mask/image in a zoom op, bit1: empty mask in mask_box)
+  int* box_words;   // 2 x DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: double-buffered bbox accumulators of mask_box
+  int box_parity;
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
   std::vector<hipGraphExec_t> graphs;

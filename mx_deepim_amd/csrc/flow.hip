@@ -11,6 +11,7 @@
 // The library is built with -ffp-contract=off so the f32 operation order below is
 // exactly the order of the reference expressions (no fused multiply-adds).
 #include "common.h"
+#include <limits.h>
 
 namespace {
 
@@ -204,6 +205,46 @@ __global__ __launch_bounds__(256) void depth_to_mask_kernel(float* __restrict__ 
   if (i < n) mask[i] = depth[i] > thresh ? 1.f : 0.f;
 }
 
+// rectangle of a mask the way the reference draws it (lib/pair_matching/data_pair.py:94-105, lib/utils/image.py:363-372):
+// x/y_start = first, x/y_end = last column/row holding a non-zero, filled [y_start:y_end, x_start:x_end] — numpy slices,
+// so the last row and column stay 0. words: {xmin, xmax, ymin, ymax} per sample, pre-set to {INT_MAX,-1,INT_MAX,-1}.
+__global__ __launch_bounds__(256) void mask_bbox_kernel(int* __restrict__ words, const float* __restrict__ mask, int H,
+                                                        int W) {
+  const int b = blockIdx.y;
+  const float* m = mask + (long)b * H * W;
+  int xmin = INT_MAX, xmax = -1, ymin = INT_MAX, ymax = -1;
+  const int y0 = blockIdx.x * 8;
+  for (int i = threadIdx.x; i < 8 * W; i += 256) {
+    const int y = y0 + i / W, x = i - (i / W) * W;
+    if (y < H && m[(long)y * W + x] != 0.f) {
+      xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    xmin = min(xmin, __shfl_xor(xmin, off, 64)); xmax = max(xmax, __shfl_xor(xmax, off, 64));
+    ymin = min(ymin, __shfl_xor(ymin, off, 64)); ymax = max(ymax, __shfl_xor(ymax, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && xmax >= 0) {
+    atomicMin(&words[b * 4 + 0], xmin); atomicMax(&words[b * 4 + 1], xmax);
+    atomicMin(&words[b * 4 + 2], ymin); atomicMax(&words[b * 4 + 3], ymax);
+  }
+}
+__global__ __launch_bounds__(256) void mask_box_fill_kernel(float* __restrict__ box, const int* __restrict__ words,
+                                                            int* __restrict__ next_words, int* __restrict__ status,
+                                                            int H, int W) {
+  const int b = blockIdx.y;
+  const int xs = words[b * 4 + 0], xe = words[b * 4 + 1], ys = words[b * 4 + 2], ye = words[b * 4 + 3];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {   // arm the other word set for the next call (its last reader finished earlier in stream order)
+    next_words[b * 4 + 0] = INT_MAX; next_words[b * 4 + 1] = -1; next_words[b * 4 + 2] = INT_MAX; next_words[b * 4 + 3] = -1;
+    if (xe < 0) atomicOr(status, 2);   // empty mask: the reference's np.min of an empty array raises
+  }
+  if (i >= (long)H * W) return;
+  const int y = (int)(i / W), x = (int)(i - (long)y * W);
+  box[(long)b * H * W + i] = (xe >= 0 && y >= ys && y < ye && x >= xs && x < xe) ? 1.f : 0.f;
+}
+
 Mat3 load_mat3(const float* h) {
   Mat3 m;
   for (int i = 0; i < 9; ++i) m.v[i] = h[i];
@@ -330,6 +371,19 @@ extern "C" int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow, float* 
   dim3 grid(di_div_up((long)W * H, 256), B);
   hipLaunchKernelGGL(flow_updater_kernel, grid, dim3(256), 0, ctx->stream, flow, flow_weights, depth_src, depth_tgt,
                      KT, Kinv, thresh, wh_rep, H, W);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float* mask, int B, int H, int W) {
+  if (B == 0) return 0;
+  DI_REQUIRE(B <= DI_MAX_BOX_SAMPLES, "mask_box: batch too large");
+  int* cur = ctx->box_words + (ctx->box_parity ? DI_MAX_BOX_SAMPLES * 4 : 0);
+  int* nxt = ctx->box_words + (ctx->box_parity ? 0 : DI_MAX_BOX_SAMPLES * 4);
+  ctx->box_parity ^= 1;
+  hipLaunchKernelGGL(mask_bbox_kernel, dim3(di_div_up(H, 8), B), dim3(256), 0, ctx->stream, cur, mask, H, W);
+  hipLaunchKernelGGL(mask_box_fill_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, box, cur, nxt,
+                     ctx->status, H, W);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -44,8 +44,17 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
     delete c;
     return (int)e;
   }
-  e = hipMalloc((void**)&c->status, 64);
+  // status word + the bbox accumulators of deepim_mask_box_forward ({INT_MAX,-1,INT_MAX,-1} per sample, two sets)
+  const size_t box_bytes = (size_t)2 * DI_MAX_BOX_SAMPLES * 4 * sizeof(int);
+  e = hipMalloc((void**)&c->status, 64 + box_bytes);
   if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 64, c->stream);
+  if (e == hipSuccess) {
+    c->box_words = c->status + 16;
+    c->box_parity = 0;
+    std::vector<int> init((size_t)2 * DI_MAX_BOX_SAMPLES * 4);
+    for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0x7fffffff; init[i + 1] = -1; }
+    e = hipMemcpy(c->box_words, init.data(), box_bytes, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     deepim_set_error("hipMalloc(status)", e);
     hipStreamDestroy(c->stream);

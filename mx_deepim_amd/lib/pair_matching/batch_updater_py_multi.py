@@ -83,10 +83,10 @@ class batchUpdaterPyMulti(object):
 
 
 def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None, out=None):
-    """Test-loop update between refinement iterations — mirror of deepim/core/tester.py:420-455: re-render at the
-    refined pose, mask_rendered = depth > 0.2, and (TEST.UPDATE_MASK == "box_rendered") mask_observed = the mask_rendered
-    the PREVIOUS iteration saw. All on the device; `out` may carry preallocated image_rendered / depth_rendered /
-    mask_rendered arrays (the arrays of `data` itself are never overwritten, so the swap needs no copy)."""
+    """Test-loop update between refinement iterations — mirror of deepim/core/tester.py:420-455 +
+    lib/pair_matching/data_pair.py:62-132 (`update_data_batch`): re-render at the refined pose, mask_rendered =
+    depth > 0.2, and (TEST.UPDATE_MASK == "box_rendered") mask_observed = rectangle of the new rendered mask. All on the
+    device; `out` may carry preallocated image_rendered / depth_rendered / mask_rendered / mask_observed arrays."""
     ctx = refined_pose.context
     B, H, W = refined_pose.shape[0], render_machine.height, render_machine.width
     out = out or {}
@@ -113,7 +113,11 @@ def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None,
         new["mask_rendered"] = mask
         if cfg.network.PRED_MASK:
             if cfg.TEST.UPDATE_MASK == "box_rendered":
-                new["mask_observed"] = data["mask_rendered"]
+                # tester.py:445-449 hands the old mask_rendered over, but update_data_batch (data_pair.py:94-105) ignores
+                # it for this mode and draws the rectangle of the NEW rendered mask
+                box = out.get("mask_observed") or ctx.empty((B, 1, H, W))
+                lib.deepim_mask_box_forward(ctx.handle, box, mask, B, H, W)
+                new["mask_observed"] = box
             elif cfg.TEST.UPDATE_MASK != "init":
                 raise Exception("Unknown UPDATE_MASK type: {}".format(cfg.TEST.UPDATE_MASK))
     return new

@@ -117,10 +117,12 @@ def to_tensor(rgb, means=PIXEL_MEANS):
 
 
 def box_mask(mask):
+    """INIT_MASK / UPDATE_MASK "box_rendered" (lib/utils/image.py:363-372): [y_start:y_end, x_start:x_end] with end = the
+    LAST non-zero row/column used as an exclusive slice bound, so that row and column stay 0."""
     ys, xs = np.nonzero(mask)
     out = np.zeros_like(mask, dtype=np.float32)
     if len(ys):
-        out[ys.min():ys.max() + 1, xs.min():xs.max() + 1] = 1
+        out[ys.min():ys.max(), xs.min():xs.max()] = 1
     return out
 
 

@@ -122,3 +122,15 @@ def flow_updater(depth_src, depth_tgt, pose_src, pose_tgt, K, thresh=3e-3, wh_re
         flow[b, 0], flow[b, 1] = (wd, hd) if wh_rep else (hd, wd)
         wts[b, 0] = wts[b, 1] = ok.reshape(H, W)
     return flow, wts
+
+
+def mask_box(mask):
+    """data_pair.py:94-105 / image.py:363-372: rectangle [y_start:y_end, x_start:x_end] over the non-zeros of a (H,W) mask
+    (end indices exclusive, as the numpy slices of the reference are); zeros for an empty mask."""
+    mask = np.asarray(mask)
+    out = np.zeros(mask.shape, f32)
+    nz_x = np.nonzero(np.max(mask, 0))[0]
+    nz_y = np.nonzero(np.max(mask, 1))[0]
+    if len(nz_x) and len(nz_y):
+        out[np.min(nz_y):np.max(nz_y), np.min(nz_x):np.max(nz_x)] = 1.0
+    return out

@@ -187,3 +187,65 @@ def test_updater_closes_the_loop_on_device(ctx, small_batch):
     rf, rv = oflow.gpu_flow(dep, small_batch["depth_gt_observed"], KT, np.linalg.inv(K))
     np.testing.assert_allclose(new["flow"].asnumpy(), rf, atol=1e-4)
     assert (new["flow_weights"].asnumpy()[:, 0] != rv[:, 0]).mean() < 1e-4
+
+
+def test_mask_box_matches_reference_rectangle(ctx):
+    """deepim_mask_box_forward == the [y_start:y_end, x_start:x_end] rectangle of data_pair.py:94-105 (exclusive ends),
+    twice in a row (the bbox accumulators are double-buffered and re-armed on the device)."""
+    from oracle import flow as oflow
+    rng = np.random.default_rng(8)
+    B, H, W = 5, 48, 70
+    masks = np.zeros((B, 1, H, W), np.float32)
+    masks[0, 0, 10:30, 20:50] = 1
+    masks[1, 0, 5, 7] = 1                                  # single pixel: start == end → empty rectangle
+    masks[2, 0] = (rng.random((H, W)) > 0.97)              # scattered
+    masks[3, 0, :, :] = 1                                  # full frame: last row/column stay 0
+    masks[4, 0, 0, 0] = masks[4, 0, H - 1, W - 1] = 0.3    # non-binary non-zeros count
+    for rep in range(3):
+        box = ctx.empty((B, 1, H, W))
+        lib.deepim_mask_box_forward(ctx.handle, box, ctx.array(masks), B, H, W)
+        got = box.asnumpy()
+        for b in range(B):
+            np.testing.assert_array_equal(got[b, 0], oflow.mask_box(masks[b, 0]))
+        masks = np.ascontiguousarray(masks[::-1])         # different boxes next time: stale accumulators would show
+    st = ctypes.c_int(-1)
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value == 0
+    # empty mask: zeros + status bit 1 (the reference raises on np.min of an empty array)
+    masks[2] = 0
+    box = ctx.empty((B, 1, H, W))
+    lib.deepim_mask_box_forward(ctx.handle, box, ctx.array(masks), B, H, W)
+    assert not box.asnumpy()[2].any()
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value & 2
+    lib.deepim_mask_box_forward(ctx.handle, box, box, 0, H, W)   # B = 0 no-op
+
+
+def test_update_test_batch_mirrors_tester_loop(ctx, small_batch):
+    """tester.py:420-455 + data_pair.update_data_batch on the device: new frame, rendered mask, box_rendered mask."""
+    from oracle import flow as oflow
+    from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import update_test_batch
+    cfg = default_config()
+    B, H, W = 2, 480, 640
+    mesh = synthetic.ellipsoid_mesh(AXES, 24, 48)
+    mesh.pop("uv")
+    means = synthetic.PIXEL_MEANS[::-1].copy()
+    rm = Render_Py("unused", ["obj"], K, W, H, meshes={"obj": mesh}, ctx=ctx, pixel_means=means)
+    pose = ctx.array(small_batch["pose_tgt"])
+    data = {"image_observed": ctx.array(small_batch["image_observed"]), "src_pose": ctx.array(small_batch["src_pose"][0]),
+            "image_rendered": ctx.array(small_batch["image_rendered"][0]), "mask_rendered": ctx.array(small_batch["mask_rendered"][0]),
+            "mask_observed": ctx.array(small_batch["mask_observed"])}
+    new = update_test_batch(cfg, data, rm, pose)
+    assert new["src_pose"] is pose and new["image_observed"] is data["image_observed"]
+    mr = new["mask_rendered"].asnumpy()
+    for b in range(B):
+        ri, rd = orender.render(mesh["vertices"], mesh["colors"], mesh["faces"], small_batch["pose_tgt"][b], K, H, W, pixel_means=means)
+        np.testing.assert_allclose(new["image_rendered"].asnumpy()[b], ri, atol=1e-3)
+        np.testing.assert_array_equal(mr[b, 0], (rd > 0.2).astype(np.float32))
+        np.testing.assert_array_equal(new["mask_observed"].asnumpy()[b, 0], oflow.mask_box(mr[b, 0]))
+    assert "depth_rendered" not in new                      # INPUT_DEPTH off in the shipped config
+    cfg.TEST.UPDATE_MASK = "init"
+    assert update_test_batch(cfg, data, rm, pose)["mask_observed"] is data["mask_observed"]
+    cfg.TEST.UPDATE_MASK = "mask_rendered"
+    with pytest.raises(Exception):
+        update_test_batch(cfg, data, rm, pose)
