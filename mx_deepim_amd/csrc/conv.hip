@@ -301,9 +301,7 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#ifndef ABL_NOBARRIER
     __syncthreads();
-#endif
   }
 #undef GATHER
 #undef BSEL

@@ -25,8 +25,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HKT = 64;   // K per chunk
-constexpr int HOCT = 8;   // octets per chunk
+constexpr int HOCT = 8;   // octets per chunk (K chunk = 8 octets x 8 halves = 64)
 constexpr int HBM = 128, HBN = 128;
 
 struct ConvF16Params {
