@@ -305,6 +305,16 @@ int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth, const flo
                           int tex_h, int tex_w, const float* poses, const float* K_host,
                           const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
                           float zfar);
+/* The same draw fused with the rest of the test-loop update (deepim/core/tester.py:437-449,
+ * lib/pair_matching/data_pair.py:94-105): also writes mask_rendered = depth > mask_thresh (B,1,H,W) and, when mask_box
+ * is not NULL, the box_rendered rectangle of that mask (see deepim_mask_box_forward) — one pass over the frame instead
+ * of three. */
+int deepim_render_update_forward(deepim_ctx* ctx, float* image, float* depth, float* mask_rendered,
+                                 float* mask_box /*or NULL*/, float mask_thresh, const float* vertices,
+                                 const float* vertex_attr, const int32_t* faces, const float* texture,
+                                 int tex_h, int tex_w, const float* poses, const float* K_host,
+                                 const float* pixel_means_host, int V, int F, int B, int H, int W,
+                                 float znear, float zfar);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ struct deepim_ctx {
   std::vector<ConvTab> conv_tabs;
   std::vector<ConvPlan> conv_plans;
   int conv_direct;    // LDS-free register-fed kernel for 128x128-tiled convs: 0 off, 1 (default) unless conv_max_split == 1, 2 always
+  int fc_slices;        // dev: K slices of the FC GEMV (0 = enough for ~1024 blocks)
   int conv_tail_split;  // 1: let the autotuner consider tail splits (default 0, see launch_conv)
   int conv_force_plan;  // dev: 0 = off, n > 0 = uniform split-K n, n < 0 = tail split with -n slices
   int conv_tail_slots;  // resident 128x128 blocks of the LDS-free kernel on the whole chip (256 CUs x 4): round size for the tail split
@@ -69,6 +70,9 @@ void deepim_set_error_msg(const char* msg);
       return -1;                                         \
     }                                                    \
   } while (0)
+
+// fill pass of the box_rendered rectangle from accumulated bbox words (csrc/flow.hip); re-arms `nxt`
+int deepim_mask_box_fill(deepim_ctx* ctx, float* box, int* cur, int* nxt, int B, int H, int W);
 
 // Grow-only scratch; never reallocated while a graph capture is open.
 int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out);

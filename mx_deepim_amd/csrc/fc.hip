@@ -3,18 +3,19 @@
 //   rot / trans FCs + ZoomTrans(inv) + Concat → se3   deepIM_flownet.py:715-726, zoom_trans.py:22-46
 //
 // fc6 is a 256×81920 weight stream (84 MB fp32) against a handful of activation rows:
-// HBM-bound on the weights. Split-K GEMV-style kernel: a block owns 16 output rows ×
-// one K slice; each lane streams dwordx4 of 4 weight rows and re-uses every activation
-// dwordx4 it loads for those 4 rows (activations come from L2). Partials are reduced in
-// a fixed order by a second tiny kernel (deterministic, no float atomics) that also
-// applies bias + LeakyReLU.
+// HBM-bound on the weights in principle, L1-bound on the activation re-reads in practice
+// (16 activation dwordx4 per lane per step against the weight loads). Split-K GEMV-style
+// kernel: a block owns 32 output rows × one K slice; each lane streams dwordx4 of 8 weight
+// rows and re-uses every activation dwordx4 it loads for those 8 rows (4 rows: 60 µs,
+// 8 rows: 43 µs for fc6 at B = 16). Partials are reduced in a fixed order by a second tiny
+// kernel (deterministic, no float atomics) that also applies bias + LeakyReLU.
 #include "common.h"
 
 namespace {
 
 constexpr int FC_BT = 16;   // batch rows per pass
-constexpr int FC_RW = 4;    // output rows per wave
-constexpr int FC_ROWS = 16; // output rows per block (4 waves)
+constexpr int FC_RW = 8;    // output rows per wave: every activation dwordx4 (the L1-side bottleneck) feeds 8 rows
+constexpr int FC_ROWS = 32; // output rows per block (4 waves)
 
 // partial[s][b][o] = Σ_{k in slice s} x[b][k]·w[o][k]
 __global__ __launch_bounds__(256) void fc_partial_kernel(float* __restrict__ partial, const float* __restrict__ x,
@@ -51,39 +52,46 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(float* __restrict__ par
       }
     }
   }
-  // Butterfly reduce-scatter over the wavefront: 64 per-lane partial sums (4 rows x 16 batch rows) → after
-  // 6 exchange steps lane l holds the wave total of value l. 63 shuffles instead of 64 x 6.
-  float v[FC_RW * FC_BT];
+  // Butterfly reduce-scatter over the wavefront, 4 rows (64 per-lane partial sums = 4 rows x 16 batch rows) at a time:
+  // after 6 exchange steps lane l holds the wave total of value l. 63 shuffles instead of 64 x 6.
 #pragma unroll
-  for (int r = 0; r < FC_RW; ++r)
+  for (int h = 0; h < FC_RW / 4; ++h) {
+    float v[64];
 #pragma unroll
-    for (int b = 0; b < FC_BT; ++b) v[r * FC_BT + b] = acc[r][b];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-  for (int off = 32, n = 32; off > 0; off >>= 1, n >>= 1) {
-    const bool hi = (lane & off) != 0;
+      for (int b = 0; b < FC_BT; ++b) v[r * FC_BT + b] = acc[h * 4 + r][b];
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      const float keep = hi ? v[i + n] : v[i];
-      const float send = hi ? v[i] : v[i + n];
-      v[i] = keep + __shfl_xor(send, off, 64);
+    for (int off = 32, n = 32; off > 0; off >>= 1, n >>= 1) {
+      const bool hi = (lane & off) != 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const float keep = hi ? v[i + n] : v[i];
+        const float send = hi ? v[i] : v[i + n];
+        v[i] = keep + __shfl_xor(send, off, 64);
+      }
     }
-  }
-  {
-    const int r = lane >> 4, b = lane & 15;
+    const int r = h * 4 + (lane >> 4), b = lane & 15;
     if (o0 + r < O && b < nb) partial[((long)s * B + (b0 + b)) * O + o0 + r] = v[0];
   }
 }
 
+// out[i] = lrelu(Σ_s partial[s][i] + bias): 4 outputs per wave, 16 lanes each; lane j sums slices j, j+16, ... in order,
+// then a fixed-shape butterfly adds the 16 lane sums — deterministic, and the S dependent loads no longer serialise
 __global__ __launch_bounds__(256) void fc_finalize_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                           const float* __restrict__ bias, int B, int O, int S,
                                                           float slope) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * O) return;
-  const int o = i % O;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int j = threadIdx.x & 15;
   float v = 0.f;
-  for (int s = 0; s < S; ++s) v += partial[(long)s * B * O + i];
-  v += bias ? bias[o] : 0.f;
-  out[i] = v > 0.f ? v : v * slope;
+  if (i < B * O)
+    for (int s = j; s < S; s += 16) v += partial[(long)s * B * O + i];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+  if (i < B * O && j == 0) {
+    v += bias ? bias[i % O] : 0.f;
+    out[i] = v > 0.f ? v : v * slope;
+  }
 }
 
 // one block (one wave) per sample: 7 dot products of length F, then inverse ZoomTrans
@@ -123,8 +131,8 @@ extern "C" int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, c
   if (B == 0) return 0;
   DI_REQUIRE((I & 3) == 0, "fc: input width must be a multiple of 4");
   const int rowblocks = di_div_up(O, FC_ROWS);
-  // enough K slices to fill the chip (≥ ~1024 blocks), each a multiple of 256 elements
-  int S = di_div_up(1024, rowblocks);
+  // enough K slices to fill the chip (~512 blocks of 2 waves/SIMD), each a multiple of 256 elements
+  int S = ctx->fc_slices > 0 ? ctx->fc_slices : di_div_up(512, rowblocks);   // measured best at fc6: 8 row blocks x 64 slices
   int slice = di_div_up(di_div_up(I, S), 256) * 256;
   S = di_div_up(I, slice);
   void* scratch;
@@ -135,7 +143,7 @@ extern "C" int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, c
     hipLaunchKernelGGL(fc_partial_kernel, dim3(rowblocks, S), dim3(256), 0, ctx->stream, partial, in, w, B, I, O, slice,
                        b0);
   }
-  hipLaunchKernelGGL(fc_finalize_kernel, dim3(di_div_up((long)B * O, 256)), dim3(256), 0, ctx->stream, out, partial,
+  hipLaunchKernelGGL(fc_finalize_kernel, dim3(di_div_up((long)B * O, 16)), dim3(256), 0, ctx->stream, out, partial,
                      bias, B, O, S, slope);
   DI_LAUNCH_CHECK();
   return 0;

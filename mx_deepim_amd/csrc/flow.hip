@@ -375,6 +375,14 @@ extern "C" int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow, float* 
   return 0;
 }
 
+// second half of the rectangle op, shared with the fused re-render (csrc/render.hip accumulates the bbox itself)
+int deepim_mask_box_fill(deepim_ctx* ctx, float* box, int* cur, int* nxt, int B, int H, int W) {
+  hipLaunchKernelGGL(mask_box_fill_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, box, cur, nxt,
+                     ctx->status, H, W);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float* mask, int B, int H, int W) {
   if (B == 0) return 0;
   DI_REQUIRE(B <= DI_MAX_BOX_SAMPLES, "mask_box: batch too large");
@@ -382,10 +390,7 @@ extern "C" int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float*
   int* nxt = ctx->box_words + (ctx->box_parity ? 0 : DI_MAX_BOX_SAMPLES * 4);
   ctx->box_parity ^= 1;
   hipLaunchKernelGGL(mask_bbox_kernel, dim3(di_div_up(H, 8), B), dim3(256), 0, ctx->stream, cur, mask, H, W);
-  hipLaunchKernelGGL(mask_box_fill_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, box, cur, nxt,
-                     ctx->status, H, W);
-  DI_LAUNCH_CHECK();
-  return 0;
+  return deepim_mask_box_fill(ctx, box, cur, nxt, B, H, W);
 }
 
 extern "C" int deepim_depth_to_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n) {

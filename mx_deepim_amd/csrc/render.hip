@@ -16,6 +16,7 @@
 //   resolve:  one thread per pixel: re-derives the barycentrics of the winning triangle, shades, writes the
 //             network tensors directly: image (B,3,H,W) RGB mean-subtracted, depth (B,1,H,W), 0 = background
 #include "common.h"
+#include <limits.h>
 
 namespace {
 
@@ -120,12 +121,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
                                                       const unsigned long long* __restrict__ zbuf,
                                                       const PV* __restrict__ pv_all, const int* __restrict__ faces,
                                                       const float* __restrict__ attr, const float* __restrict__ tex,
-                                                      int TH, int TW, Vec3 means, int V, int H, int W, float znear) {
+                                                      int TH, int TW, Vec3 means, int V, int H, int W, float znear,
+                                                      float* __restrict__ mask, float mask_thresh,
+                                                      int* __restrict__ box_words) {
   const int b = blockIdx.y;
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const long plane = (long)H * W;
-  if (p >= plane) return;
-  const unsigned long long key = zbuf[(long)b * plane + p];
+  const bool inside = p < plane;
+  const unsigned long long key = inside ? zbuf[(long)b * plane + p] : ~0ull;
   float rgb[3] = {0.f, 0.f, 0.f};
   float z = 0.f;
   if (key != ~0ull) {
@@ -150,21 +153,41 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
       for (int c = 0; c < 3; ++c) rgb[c] = tex_bilinear(tex, TH, TW, c, u, v);
     }
   }
+  if (inside) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) image[((long)b * 3 + c) * plane + p] = rgb[c] - means.v[c];
-  depth[(long)b * plane + p] = z;
+    for (int c = 0; c < 3; ++c) image[((long)b * 3 + c) * plane + p] = rgb[c] - means.v[c];
+    depth[(long)b * plane + p] = z;
+  }
+  if (mask != nullptr) {
+    // fused tester.py:440-442 (mask_rendered = depth > thresh) and the bbox pass of the box_rendered rectangle
+    const bool on = inside && z > mask_thresh;
+    if (inside) mask[(long)b * plane + p] = on ? 1.f : 0.f;
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    int xmin = on ? x : INT_MAX, xmax = on ? x : -1, ymin = on ? y : INT_MAX, ymax = on ? y : -1;
+    if (box_words != nullptr && __ballot(on) != 0ull) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, off, 64)); xmax = max(xmax, __shfl_xor(xmax, off, 64));
+        ymin = min(ymin, __shfl_xor(ymin, off, 64)); ymax = max(ymax, __shfl_xor(ymax, off, 64));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&box_words[b * 4 + 0], xmin); atomicMax(&box_words[b * 4 + 1], xmax);
+        atomicMin(&box_words[b * 4 + 2], ymin); atomicMax(&box_words[b * 4 + 3], ymax);
+      }
+    }
+  }
 }
 
 }  // namespace
 
-extern "C" int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth, const float* vertices,
-                                     const float* vertex_attr, const int32_t* faces, const float* texture,
-                                     int tex_h, int tex_w, const float* poses, const float* K_host,
-                                     const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
-                                     float zfar) {
+static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask, float* mask_box, float mask_thresh,
+                       const float* vertices, const float* vertex_attr, const int32_t* faces, const float* texture,
+                       int tex_h, int tex_w, const float* poses, const float* K_host, const float* pixel_means_host,
+                       int V, int F, int B, int H, int W, float znear, float zfar) {
   if (B == 0) return 0;
   DI_REQUIRE(V > 0 && F > 0 && H > 0 && W > 0, "render: empty mesh or image");
   DI_REQUIRE(znear > 0.f && zfar > znear, "render: need 0 < zNear < zFar");
+  DI_REQUIRE(mask_box == nullptr || (mask != nullptr && B <= DI_MAX_BOX_SAMPLES), "render: mask_box needs mask, B <= 4096");
   const size_t zbytes = (size_t)B * H * W * sizeof(unsigned long long);
   const size_t pbytes = (size_t)B * V * sizeof(PV);
   void* scratch;
@@ -176,12 +199,40 @@ extern "C" int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth
   for (int i = 0; i < 9; ++i) K.v[i] = K_host[i];
   Vec3 means = {{0, 0, 0}};
   if (pixel_means_host) for (int i = 0; i < 3; ++i) means.v[i] = pixel_means_host[i];
+  int *cur = nullptr, *nxt = nullptr;
+  if (mask_box) {
+    cur = ctx->box_words + (ctx->box_parity ? DI_MAX_BOX_SAMPLES * 4 : 0);
+    nxt = ctx->box_words + (ctx->box_parity ? 0 : DI_MAX_BOX_SAMPLES * 4);
+    ctx->box_parity ^= 1;
+  }
   DI_CHECK(hipMemsetAsync(zbuf, 0xff, zbytes, ctx->stream));
   hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V);
   hipLaunchKernelGGL(raster_kernel, dim3(di_div_up(F, 256), B), dim3(256), 0, ctx->stream, zbuf, pv, (const int*)faces, V,
                      F, H, W, znear, zfar);
   hipLaunchKernelGGL(resolve_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, image, depth, zbuf,
-                     pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear);
+                     pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear, mask, mask_thresh,
+                     cur);
   DI_LAUNCH_CHECK();
+  if (mask_box) return deepim_mask_box_fill(ctx, mask_box, cur, nxt, B, H, W);
   return 0;
+}
+
+extern "C" int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth, const float* vertices,
+                                     const float* vertex_attr, const int32_t* faces, const float* texture,
+                                     int tex_h, int tex_w, const float* poses, const float* K_host,
+                                     const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
+                                     float zfar) {
+  return render_impl(ctx, image, depth, nullptr, nullptr, 0.f, vertices, vertex_attr, faces, texture, tex_h, tex_w, poses,
+                     K_host, pixel_means_host, V, F, B, H, W, znear, zfar);
+}
+
+extern "C" int deepim_render_update_forward(deepim_ctx* ctx, float* image, float* depth, float* mask_rendered,
+                                            float* mask_box, float mask_thresh, const float* vertices,
+                                            const float* vertex_attr, const int32_t* faces, const float* texture,
+                                            int tex_h, int tex_w, const float* poses, const float* K_host,
+                                            const float* pixel_means_host, int V, int F, int B, int H, int W,
+                                            float znear, float zfar) {
+  DI_REQUIRE(mask_rendered != nullptr, "render_update: mask_rendered is NULL");
+  return render_impl(ctx, image, depth, mask_rendered, mask_box, mask_thresh, vertices, vertex_attr, faces, texture, tex_h,
+                     tex_w, poses, K_host, pixel_means_host, V, F, B, H, W, znear, zfar);
 }

@@ -34,6 +34,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->conv_direct = 1;
   c->conv_tail_slots = 1024;
   c->conv_force_plan = 0;
+  c->fc_slices = 0;
   c->conv_tail_split = 0;
   c->conv_tile256 = 0;   // measured: 113.1 vs 113.7 TF for 128x128 — kept as an option, off by default
   c->conv_split_below = 512;
@@ -145,6 +146,7 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv_split_below") == 0) { ctx->conv_split_below = value; return 0; }
   if (strcmp(name, "conv_split_target") == 0) { ctx->conv_split_target = value > 0 ? value : 1; return 0; }
   if (strcmp(name, "conv_direct") == 0) { ctx->conv_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+  if (strcmp(name, "fc_slices") == 0) { ctx->fc_slices = value > 0 ? value : 0; return 0; }
   if (strcmp(name, "conv_tail_split") == 0) { ctx->conv_tail_split = value ? 1 : 0; return 0; }
   if (strcmp(name, "conv_force_plan") == 0) { ctx->conv_force_plan = value; return 0; }
   if (strcmp(name, "conv_tail_slots") == 0) { DI_REQUIRE(value >= 8 && value % 8 == 0, "conv_tail_slots must be a positive multiple of 8"); ctx->conv_tail_slots = value; return 0; }

@@ -93,31 +93,34 @@ def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None,
     image = out.get("image_rendered") or ctx.empty((B, 3, H, W))
     depth = out.get("depth_rendered") or ctx.empty((B, 1, H, W))
     new = dict(data)
-    if class_index is None or np.ndim(class_index) == 0:
-        render_machine.render_into(image, depth, 0 if class_index is None else int(class_index), refined_pose)
-    else:
-        ids = np.asarray(class_index).astype(np.int64).reshape(B)
-        b0 = 0
-        while b0 < B:
-            b1 = b0 + 1
-            while b1 < B and ids[b1] == ids[b0]:
-                b1 += 1
-            render_machine.render_into(image[b0:b1], depth[b0:b1], ids[b0], refined_pose[b0:b1])
-            b0 = b1
-    new["image_rendered"], new["src_pose"] = image, refined_pose
-    if cfg.network.INPUT_DEPTH:
-        new["depth_rendered"] = depth
+    mask = box = None
     if cfg.network.INPUT_MASK:
         mask = out.get("mask_rendered") or ctx.empty((B, 1, H, W))
-        lib.deepim_depth_to_mask(ctx.handle, mask, depth, ctypes.c_float(0.2), B * H * W)
-        new["mask_rendered"] = mask
         if cfg.network.PRED_MASK:
             if cfg.TEST.UPDATE_MASK == "box_rendered":
                 # tester.py:445-449 hands the old mask_rendered over, but update_data_batch (data_pair.py:94-105) ignores
                 # it for this mode and draws the rectangle of the NEW rendered mask
                 box = out.get("mask_observed") or ctx.empty((B, 1, H, W))
-                lib.deepim_mask_box_forward(ctx.handle, box, mask, B, H, W)
-                new["mask_observed"] = box
             elif cfg.TEST.UPDATE_MASK != "init":
                 raise Exception("Unknown UPDATE_MASK type: {}".format(cfg.TEST.UPDATE_MASK))
+    # one fused pass per run of equal class ids: draw, mask_rendered = depth > 0.2, rectangle
+    ids = np.zeros(B, np.int64) if class_index is None else np.broadcast_to(
+        np.asarray(class_index).astype(np.int64).reshape(-1), (B,)) if np.size(class_index) == 1 else \
+        np.asarray(class_index).astype(np.int64).reshape(B)
+    b0 = 0
+    while b0 < B:
+        b1 = b0 + 1
+        while b1 < B and ids[b1] == ids[b0]:
+            b1 += 1
+        render_machine.render_into(image[b0:b1], depth[b0:b1], ids[b0], refined_pose[b0:b1],
+                                   mask_rendered=None if mask is None else mask[b0:b1],
+                                   mask_box=None if box is None else box[b0:b1], mask_thresh=0.2)
+        b0 = b1
+    new["image_rendered"], new["src_pose"] = image, refined_pose
+    if cfg.network.INPUT_DEPTH:
+        new["depth_rendered"] = depth
+    if mask is not None:
+        new["mask_rendered"] = mask
+    if box is not None:
+        new["mask_observed"] = box
     return new

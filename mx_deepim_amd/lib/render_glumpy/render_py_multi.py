@@ -113,15 +113,23 @@ class Render_Py(object):
                                         texture=load_texture(os.path.join(folder, "texture_map.png"))))
 
     # -- device API ----------------------------------------------------------------------------------------------
-    def render_into(self, image, depth, cls_idx, poses, K=None, pixel_means="default"):
-        """image (n,3,H,W), depth (n,1,H,W), poses (n,3,4): all device arrays; one mesh."""
+    def render_into(self, image, depth, cls_idx, poses, K=None, pixel_means="default", mask_rendered=None, mask_box=None,
+                    mask_thresh=0.2):
+        """image (n,3,H,W), depth (n,1,H,W), poses (n,3,4): all device arrays; one mesh. With `mask_rendered` (n,1,H,W)
+        the same pass also writes depth > mask_thresh, and with `mask_box` its box_rendered rectangle."""
         m = self.mesh_list[int(cls_idx)]
         K = self.K if K is None else np.ascontiguousarray(K, dtype=np.float32).reshape(3, 3)
         means = self.pixel_means if isinstance(pixel_means, str) else pixel_means
         n = poses.shape[0]
-        lib.deepim_render_forward(self.ctx.handle, image, depth, m.vertices, m.attr, m.faces, m.texture, m.tex_h, m.tex_w,
-                                  poses, K, means, m.V, m.F, n, self.height, self.width, ctypes.c_float(self.zNear),
-                                  ctypes.c_float(self.zFar))
+        tail = (m.vertices, m.attr, m.faces, m.texture, m.tex_h, m.tex_w, poses, K, means, m.V, m.F, n, self.height,
+                self.width, ctypes.c_float(self.zNear), ctypes.c_float(self.zFar))
+        if mask_rendered is None:
+            if mask_box is not None:
+                raise ValueError("mask_box needs mask_rendered")
+            lib.deepim_render_forward(self.ctx.handle, image, depth, *tail)
+        else:
+            lib.deepim_render_update_forward(self.ctx.handle, image, depth, mask_rendered, mask_box,
+                                             ctypes.c_float(mask_thresh), *tail)
 
     def render_batch(self, class_index, poses, K=None):
         """poses (B,3,4) device; class_index: scalar, host sequence of B class ids, or None (= class 0).
