@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* 
   const long opix = (long)h * W + w0;
   const int sy0 = (int)floorf((float)H / 2 - 5), sy1 = (int)ceilf((float)H / 2 + 5);
   const int sx0 = (int)floorf((float)W / 2 - 5), sx1 = (int)ceilf((float)W / 2 + 5);
+  // VALU-bound, not HBM-bound: the reference's float/double blend costs ~13 fp64-rate ops per output (≈60 of the
+  // 90 µs at B = 16); two channels in flight hide the tap-load latency behind it
+#pragma unroll 2
   for (int c = 0; c < plan.n; ++c) {
     const Chan& ch = plan.ch[c];
     const float* s = ch.src + (long)b * ch.src_bstride + row0;
