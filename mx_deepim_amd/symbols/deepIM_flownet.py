@@ -124,23 +124,16 @@ class deepIM_flownet(object):
             w[i] = (1 - abs(x / f - c)) * (1 - abs(y / f - c))
         return w.reshape(shape)
 
-    def init_weights(self, cfg=None, arg_params=None, aux_params=None, seed=2333):
+    def init_weights(self, cfg=None, arg_params=None, aux_params=None, seed=2333, names=None):
         """Seeded synthetic parameters (no checkpoints offline): He-normal conv/FC so activations stay
         O(1) through the 10 layers, rot/trans as the reference initialises them
         (deepIM_flownet.py:795-803), bilinear upsampling kernels (:808-822)."""
         rng = np.random.default_rng(seed)
         arg_params = {} if arg_params is None else arg_params
         shapes = self.arg_shape_dict()
-        w1 = arg_params.get("flow_conv1_weight")
-        if w1 is not None and w1.shape[1] < shapes["flow_conv1_weight"][1]:
-            # an RGB-pair (6-channel FlowNet) checkpoint under a graph with depth / mask inputs: the extra input
-            # channels start from zero weights (deepIM_flownet.py:759-773)
-            w1 = np.asarray(w1.asnumpy() if hasattr(w1, "asnumpy") else w1, dtype=np.float32)
-            extra = shapes["flow_conv1_weight"][1] - w1.shape[1]
-            arg_params["flow_conv1_weight"] = np.concatenate(
-                [w1, np.zeros((w1.shape[0], extra) + w1.shape[2:], np.float32)], axis=1)
+        self.adapt_checkpoint(arg_params, shapes)
         for name, shape in shapes.items():
-            if name in arg_params:
+            if name in arg_params or (names is not None and name not in names):   # `names`: only these (tests)
                 continue
             if name.endswith("upsampling_weight"):
                 arg_params[name] = self._init_bilinear(shape)
@@ -158,6 +151,18 @@ class deepIM_flownet(object):
                     fan_in = shape[0] * 4  # 2x2 taps reach each output of a k4 s2 transposed conv
                 gain = 2.0 / (1 + SLOPE ** 2)
                 arg_params[name] = (rng.standard_normal(shape) * np.sqrt(gain / fan_in)).astype(np.float32)
+        return arg_params
+
+    @staticmethod
+    def adapt_checkpoint(arg_params, shapes):
+        """An RGB-pair (6-channel FlowNet) checkpoint under a graph with depth / mask inputs: the extra input channels of
+        `flow_conv1_weight` start from zero weights (deepIM_flownet.py:759-773). In place; returns arg_params."""
+        w1 = arg_params.get("flow_conv1_weight")
+        if w1 is not None and w1.shape[1] < shapes["flow_conv1_weight"][1]:
+            w1 = np.asarray(w1.asnumpy() if hasattr(w1, "asnumpy") else w1, dtype=np.float32)
+            extra = shapes["flow_conv1_weight"][1] - w1.shape[1]
+            arg_params["flow_conv1_weight"] = np.concatenate(
+                [w1, np.zeros((w1.shape[0], extra) + w1.shape[2:], np.float32)], axis=1)
         return arg_params
 
     # ------------------------------------------------------------------ bind

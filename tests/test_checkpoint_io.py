@@ -77,23 +77,26 @@ def test_load_param_mirror_and_flownet_import(tmp_path):
     from mx_deepim_amd.symbols import deepIM_flownet
     cfg = default_config()
     net = deepIM_flownet().get_symbol(cfg)
-    full = net.init_weights(cfg, seed=1)
+    shapes = net.arg_shape_dict()
+    rng = np.random.default_rng(1)
     # a 6-channel FlowNet-style checkpoint with the suffixes older files carry
-    ckpt = {k: v for k, v in full.items() if k.startswith(("flow_conv1", "conv2", "conv3"))}
-    ckpt["flow_conv1_weight"] = ckpt["flow_conv1_weight"][:, :6].copy()
-    ckpt["fc6_weight_test"] = full["fc6_weight"]
+    ckpt = {k: rng.standard_normal(shapes[k]).astype(np.float32)
+            for k in ("flow_conv1_bias", "conv2_weight", "conv2_bias", "conv3_bias")}
+    c1 = shapes["flow_conv1_weight"]
+    ckpt["flow_conv1_weight"] = rng.standard_normal((c1[0], 6) + tuple(c1[2:])).astype(np.float32)
+    ckpt["fc7_weight_test"] = rng.standard_normal(shapes["fc7_weight"]).astype(np.float32)
     prefix = str(tmp_path / "flownet")
     save_checkpoint(prefix, 7, ckpt, {"dummy_moving_mean": np.zeros(2, np.float32)})
     arg, aux = load_checkpoint(prefix, 7)
     assert set(arg) == set(ckpt) and list(aux) == ["dummy_moving_mean"]
     arg, aux = load_param(prefix, 7, process=True)
-    assert "fc6_weight" in arg and "fc6_weight_test" not in arg
-    merged = net.init_weights(cfg, arg_params=arg, seed=3)
-    assert merged["flow_conv1_weight"].shape == full["flow_conv1_weight"].shape
-    np.testing.assert_array_equal(merged["flow_conv1_weight"][:, :6], full["flow_conv1_weight"][:, :6])
+    assert "fc7_weight" in arg and "fc7_weight_test" not in arg
+    merged = deepIM_flownet.adapt_checkpoint(dict(arg), shapes)     # what init_weights applies before filling the rest
+    assert merged["flow_conv1_weight"].shape == tuple(c1)
+    np.testing.assert_array_equal(merged["flow_conv1_weight"][:, :6], ckpt["flow_conv1_weight"])
     assert not merged["flow_conv1_weight"][:, 6:].any()
-    np.testing.assert_array_equal(merged["conv3_weight"], full["conv3_weight"])
-    np.testing.assert_array_equal(merged["fc6_weight"], full["fc6_weight"])
-    assert set(merged) == set(full)
+    np.testing.assert_array_equal(merged["conv2_weight"], ckpt["conv2_weight"])
+    np.testing.assert_array_equal(merged["fc7_weight"], ckpt["fc7_weight_test"])
+    assert set(merged) <= set(shapes) and all(tuple(merged[k].shape) == tuple(shapes[k]) for k in merged)
     with pytest.raises((IOError, OSError)):
         load_checkpoint(prefix, 8)

@@ -60,7 +60,7 @@ def test_symbol_graph_flags_follow_config():
     cfg.network.REGRESSOR_NUM = 2
     with pytest.raises(Exception):
         deepIM_flownet().get_symbol(cfg)
-    w = deepIM_flownet().get_symbol(default_config()).init_weights(seed=1)
+    w = deepIM_flownet().get_symbol(default_config()).init_weights(seed=1, names=("rot_weight", "trans_weight"))
     assert w["rot_weight"][0].min() >= 0.01 and abs(w["rot_weight"][1:]).max() <= 0.01   # deepIM_flownet.py:795-800
 
 
