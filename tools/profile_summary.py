@@ -45,7 +45,7 @@ def cmd_stats(a):
         if is_conv(n):
             conv_ns += d
     total = sum(t for _, t in agg.values())
-    out = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps %d --warmup 2" % (a.iters // 4),
+    out = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps %d --warmup 2 --batch %d" % (a.iters // 4, a.batch),
            "# (B=%d/GPU, 4 iters, 480x640, 1x MI355X). Two views:" % a.batch,
            "# (1) timed region only = the last %d pose-refinement iterations of the kernel trace (the full-run --stats table below also" % a.iters,
            "#     contains the priming pass, where each conv geometry is launched ~30x by the split-K autotuner);",
@@ -80,7 +80,7 @@ def cmd_traffic(a):
         return g
     f, w = load(a.fetch), load(a.write)
     lines = ["# HBM traffic of the hot path from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
-             "cmd: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1` "
+             "cmd: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1 --batch %d` " % a.batch +
              "(and the same with WRITE_SIZE); the last %d pose-refinement iterations of %d pairs each (warm-up + timed step; the "
              "priming pass with its autotuning launches is cut off at the pose-update kernel). Counter unit = KB (x1024 B)." % (a.iters, a.batch), "",
              "FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-B requests at "
@@ -97,9 +97,12 @@ def cmd_traffic(a):
     if a.note:
         lines.append(a.note)
     open(a.md, "w").write("\n".join(lines) + "\n")
-    json.dump({"conv_launch_group_bytes_corrected": (2 * fr + wr) * 1e6, "conv_launch_group_bytes_raw": (fr + wr) * 1e6,
-               "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=%d, FETCH doubled per MI355X_MICROARCH.md)" % (a.md, a.batch)},
-              open(a.json, "w"), indent=1)
+    import os
+    allj = json.load(open(a.json)) if os.path.exists(a.json) else {}
+    allj = {k: v for k, v in allj.items() if k.startswith("B")}          # one entry per per-GPU batch size
+    allj["B%d" % a.batch] = {"conv_launch_group_bytes_corrected": (2 * fr + wr) * 1e6, "conv_launch_group_bytes_raw": (fr + wr) * 1e6,
+                             "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=%d, FETCH doubled per MI355X_MICROARCH.md)" % (a.md, a.batch)}
+    json.dump(allj, open(a.json, "w"), indent=1)
     print("\n".join(lines))
 
 
