@@ -216,7 +216,7 @@ def main():
             if tj:
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         out = {
-            "metric": "pose-refinement iters/sec (4-iter loop, 480x640)",
+            "metric": "pose-refinement iters/sec (%d-iter loop, 480x640, bs%d)" % (NIT, B),
             "value": iters_total / dt,
             "unit": "pose-refinement iters/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
