@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
     // (inline asm: after an `asm volatile` hipcc no longer proves the table unclobbered and would fall back to
     // vector loads + waterfall loops)
     const int g0 = kc_begin * DK;
+    const int hc_last = p.nchunk * 2 - 1;
     i32x16 tq, tn;
     {
       const int2* t0 = p.tab2 + g0;
@@ -516,11 +517,13 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
         __builtin_amdgcn_sched_barrier(0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 1), rb[sl][0], acc[1][0], 0, 0, 0);
         asm volatile("" : "+v"(acc[1][0]));
-        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 0, (g + u) / 4 + 1)   // next half's weights, 4 k-steps ahead
+        // next half's weights, 4 k-steps ahead; clamped: the soffset of a raw buffer load is not range-checked, and the
+        // half after the last one of the last M tile would lie past the packed buffer
+        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 0, min((g + u) / 4 + 1, hc_last))
         __builtin_amdgcn_sched_barrier(0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ASEL(u, 1), rb[sl][1], acc[1][1], 0, 0, 0);
         asm volatile("" : "+v"(acc[1][1]));
-        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 1, (g + u) / 4 + 1)
+        if ((u & 3) == 0) DLOADA(((u >> 2) + 1) & 1, 1, min((g + u) / 4 + 1, hc_last))
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tn));
