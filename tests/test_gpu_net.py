@@ -106,6 +106,38 @@ def test_conv_direct_kernel_bit_exact(ctx, case):
     np.testing.assert_array_equal(got3, ref)
 
 
+def test_conv_direct_kernel_random_geometries(ctx):
+    """Random small geometries (odd sizes, all strides/pads/kernel sizes the net uses, ragged tiles, Cout off the tile
+    grid, split-K on and off): LDS-free kernel == pair-order oracle bit-for-bit, LDS kernel == canonical oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(16):
+        k = int(rng.choice([1, 3, 5, 7]))
+        s_ = int(rng.choice([1, 2]))
+        p_ = int(rng.integers(0, k // 2 + 1))
+        cin = 2 * int(rng.integers(1, 20))
+        cout = int(rng.choice([65, 96, 128, 130, 200, 256]))
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(k, 40)), int(rng.integers(k, 50))
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        case = (B, cin, H, W, cout, k, s_, p_)
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+        lib.deepim_set_option(ctx.handle, b"conv_direct", 2)
+        try:
+            got_d = _run_conv(ctx, x, w, b, s_, p_, 0.1)
+            lib.deepim_set_option(ctx.handle, b"conv_direct", 0)
+            got_l = _run_conv(ctx, x, w, b, s_, p_, 0.1)
+        finally:
+            lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+            lib.deepim_set_option(ctx.handle, b"conv_direct", 1)
+        np.testing.assert_array_equal(got_d, onet.conv2d(x, w, b, s_, p_, 0.1, pair_order=True), err_msg=str(case))
+        ref = onet.conv2d(x, w, b, s_, p_, 0.1)
+        np.testing.assert_array_equal(got_l, ref, err_msg=str(case))
+        got = _run_conv(ctx, x, w, b, s_, p_, 0.1)             # default policy
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), case
+
+
 def test_conv_tail_split_plan(ctx):
     """Opt-in tail split of the LDS-free kernel: 1030 tiles with a round size of 256 → 1024 full tiles + 6 tiles cut
     into K slices and summed by tail_reduce_kernel in slice order. Same sums re-associated: ≤1e-5 of the oracle."""
