@@ -68,6 +68,36 @@ def cpu_baseline(params, cfg, batch, budget_s=12.0):
                       "numpy + C/OpenMP oracle, OMP threads = all cores" % (pairs, dt)}
 
 
+def cpu_onednn_secondary(cfg, seconds=8.0, pairs=4):
+    """Secondary, labelled CPU figure: the encoder conv stack + fc6/fc7 through torch-CPU, i.e. oneDNN — the
+    library MXNet-MKL would use for the same layers. Network forward only (no zoom, no pose update), random weights."""
+    import torch
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    cin, layers = 8 if cfg.network.INPUT_MASK else 6, []
+    for name, cout, k, s_, p_ in ENCODER:
+        layers.append((torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5, torch.zeros(cout), s_, p_))
+        cin = cout
+    w6, w7 = torch.randn(256, 1024 * 8 * 10) / 300, torch.randn(256, 256) / 16
+    x = torch.randn(pairs, 8 if cfg.network.INPUT_MASK else 6, 480, 640)
+
+    def fwd():
+        with torch.no_grad():
+            y = x
+            for w, b, s_, p_ in layers:
+                y = F.leaky_relu(F.conv2d(y, w, b, stride=s_, padding=p_), 0.1)
+            y = F.leaky_relu(F.linear(y.flatten(1), w6), 0.1)
+            return F.leaky_relu(F.linear(y, w7), 0.1)
+    fwd()
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        fwd()
+        n += pairs
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "network forwards/sec", "cores": os.cpu_count(), "threads": torch.get_num_threads(),
+            "kind": "secondary: torch-CPU (oneDNN) conv stack + fc6/fc7 only, batch %d, %d forwards in %.1f s" % (pairs, n, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +109,8 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5 mode: conv stack on the fp16 matrix cores "
                     "(NOT the headline: reduced precision; reported with dtype f16)")
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
+    ap.add_argument("--cpu-onednn", action="store_true", help="also time the network forward through torch-CPU (oneDNN) "
+                    "as a labelled secondary CPU figure (imports torch: slow first import on a fresh box)")
     ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     args = ap.parse_args()
@@ -245,6 +277,8 @@ def main():
             out["layers"] = layer_timings(ctx, net)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, batch)
+            if args.cpu_onednn:
+                out["cpu_baseline"]["secondary_onednn"] = cpu_onednn_secondary(cfg)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
