@@ -406,8 +406,12 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
     vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
     split = vid / (p.gx * p.gy);
   }
-  const int bx = vid % p.gx;
-  const int mb = (vid / p.gx) % p.gy;
+#ifndef DIRECT_MFAST
+#define DIRECT_MFAST 0
+#endif
+  const int tvid = vid % (p.gx * p.gy);
+  const int bx = DIRECT_MFAST ? tvid / p.gy : tvid % p.gx;
+  const int mb = DIRECT_MFAST ? tvid % p.gy : tvid / p.gx;
   const long n0 = (long)bx * BN;
   const int lrow = lane >> 5, lcol = lane & 31;
   const long npix = p.npix;
@@ -468,13 +472,18 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 // The tap bit index goes from the scalar cache straight into the VALU shift: a VALU op that reads an SGPR produced by
 // an SALU op (s_and / s_bitcmp+s_cselect) inside the MFMA shadow stalls the SIMD's issue (tools/mfma_issue_probe.hip:
 // 155 → 115-120 TF), SGPRs written by s_load do not.
+#ifndef DIRECT_ABL
+#define DIRECT_ABL 0   // dev ablations (wrong results): 1 = B loads from one L1-resident line, 2 = A loads likewise, 4 = no tap decode
+#endif
 #define DLOADB(slot, j, ent)                                                                            \
   {                                                                                                     \
-    const unsigned inv = (unsigned)(ninv[j] >> (ent).y);                                                \
-    rb[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((inv << 31) | (unsigned)voff[j]), (ent).x, 0)); \
+    const unsigned inv = (DIRECT_ABL & 4) ? 0u : (unsigned)(ninv[j] >> ((DIRECT_ABL & 8) ? p.pad * 9 : (ent).y)); \
+    const int vo_ = (DIRECT_ABL & 1) ? lane * 4 + p.pad_bytes : (int)((inv << 31) | (unsigned)voff[j]); \
+    /* 8: real per-lane pattern (line straddling, stride) but one fixed tap, so the lines stay L1-resident */ \
+    rb[slot][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_, (DIRECT_ABL & 9) ? ((DIRECT_ABL & 8) ? p.pad_bytes : 0) : (ent).x, 0)); \
   }
 #define DLOADA(buf, i, hc) \
-  aq[buf][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, wvo[i], (hc) * 1024, 0));
+  aq[buf][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, (DIRECT_ABL & 2) ? lane * 16 : wvo[i], (DIRECT_ABL & 2) ? 0 : (hc) * 1024, 0));
 #define ASEL(u, i) (((u) & 3) == 0 ? aq[((u) >> 2) & 1][i].x : ((u) & 3) == 1 ? aq[((u) >> 2) & 1][i].y : \
                     ((u) & 3) == 2 ? aq[((u) >> 2) & 1][i].z : aq[((u) >> 2) & 1][i].w)
 
