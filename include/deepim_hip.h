@@ -186,6 +186,15 @@ int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const fl
                           const float* bias, int B, int Cin, int H, int W, int Cout,
                           int kh, int kw, int stride, int pad, float slope,
                           int out_ctotal, int out_coff);
+/* Same convolution with channel-blocked ("NC8") activations between layers: a tensor (B,C,H,W) stored as
+ * [n][C/8][h][w][8] (C % 8 == 0). in_nc8 / out_nc8 select the layout of `in` / `out` (0 = NCHW). NC8 input runs on the
+ * LDS-free kernel whose fmaf chain per output runs over (c/8, ky, kx, s, h) with channel 8(c/8) + s + 4h — one 16-byte
+ * load per lane feeds four MFMA k-steps; it needs Cout > 64. The encoder uses NCHW -> NC8 for conv1, NC8 -> NC8 up to
+ * conv6, NC8 -> NCHW for conv6_1 (fc6 wants MXNet's flatten order). deepim_relayout_nc8 converts a tensor either way. */
+int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                             const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                             int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8, int out_nc8);
+int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, int C, size_t hw, int to_nc8);
 /* fp16 conv path (BASELINE config 5): NHWC fp16 activations, fp16 weights (packed once), fp16 matrix cores
  * with fp32 accumulation, bias + LeakyReLU in fp32, NHWC fp16 output. Same layer semantics as
  * deepim_conv2d_forward (deepIM_flownet.py:63-107); tolerance documented in DESIGN.md (fp16 cannot meet 1e-4).

@@ -32,6 +32,7 @@ constexpr int KT = 16;        // K chunk
 constexpr int GRAN = 64;      // weight packing granule (rows)
 constexpr int MODE_CONV = 0;
 constexpr int MODE_DECONV = 1;  // k4 s2 p0 transposed conv, one launch z-slice per output parity
+constexpr int MODE_NC8_TAB = 4;     // tap table of the NC8 kernel (one entry per (c8, tap) group)
 constexpr int MODE_DIRECT_TAB = 3;  // tap-table flavour of the LDS-free kernel (conv_tabs key only; 2 is taken by conv_f16.hip)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -89,6 +90,10 @@ struct ConvParams {
   // would form the under-filled last round is cut into tail_s K slices (tile-local partials → tail_reduce_kernel)
   int n_full, tail_s, tail_cps, n_tail_pad;
   float* tail_partial;      // [tail_s][R][128 co][128 px]
+  // channel-blocked activations ("NC8": [n][C/8][h][w][8]) between the encoder layers
+  int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW)
+  const float* wd8;         // weights for NC8 inputs [Cout/32][group = (c8,ky,kx)][lane][4]
+  const int2* tab8;         // per group: {byte offset (c8*H*W + ky*W + kx)*32, bit ky*8+kx}
 };
 
 template <int BM, int BN, int MODE, int NT = 256>
@@ -352,6 +357,40 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
 }
 
 
+
+// Epilogue for channel-blocked output [n][Cout/8][ho][wo][8]: the 16 accumulator registers of a lane are 4 groups of 4
+// consecutive channels (rows 8g + 4*lrow + 0..3 of the 32-row MFMA tile) of ONE pixel → four 16-byte stores per tile
+// instead of sixteen scattered dwords. Cout must be a multiple of 8.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_nc8(f32x16 (&acc)[TM][TN], float* __restrict__ outp, const ConvParams& p,
+                                               bool partial, int co0, long pix0, int lrow, int lcol) {
+  const int hw = p.Ho * p.Wo, c8n = p.Cout >> 3;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = pix0 + j * 32 + lcol;
+    if (op >= p.npix) continue;
+    const int n = (int)(op / hw);
+    const int r0 = (int)(op - (long)n * hw);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = ((co0 + i * 32) >> 3) + g;
+        if (cb >= c8n) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (!partial) {
+          const int c = cb * 8 + 4 * lrow;
+          const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0, 0, 0, 0);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+          v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+        }
+        *reinterpret_cast<float4*>(outp + (((long)n * c8n + cb) * hw + r0) * 8 + 4 * lrow) = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-free variant for the encoder convolutions (MODE_CONV, even Cin): every wave feeds its MFMAs straight from
 // registers loaded with coalesced buffer loads — no LDS staging, no block barrier, four fully independent waves per
@@ -559,10 +598,183 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
   float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
   const int ctotal = partial ? p.Cout : p.out_ctotal;
   const int coff = partial ? 0 : p.out_coff;
+  if (p.out_nc8) {
+    store_tile_nc8<TM, TN>(acc, outp, p, partial, mb * BM + wm0, n0 + wn0, lrow, lcol);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long op = n0 + wn0 + j * 32 + lcol;
     if (op >= npix) continue;
+    const int hw = p.Ho * p.Wo;
+    const int n = (int)(op / hw);
+    const int r0 = (int)(op - (long)n * hw);
+    const long obase = ((long)n * ctotal + coff) * hw + r0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * BM + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (co < p.Cout) {
+          float v = acc[i][j][r];
+          if (!partial) {
+            v = v + (p.bias ? p.bias[co] : 0.f);
+            v = v > 0.f ? v : v * p.slope;
+          }
+          outp[obase + (long)co * hw] = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same LDS-free design on channel-blocked ("NC8") activations [n][C/8][h][w][8] — the layout the encoder layers
+// hand to each other (conv1 writes it, conv6_1 returns to NCHW for fc6). K runs (c8, ky, kx, s, h) with channel
+// c8*8 + s + 4h: the four k-steps s of one (c8, tap) group pair channels (s, s+4), so lanes 0-31 read channels 0-3 and
+// lanes 32-63 channels 4-7 of the 32-byte pixel record — ONE dwordx4 per lane feeds four k-steps, and a wave reads
+// 1 KB (stride 1) of fully used, contiguous bytes per load. 4 loads (2 activation, 2 weight, all b128) per 16 MFMAs
+// instead of 10; operands of 4 groups in flight (ring of 4, loads issued 3 groups = 48 MFMAs ahead).
+template <int OUT_NC8>
+__global__ __launch_bounds__(256, 3) void conv_nc8_kernel(ConvParams p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NG = 4;   // NG: groups per loop body = ring size
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  int vid;
+  {
+    const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+    vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
+  }
+  const int bx = vid % p.gx;
+  const int mb = (vid / p.gx) % p.gy;
+  const int split = vid / (p.gx * p.gy);
+  const long n0 = (long)bx * BN;
+  const int lrow = lane >> 5, lcol = lane & 31;
+  const int pad8 = p.pad_bytes * 8;   // descriptor base shift in bytes of the blocked layout
+
+  int voff[TN];
+  unsigned long long ninv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long pix = n0 + wn0 + j * 32 + lcol;
+    unsigned long long m64 = 0;
+    voff[j] = 0;
+    if (pix < p.npix) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int r = (int)(pix - (long)n * hw);
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      voff[j] = (n * (p.Cin >> 3) * p.H * p.W + hi0 * p.W + wi0) * 32 + lrow * 16 + pad8;
+      unsigned mky = 0, mkx = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
+        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+    }
+    ninv[j] = ~m64;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.in - pad8), 0, (int)(p.in_bytes + (unsigned)pad8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd8, 0, (int)p.wd_bytes, 0x00020000);
+  const int ngroup = p.nchunk * 2;
+  int wvo[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * 4 + (wm0 >> 5) + i) * ngroup) * 64 + lane) * 16;
+
+  // chunks_per_split is even on this path, so a block always owns whole bodies of NG = 4 groups
+  const int g_begin = __builtin_amdgcn_readfirstlane(split * p.chunks_per_split * 2);
+  const int g_end = __builtin_amdgcn_readfirstlane(min(p.nchunk, (split + 1) * p.chunks_per_split) * 2);
+  const int g_last = ngroup - 1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 bq[NG][TN], aq[NG][TM];
+#define NLOADB(slot, j, off, bit)                                                                        \
+  {                                                                                                      \
+    const unsigned inv = (unsigned)(ninv[j] >> (bit));                                                   \
+    bq[slot][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((inv << 31) | (unsigned)voff[j]), (off), 0)); \
+  }
+#define NLOADA(slot, i, g) \
+  aq[slot][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, wvo[i], min((g), g_last) * 1024, 0));
+#define QSEL(v, s) ((s) == 0 ? (v).x : (s) == 1 ? (v).y : (s) == 2 ? (v).z : (v).w)
+
+  if (g_begin < g_end) {
+    // tap-table entries of 8 groups (16 dwords) per scalar load: [0..5] feed this body's loads (groups +3..+5 are the next
+    // body's first three), fetched one body ahead
+    i32x16 tq, tn;
+    {
+      const int2* t0 = p.tab8 + g_begin;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tn) : "s"(t0));
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        NLOADB(u, 0, tn[2 * u], tn[2 * u + 1]) NLOADB(u, 1, tn[2 * u], tn[2 * u + 1])
+        NLOADA(u, 0, g_begin + u) NLOADA(u, 1, g_begin + u)
+      }
+      const int2* t1 = p.tab8 + g_begin + 3;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tq) : "s"(t1));
+    }
+    for (int g = g_begin; g < g_end; g += NG) {
+      const int2* t2 = p.tab8 + g + NG + 3;   // table is padded past the end
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(tn) : "s"(t2));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const int ld = (q + 3) % NG;     // slot of the group loaded while group q is multiplied
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][0], s_), QSEL(bq[q][0], s_), acc[0][0], 0, 0, 0);
+          asm volatile("" : "+v"(acc[0][0]));
+          if (s_ == 1) NLOADB(ld, 0, tq[2 * q], tq[2 * q + 1])
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][0], s_), QSEL(bq[q][1], s_), acc[0][1], 0, 0, 0);
+          asm volatile("" : "+v"(acc[0][1]));
+          if (s_ == 1) NLOADB(ld, 1, tq[2 * q], tq[2 * q + 1])
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][1], s_), QSEL(bq[q][0], s_), acc[1][0], 0, 0, 0);
+          asm volatile("" : "+v"(acc[1][0]));
+          if (s_ == 1) NLOADA(ld, 0, g + q + 3)
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][1], s_), QSEL(bq[q][1], s_), acc[1][1], 0, 0, 0);
+          asm volatile("" : "+v"(acc[1][1]));
+          if (s_ == 1) NLOADA(ld, 1, g + q + 3)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tn));
+      tq = tn;
+    }
+  }
+#undef NLOADB
+#undef NLOADA
+#undef QSEL
+
+  const bool partial = p.ksplit > 1;
+  float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
+  if (OUT_NC8) {
+    store_tile_nc8<TM, TN>(acc, outp, p, partial, mb * BM + wm0, n0 + wn0, lrow, lcol);
+    return;
+  }
+  const int ctotal = partial ? p.Cout : p.out_ctotal;
+  const int coff = partial ? 0 : p.out_coff;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = n0 + wn0 + j * 32 + lcol;
+    if (op >= p.npix) continue;
     const int hw = p.Ho * p.Wo;
     const int n = (int)(op / hw);
     const int r0 = (int)(op - (long)n * hw);
@@ -624,6 +836,41 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ ou
   }
 }
 
+// split-K second pass for channel-blocked outputs: partials and output share the [n][C/8][hw][8] layout, so the pass is
+// elementwise on float4 (4 consecutive channels)
+__global__ __launch_bounds__(256) void splitk_reduce_nc8_kernel(float* __restrict__ out, const float* __restrict__ partial,
+                                                                const float* __restrict__ bias, long total4,
+                                                                long stride, int S, int C8, int hw, float slope) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  float4 v = reinterpret_cast<const float4*>(partial)[i];
+  for (int s = 1; s < S; ++s) {
+    const float4 w = reinterpret_cast<const float4*>(partial + (long)s * stride)[i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  const int c = (int)((i / (2L * hw)) % C8) * 8 + (int)(i & 1) * 4;   // 2 float4 per pixel record
+  const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+  v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+
+// NC8 <-> NCHW re-layout of an activation tensor (decoder skip connections, tests)
+__global__ __launch_bounds__(256) void relayout_nc8_kernel(float* __restrict__ dst, const float* __restrict__ src, int C,
+                                                           int hw, long total, int to_nc8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index in the NC8 tensor
+  if (i >= total) return;
+  const int q = (int)(i & 7);
+  const long pix = (i >> 3) % hw;
+  const long nc8 = (i >> 3) / hw;
+  const int C8 = C >> 3;
+  const long n = nc8 / C8;
+  const int c = (int)(nc8 % C8) * 8 + q;
+  const long j = (n * C + c) * hw + pix;                 // index in the NCHW tensor
+  if (to_nc8) dst[i] = src[j]; else dst[j] = src[i];
+}
+
 // ------------------------------------------------------------ packing ----
 // conv:   packed[g][kc][kk][mm] = w[(g*64+mm)][kc*16+kk]  (w as (Cout, K) row-major), zero padded
 __global__ void pack_conv_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int K, int nchunk,
@@ -677,6 +924,25 @@ __global__ void build_direct_tab_kernel(int2* __restrict__ tab, int npair_real, 
   tab[g] = make_int2((2 * ci2 * H * W + ky * W + kx) * 4, ky * 8 + kx);
 }
 
+// NC8 layout: packed[mt][g][lane = h*32 + r][s] = w[mt*32 + r][c8*8 + s + 4h][ky][kx], g = (c8*kh + ky)*kw + kx
+__global__ void pack_nc8_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, int khw,
+                                int ngroup, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int s = (int)(i & 3), r = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1);
+  const int g = (int)((i >> 8) % ngroup);
+  const int mt = (int)(i / (256L * ngroup));
+  const int co = mt * 32 + r, ci = (g / khw) * 8 + s + 4 * h, t = g % khw;
+  packed[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * khw + t] : 0.f;
+}
+__global__ void build_nc8_tab_kernel(int2* __restrict__ tab, int ngroup_real, int n, int kh, int kw, int H, int W) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  if (g >= ngroup_real) { tab[g] = make_int2(0, 63); return; }
+  const int kx = g % kw, ky = (g / kw) % kh, c8 = g / (kw * kh);
+  tab[g] = make_int2((c8 * H * W + ky * W + kx) * 32, ky * 8 + kx);
+}
+
 __global__ void build_conv_tab_kernel(int2* __restrict__ tab, int K, int Kpad, int kh, int kw, int H, int W) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
@@ -727,10 +993,10 @@ struct TileChoice { int bm, bn, ksplit, tail_s; };
 // Tile/split heuristic for 256 CUs × 3 resident blocks: 128x128 (best MFMA density per LDS byte and per
 // gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the chip under-filled, split K
 // across grid.z (deterministic two-pass reduction) before shrinking the tile.
-TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, int classes) {
+TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, int classes, bool wide64 = false) {
   const int below = ctx->conv_split_below, target = ctx->conv_split_target;
   int bm = 128, bn = 128;
-  if (Cout <= 64) { bm = 64; bn = npix >= 256L * 1024 ? 256 : 128; }
+  if (Cout <= 64) { bm = 64; bn = (wide64 || npix >= 256L * 1024) ? 256 : 128; }   // wide64: the only 64-row LDS-free shape
   else if (ctx->conv_tile256 && Cout % 256 == 0) bm = 256;   // 8-wave block: every gathered activation feeds 256 channels
   const long blocks = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
   int ks = 1;
@@ -742,6 +1008,7 @@ template <int MODE>
 int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   p.ksplit = t.ksplit;
   p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
+  if (p.in_nc8) p.chunks_per_split = (p.chunks_per_split + 1) & ~1;   // the NC8 kernel consumes whole pairs of chunks
   p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
   p.partial = nullptr;
   p.partial_stride = (long)p.B * p.Cout * p.Ho * p.Wo;
@@ -776,7 +1043,10 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   }
   DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
   dim3 grid(p.gx * p.gy * p.gz);
-  if (direct_ok)
+  if (MODE == MODE_CONV && p.in_nc8) {
+    if (p.out_nc8) hipLaunchKernelGGL(conv_nc8_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(conv_nc8_kernel<0>, grid, dim3(256), 0, ctx->stream, p);
+  } else if (direct_ok)
     hipLaunchKernelGGL(conv_direct_kernel<2>, grid, dim3(256), 0, ctx->stream, p);
   else if (MODE == MODE_CONV && t.bm == 64 && t.bn == 256 && p.tab2 != nullptr)
     hipLaunchKernelGGL(conv_direct_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
@@ -790,9 +1060,13 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     hipLaunchKernelGGL((conv_mfma_kernel<64, 128, MODE>), grid, dim3(256), 0, ctx->stream, p);
   if (p.ksplit > 1) {
     const long total = p.partial_stride;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
-                       p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
-                       p.slope);
+    if (p.out_nc8)
+      hipLaunchKernelGGL(splitk_reduce_nc8_kernel, dim3(di_div_up(total / 4, 256)), dim3(256), 0, ctx->stream, p.out,
+                         p.partial, p.bias, total / 4, p.partial_stride, p.ksplit, p.Cout >> 3, p.Ho * p.Wo, p.slope);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
+                         p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
+                         p.slope);
   }
   DI_LAUNCH_CHECK();
   return 0;
@@ -802,9 +1076,9 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
 // HIP events and remember the fastest. The kernel is idempotent, so the trial launches only rewrite `out`.
 template <int MODE>
 int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
-  TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes);
+  TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes, p.out_nc8 != 0);
   const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
-                           ctx->conv_split_below * 16 + ctx->conv_tail_split * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0),
+                           ctx->conv_split_below * 16 + ctx->conv_tail_split * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0) + 1024 * (p.in_nc8 * 2 + p.out_nc8),
                            ctx->conv_split_target};
   if (ctx->conv_autotune && ctx->conv_max_split != 1) {
     bool found = false;
@@ -887,7 +1161,10 @@ int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, in
   const int Kpad = chunk_count(K) * KT;
   int2* tab;
   DI_CHECK(hipMalloc((void**)&tab, (size_t)(Kpad + 32) * sizeof(int2)));
-  if (mode == MODE_DIRECT_TAB)   // one entry per k-pair, padded past the end for the kernel's read-ahead
+  if (mode == MODE_NC8_TAB)      // one entry per group of 8 K elements, padded past the end for the read-ahead
+    hipLaunchKernelGGL(build_nc8_tab_kernel, dim3(di_div_up(Kpad / 8 + 24, 256)), dim3(256), 0, ctx->stream, tab, K / 8,
+                       Kpad / 8 + 24, kh, kw, H, W);
+  else if (mode == MODE_DIRECT_TAB)   // one entry per k-pair, padded past the end for the kernel's read-ahead
     hipLaunchKernelGGL(build_direct_tab_kernel, dim3(di_div_up(Kpad / 2 + 16, 256)), dim3(256), 0, ctx->stream, tab, K / 2,
                        Kpad / 2 + 16, kh, kw, H, W);
   else if (mode == MODE_CONV)
@@ -904,12 +1181,13 @@ int get_tab(deepim_ctx* ctx, int mode, int Cin, int kh, int kw, int H, int W, in
 
 }  // namespace
 
-// the packed buffer holds two layouts back to back, each gran·nchunk·1024 floats: [granule][chunk][16][64] for the
-// LDS kernel, then [32-row tile][k-pair][2][32] for the LDS-free kernel
+// the packed buffer holds three layouts back to back, each gran·nchunk·1024 floats: [granule][chunk][16][64] for the
+// LDS kernel, [32-row tile][k-pair/4][lane][4] for the LDS-free kernel on NCHW input, and the same shape in the
+// channel order of the NC8 kernel
 inline size_t packed_half(int Cout, int K) { return (size_t)gran_count(Cout) * chunk_count(K) * KT * GRAN; }
 
 extern "C" size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw) {
-  return 2 * packed_half(Cout, Cin * kh * kw) * sizeof(float);
+  return 3 * packed_half(Cout, Cin * kh * kw) * sizeof(float);
 }
 
 extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh,
@@ -920,6 +1198,8 @@ extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const 
                      nchunk, total);
   hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
                      Cin, kh * kw, nchunk * (KT / 2), total);
+  hipLaunchKernelGGL(pack_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + 2 * total, w, Cout,
+                     Cin, kh * kw, nchunk * 2, total);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -927,6 +1207,14 @@ extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const 
 extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                      const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                      int stride, int pad, float slope, int out_ctotal, int out_coff) {
+  return deepim_conv2d_forward_ex(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
+                                  out_coff, 0, 0);
+}
+
+extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
+                                        const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                        int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8,
+                                        int out_nc8) {
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
   ConvParams p;
@@ -950,11 +1238,25 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
+  p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8 ? 1 : 0; p.wd8 = nullptr; p.tab8 = nullptr;
+  if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
+  if (in_nc8) {
+    DI_REQUIRE((Cin & 7) == 0 && Cout > 64, "conv2d: NC8 input needs Cin % 8 == 0 and Cout > 64");
+    const size_t half = packed_half(Cout, Cin * kh * kw);
+    int2* tab8;
+    rc = get_tab(ctx, MODE_NC8_TAB, Cin, kh, kw, H, W, &tab8);
+    if (rc) return rc;
+    p.tab8 = tab8;
+    p.wd8 = packed_w + 2 * half;
+    p.wd_bytes = (unsigned)(half * sizeof(float));
+    return launch_conv<MODE_CONV>(ctx, p, 1);
+  }
   // LDS-free kernel: 128x128-tiled layers with even Cin. conv_max_split = 1 asks for the canonical single
   // (ci,ky,kx)-ordered chain per output, which only the LDS kernel provides; conv_direct = 2 forces the LDS-free kernel
   // regardless (its chain runs over (ci/2,ky,kx,ci%2)).
-  const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
-  if (direct && (Cin & 1) == 0 && (Cout > 64 || p.npix >= 256L * 1024)) {   // the tile shapes the LDS-free kernel has
+  const bool direct = out_nc8 || ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
+  if (out_nc8) DI_REQUIRE((Cin & 1) == 0, "conv2d: NC8 output needs an even Cin (LDS-free kernels only)");
+  if (direct && (Cin & 1) == 0 && (Cout > 64 || out_nc8 || p.npix >= 256L * 1024)) {   // the tile shapes the LDS-free kernel has
     const size_t half = packed_half(Cout, Cin * kh * kw);
     int2* tab2;
     rc = get_tab(ctx, MODE_DIRECT_TAB, Cin, kh, kw, H, W, &tab2);
@@ -1005,6 +1307,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
+  p.in_nc8 = p.out_nc8 = 0; p.wd8 = nullptr; p.tab8 = nullptr;
   return launch_conv<MODE_DECONV>(ctx, p, 4);
 }
 
@@ -1015,6 +1318,16 @@ extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const
   dim3 grid(di_div_up(Wo, 256), Ho, B * C);
   hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
                      scale);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, int C, size_t hw, int to_nc8) {
+  if (B == 0 || C == 0) return 0;
+  DI_REQUIRE((C & 7) == 0, "relayout_nc8: C must be a multiple of 8");
+  const long total = (long)B * C * (long)hw;
+  hipLaunchKernelGGL(relayout_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dst, src, C, (int)hw, total,
+                     to_nc8);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -75,6 +75,7 @@ class deepIM_flownet(object):
         self.cin = 6 + (2 if self.input_depth else 0) + (2 if self.input_mask else 0)
         # BASELINE config 5: conv stack on the fp16 matrix cores (NHWC fp16 activations, fp32 accumulate)
         self.fp16_conv = bool(n.get("FP16_CONV", False))
+        self.nc8 = bool(cfg.network.get('NC8_CONV', True)) if hasattr(cfg.network, 'get') else True
         self.H, self.W = cfg.SCALES[0]
         self.K = np.ascontiguousarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         # Prop-side channel reversal of the means (zoom_image_with_factor.py:79-81)
@@ -268,13 +269,37 @@ class deepIM_flownet(object):
         lib.deepim_nhwc_f16_to_nchw_f32(h, A["conv6_1"], src, B, 1024, 8, 10)
 
     def encoder(self):
+        """10 conv layers. With `self.nc8` (default) the layers hand each other channel-blocked activations
+        ([n][C/8][h][w][8]): conv1 reads the NCHW net input and writes NC8, conv6_1 returns to NCHW for fc6 (MXNet's
+        flatten order); `self.act[name]` of the layers in between then holds NC8 data (`activation_nchw` converts).
+        `self.nc8 = False` keeps NCHW throughout (the canonical-order, bit-exact configuration of the tests)."""
         if self.fp16_conv:
             return self.encoder_fp16()
         A = self.act
         src = A["net_input"]
-        for name, cin, h, w, cout, k, s, p in self.enc_geom:
-            self._conv(name, src, A[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
+        last = len(self.enc_geom) - 1
+        for li, (name, cin, h, w, cout, k, s, p) in enumerate(self.enc_geom):
+            if self.nc8:
+                lib.deepim_conv2d_forward_ex(self.ctx.handle, A[name], src, self.packed[name], self.params[name + "_bias"],
+                                             self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,
+                                             1 if li > 0 else 0, 1 if li < last else 0)
+            else:
+                self._conv(name, src, A[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
             src = A[name]
+        self.act_layout = "nc8" if self.nc8 else "nchw"
+
+    def activation_nchw(self, name):
+        """Encoder activation `name` as an NCHW device array (a converted copy when the encoder ran channel-blocked)."""
+        a = self.act[name]
+        names = [g[0] for g in self.enc_geom]
+        if self.fp16_conv or getattr(self, "act_layout", "nchw") != "nc8" or name not in names[:-1]:
+            return a
+        key = name + "_nchw"          # one conversion buffer per tensor, allocated on first use (not during graph capture)
+        if key not in self.act:
+            self.act[key] = self.ctx.empty(a.shape)
+        out = self.act[key]
+        lib.deepim_relayout_nc8(self.ctx.handle, out, a, a.shape[0], a.shape[1], a.shape[2] * a.shape[3], 0)
+        return out
 
     def pose_head(self):
         A, P, h, B = self.act, self.params, self.ctx.handle, self.B
@@ -290,11 +315,11 @@ class deepIM_flownet(object):
         """FlowNetS refinement (deepIM_flownet.py:120-167)."""
         A, h, B = self.act, self.ctx.handle, self.B
         self._conv("Convolution1", A["conv6_1"], A["flow6"], B, 1024, 8, 10, 2, 3, 1, 1, 1.0)
-        lib.deepim_copy_channels(h, A["Concat2"], 1026, 0, A["conv5_1"], 512, B, 15 * 20)
+        lib.deepim_copy_channels(h, A["Concat2"], 1026, 0, self.activation_nchw("conv5_1"), 512, B, 15 * 20)
         self._deconv("deconv5", A["conv6_1"], A["Concat2"], B, 1024, 8, 10, 512, 15, 20, SLOPE, 1026, 512)
         self._deconv("upsample_flow6to5", A["flow6"], A["Concat2"], B, 2, 8, 10, 2, 15, 20, 1.0, 1026, 1024)
         self._conv("Convolution2", A["Concat2"], A["flow5"], B, 1026, 15, 20, 2, 3, 1, 1, 1.0)
-        lib.deepim_copy_channels(h, A["Concat3"], 770, 0, A["conv4_1"], 512, B, 30 * 40)
+        lib.deepim_copy_channels(h, A["Concat3"], 770, 0, self.activation_nchw("conv4_1"), 512, B, 30 * 40)
         self._deconv("deconv4", A["Concat2"], A["Concat3"], B, 1026, 15, 20, 256, 30, 40, SLOPE, 770, 512)
         self._deconv("upsample_flow5to4", A["flow5"], A["Concat3"], B, 2, 15, 20, 2, 30, 40, 1.0, 770, 768)
 

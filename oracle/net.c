@@ -16,7 +16,8 @@ static inline float lrelu(float v, float slope) { return v > 0.f ? v : v * slope
 
 /* out (B,Cout,Ho,Wo).  pair_order = 0: the chain runs over k = (ci,ky,kx), ci slowest (the natural MXNet weight order);
  * pair_order = 1: over (ci/2, ky, kx, ci%2) — adjacent input channels interleaved per tap, the order of the LDS-free
- * MI355X kernel (needs even Cin).  fp32 addition is not associative and the reference's own order (cuDNN / MKL-DNN
+ * MI355X kernel on NCHW input (needs even Cin); pair_order = 2: over (ci/8, ky, kx, s, h) with channel 8(ci/8) + s + 4h
+ * — the order of the same kernel on channel-blocked (NC8) input (needs Cin % 8 == 0).  fp32 addition is not associative and the reference's own order (cuDNN / MKL-DNN
  * under MXNet) is unspecified, so both are equally faithful restatements; each kernel is checked bit-for-bit against
  * the order it implements and to 1e-5 against the other. */
 void oracle_conv2d_order(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
@@ -30,7 +31,8 @@ void oracle_conv2d_order(float* out, const float* in, const float* w, const floa
       memset(acc, 0, sizeof(float) * Ho * Wo);
       for (int s = 0; s < K; ++s) {
         int ci, t;
-        if (pair_order) { const int g = s >> 1; ci = 2 * (g / khw) + (s & 1); t = g % khw; }
+        if (pair_order == 2) { const int g = s >> 3, e = s & 7; ci = 8 * (g / khw) + (e >> 1) + 4 * (e & 1); t = g % khw; }
+        else if (pair_order) { const int g = s >> 1; ci = 2 * (g / khw) + (s & 1); t = g % khw; }
         else { ci = s / khw; t = s % khw; }
         const int ky = t / kw, kx = t % kw;
         const float* ip = in + ((size_t)n * Cin + ci) * H * W;

@@ -34,15 +34,16 @@ def _c(a):
 
 
 def conv2d(x, w, b, stride, pad, slope=1.0, pair_order=False):
-    """pair_order: accumulate over (ci/2, ky, kx, ci%2) instead of (ci, ky, kx) — see net.c."""
+    """pair_order: False/0 = (ci, ky, kx); True/1 = (ci/2, ky, kx, ci%2); 2 = (ci/8, ky, kx, s, h), channel 8(ci/8)+s+4h
+    — the accumulation orders of the three MI355X conv kernels, see net.c."""
     x, w, b = _c(x), _c(w), _c(b)
     B, Cin, H, W = x.shape
     Cout, _, kh, kw = w.shape
-    assert not pair_order or Cin % 2 == 0
+    assert not pair_order or Cin % (8 if int(pair_order) == 2 else 2) == 0
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     out = np.empty((B, Cout, Ho, Wo), f32)
     _lib().oracle_conv2d_order(_p(out), _p(x), _p(w), _p(b), B, Cin, H, W, Cout, kh, kw, stride, pad, ctypes.c_float(slope),
-                               int(bool(pair_order)))
+                               int(pair_order))
     return out
 
 

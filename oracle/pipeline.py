@@ -13,10 +13,13 @@ ENCODER = [("flow_conv1", 2, 3), ("conv2", 2, 2), ("conv3", 2, 2), ("conv3_1", 1
            ("conv5", 2, 1), ("conv5_1", 1, 1), ("conv6", 2, 1), ("conv6_1", 1, 1)]
 
 
-def encoder(params, x):
+def encoder(params, x, nc8=False):
+    """nc8: accumulate every layer in the order the channel-blocked MI355X configuration uses (conv1: channel pairs on
+    the NCHW net input, order 1; the rest: order 2 of net.c) instead of the canonical (ci,ky,kx)."""
     acts = {}
-    for name, s, p in ENCODER:
-        x = net.conv2d(x, params[name + "_weight"], params[name + "_bias"], s, p, SLOPE)
+    for li, (name, s, p) in enumerate(ENCODER):
+        order = (1 if li == 0 else 2) if nc8 else 0
+        x = net.conv2d(x, params[name + "_weight"], params[name + "_bias"], s, p, SLOPE, pair_order=order)
         acts[name] = x
     return acts
 
@@ -80,12 +83,12 @@ def flow_head(params, concat3, zoom_factor, H, W, normalize_flow):
 
 
 def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", heads=False,
-                     normalize_flow=20.0, fp16_conv=False):
+                     normalize_flow=20.0, fp16_conv=False, nc8=False):
     """-> dict with net_input, zoom_factor, encoder activations, se3 (B,7), pose_est (B,3,4 float64)."""
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"))
     out = {"net_input": x, "zoom_factor": zf}
-    acts = encoder_fp16(params, x) if fp16_conv else encoder(params, x)
+    acts = encoder_fp16(params, x) if fp16_conv else encoder(params, x, nc8=nc8)
     out.update(acts)
     if heads:
         dec = decoder(params, acts)

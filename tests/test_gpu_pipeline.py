@@ -27,22 +27,26 @@ def _np_data(d, f=0):
             "mask_observed": d["mask_observed"], "mask_rendered": d["mask_rendered"][f], "src_pose": d["src_pose"][f]}
 
 
-def test_fast_test_iteration_matches_oracle(ctx, small_batch):
+@pytest.mark.parametrize("nc8", [False, True])
+def test_fast_test_iteration_matches_oracle(ctx, small_batch, nc8):
+    """nc8 False: NCHW throughout, canonical (ci,ky,kx) chains; True: the default channel-blocked encoder. Either way every
+    conv output is one fmaf chain (conv_max_split = 1) in a known order → bit-identical to the oracle run in that order."""
     d = small_batch
     B = d["image_observed"].shape[0]
     cfg = default_config()
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=7)
     net.bind(ctx, B, params)
+    net.nc8 = nc8
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)   # single fmaf chain per output → bit-exact convs
     pose = net.refine_iteration(_data(ctx, d)).asnumpy()
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     ref = opipe.refine_iteration(params, _np_data(d), d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds,
-                                 cfg.network.ROT_COORD)
+                                 cfg.network.ROT_COORD, nc8=nc8)
     np.testing.assert_array_equal(net.act["zoom_factor"].asnumpy(), ref["zoom_factor"])
     np.testing.assert_array_equal(net.act["net_input"].asnumpy(), ref["net_input"])
     for name in ("flow_conv1", "conv3_1", "conv6_1"):
-        np.testing.assert_array_equal(net.act[name].asnumpy(), ref[name])
+        np.testing.assert_array_equal(net.activation_nchw(name).asnumpy(), ref[name], err_msg=name)
     se3 = net.act["se3"].asnumpy()
     assert np.abs(se3 - ref["se3"]).max() / np.abs(ref["se3"]).max() < 1e-4
     assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
@@ -54,7 +58,8 @@ def test_fast_test_iteration_matches_oracle(ctx, small_batch):
     assert np.abs(pose2 - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
 
 
-def test_heads_iteration_matches_oracle(ctx, small_batch):
+@pytest.mark.parametrize("nc8", [False, True])
+def test_heads_iteration_matches_oracle(ctx, small_batch, nc8):
     d = small_batch
     B = 1
     d1 = {k: (v[:, :B] if k in ("image_rendered", "mask_rendered", "depth_rendered", "src_pose") else (v[:B] if k != "K" else v))
@@ -65,12 +70,13 @@ def test_heads_iteration_matches_oracle(ctx, small_batch):
     assert net.with_mask_head and net.with_flow_head
     params = net.init_weights(cfg, seed=8)
     net.bind(ctx, B, params)
+    net.nc8 = nc8
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     out = net.forward(_data(ctx, d1))
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     ref = opipe.refine_iteration(params, _np_data(d1), d["K"], MEANS_REV, cfg.dataset.trans_means,
                                  cfg.dataset.trans_stds, cfg.network.ROT_COORD, heads=True,
-                                 normalize_flow=cfg.dataset.NORMALIZE_FLOW)
+                                 normalize_flow=cfg.dataset.NORMALIZE_FLOW, nc8=nc8)
     for name in ("flow6", "Concat2", "flow5", "Concat3", "mask_lowres", "flow_lowres"):
         np.testing.assert_array_equal(net.act[name].asnumpy(), ref[name], err_msg=name)
     np.testing.assert_array_equal(net.act["mask_logits"].asnumpy(), ref["mask_logits"])

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--target", type=int, default=768)
     ap.add_argument("--direct", type=int, default=0, help="1: LDS-free register-fed conv kernel")
     ap.add_argument("--maxsplit", type=int, default=0)
+    ap.add_argument("--nc8", type=int, default=1, help="1: channel-blocked activations between the layers (default)")
     ap.add_argument("--check", action="store_true", help="compare every layer against the LDS kernel (split-K off)")
     a = ap.parse_args()
     ctx = Context.get(0)
@@ -35,6 +36,7 @@ def main():
     cfg.network.FP16_CONV = a.fp16
     net = deepIM_flownet().get_symbol(cfg)
     net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
+    net.nc8 = bool(a.nc8)
     from mx_deepim_amd.runtime import lib
     lib.deepim_set_option(ctx.handle, b"conv_xcd_swizzle", a.swizzle)
     lib.deepim_set_option(ctx.handle, b"conv_tile256", a.tile256)
@@ -77,6 +79,12 @@ def main():
             run = lambda: lib.deepim_conv2d_f16_forward(ctx.handle, net.act[name + "_h"], src, net.packed_f16[name],
                                                         net.params[name + "_bias"], net.B, cpad, h, w, cout, k, k, s, p,
                                                         ctypes.c_float(0.1))
+        elif a.nc8:
+            li = [g[0] for g in net.enc_geom].index(name)
+            run = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, net.act[name], src, net.packed[name],
+                                                       net.params[name + "_bias"], net.B, cin, h, w, cout, k, k, s, p,
+                                                       ctypes.c_float(0.1), 0, 0, 1 if li > 0 else 0,
+                                                       1 if li < len(net.enc_geom) - 1 else 0)
         else:
             run = lambda: net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
         run()
