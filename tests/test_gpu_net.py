@@ -138,6 +138,76 @@ def test_conv_direct_kernel_random_geometries(ctx):
         assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), case
 
 
+def _to_nc8(x):
+    B, C, H, W = x.shape
+    return np.ascontiguousarray(x.reshape(B, C // 8, 8, H, W).transpose(0, 1, 3, 4, 2))
+
+
+def _from_nc8(y, shape):
+    B, C, H, W = shape
+    return np.ascontiguousarray(y.reshape(B, C // 8, H, W, 8).transpose(0, 1, 4, 2, 3).reshape(B, C, H, W))
+
+
+NC8_CASES = [
+    (2, 64, 60, 80, 128, 5, 2, 2),      # conv2 geometry
+    (1, 128, 30, 40, 256, 3, 1, 1),     # 3x3 stride 1
+    (3, 16, 17, 23, 72, 3, 1, 1),       # ragged pixel tile, Cout off the 128 grid (but % 8 == 0)
+    (1, 512, 8, 10, 1024, 3, 2, 1),     # conv6: deep K, 20 output pixels
+    (2, 8, 21, 19, 96, 7, 2, 3),        # 7x7 taps (validity bits >= 32), one channel block
+    (1, 24, 9, 9, 136, 1, 1, 0),        # 1x1: K = 24 pads to 32 (two chunks of groups)
+]
+
+
+@pytest.mark.parametrize("case", NC8_CASES)
+def test_conv_nc8_kernel(ctx, case):
+    """Channel-blocked input ([n][C/8][h][w][8]) on the LDS-free kernel, NC8 and NCHW outputs: without split-K bit-identical
+    to the oracle accumulating over (c/8, ky, kx, s, h), with split-K within fp32 re-association distance; the re-layout
+    entry round-trips."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ref2 = onet.conv2d(x, w, b, s, p, 0.1, pair_order=2)
+    ref = onet.conv2d(x, w, b, s, p, 0.1)
+    assert np.abs(ref2 - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    xin = ctx.empty(x.shape)
+    lib.deepim_relayout_nc8(ctx.handle, xin, ctx.array(x), B, cin, H * W, 1)
+    np.testing.assert_array_equal(xin.asnumpy().reshape(B, cin // 8, H, W, 8), _to_nc8(x))
+    back = ctx.empty(x.shape)
+    lib.deepim_relayout_nc8(ctx.handle, back, xin, B, cin, H * W, 0)
+    np.testing.assert_array_equal(back.asnumpy(), x)
+    pk, bias = _pack_conv(ctx, w), ctx.array(b)
+    for max_split in (1, 0):
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", max_split)
+        try:
+            for out_nc8 in (1, 0):
+                out = ctx.zeros((B, cout, Ho, Wo))
+                lib.deepim_conv2d_forward_ex(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, 1,
+                                             out_nc8)
+                got = _from_nc8(out.asnumpy(), (B, cout, Ho, Wo)) if out_nc8 else out.asnumpy()
+                if max_split == 1:
+                    np.testing.assert_array_equal(got, ref2, err_msg="out_nc8=%d" % out_nc8)
+                else:
+                    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        finally:
+            lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+
+
+def test_conv_nc8_argument_checks(ctx):
+    x, pk = ctx.zeros((1, 12, 8, 8)), ctx.zeros((1 << 16,))
+    out = ctx.zeros((1, 128, 8, 8))
+    with pytest.raises(RuntimeError):   # Cin % 8 != 0 with NC8 input
+        lib.deepim_conv2d_forward_ex(ctx.handle, out, x, pk, None, 1, 12, 8, 8, 128, 3, 3, 1, 1, cf(1.0), 0, 0, 1, 0)
+    with pytest.raises(RuntimeError):   # NC8 output into a channel slice
+        lib.deepim_conv2d_forward_ex(ctx.handle, out, x, pk, None, 1, 16, 8, 8, 64, 3, 3, 1, 1, cf(1.0), 128, 8, 0, 1)
+    with pytest.raises(RuntimeError):   # NC8 input needs the 128-row tile
+        lib.deepim_conv2d_forward_ex(ctx.handle, out, x, pk, None, 1, 16, 8, 8, 64, 3, 3, 1, 1, cf(1.0), 0, 0, 1, 0)
+    with pytest.raises(RuntimeError):
+        lib.deepim_relayout_nc8(ctx.handle, out, x, 1, 12, 64, 1)
+
+
 def test_conv_tail_split_plan(ctx):
     """Opt-in tail split of the LDS-free kernel: 1030 tiles with a round size of 256 → 1024 full tiles + 6 tiles cut
     into K slices and summed by tail_reduce_kernel in slice order. Same sums re-associated: ≤1e-5 of the oracle."""
