@@ -636,9 +636,15 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 // lanes 32-63 channels 4-7 of the 32-byte pixel record — ONE dwordx4 per lane feeds four k-steps, and a wave reads
 // 1 KB (stride 1) of fully used, contiguous bytes per load. 4 loads (2 activation, 2 weight, all b128) per 16 MFMAs
 // instead of 10; operands of 4 groups in flight (ring of 4, loads issued 3 groups = 48 MFMAs ahead).
+#ifndef NC8_RING
+#define NC8_RING 4
+#endif
+#ifndef NC8_OCC
+#define NC8_OCC 3
+#endif
 template <int OUT_NC8>
-__global__ __launch_bounds__(256, 3) void conv_nc8_kernel(ConvParams p) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NG = 4;   // NG: groups per loop body = ring size
+__global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NG = NC8_RING, NPD = NG - 1;   // NG: groups per loop body = ring size
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -721,20 +727,20 @@ __global__ __launch_bounds__(256, 3) void conv_nc8_kernel(ConvParams p) {
       const int2* t0 = p.tab8 + g_begin;
       asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tn) : "s"(t0));
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < NPD; ++u) {
         NLOADB(u, 0, tn[2 * u], tn[2 * u + 1]) NLOADB(u, 1, tn[2 * u], tn[2 * u + 1])
         NLOADA(u, 0, g_begin + u) NLOADA(u, 1, g_begin + u)
       }
-      const int2* t1 = p.tab8 + g_begin + 3;
+      const int2* t1 = p.tab8 + g_begin + NPD;
       asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(tq) : "s"(t1));
     }
     for (int g = g_begin; g < g_end; g += NG) {
-      const int2* t2 = p.tab8 + g + NG + 3;   // table is padded past the end
+      const int2* t2 = p.tab8 + g + NG + NPD;   // table is padded past the end
       asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(tn) : "s"(t2));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NG; ++q) {
-        const int ld = (q + 3) % NG;     // slot of the group loaded while group q is multiplied
+        const int ld = (q + NPD) % NG;   // slot of the group loaded while group q is multiplied
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][0], s_), QSEL(bq[q][0], s_), acc[0][0], 0, 0, 0);
@@ -747,11 +753,11 @@ __global__ __launch_bounds__(256, 3) void conv_nc8_kernel(ConvParams p) {
           __builtin_amdgcn_sched_barrier(0);
           acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][1], s_), QSEL(bq[q][0], s_), acc[1][0], 0, 0, 0);
           asm volatile("" : "+v"(acc[1][0]));
-          if (s_ == 1) NLOADA(ld, 0, g + q + 3)
+          if (s_ == 1) NLOADA(ld, 0, g + q + NPD)
           __builtin_amdgcn_sched_barrier(0);
           acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(QSEL(aq[q][1], s_), QSEL(bq[q][1], s_), acc[1][1], 0, 0, 0);
           asm volatile("" : "+v"(acc[1][1]));
-          if (s_ == 1) NLOADA(ld, 1, g + q + 3)
+          if (s_ == 1) NLOADA(ld, 1, g + q + NPD)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
