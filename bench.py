@@ -262,7 +262,7 @@ def main():
                                    if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "iters": NIT, "parallelism": "pairs sharded across %d GPU(s), RCCL all-gather "
                                                                         "of refined poses per iteration" % world},
-            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_direct_kernel") +
+            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_nc8_kernel / conv_direct_kernel") +
                          " (10 encoder launches per iteration incl. split-K reduces)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -24,8 +24,7 @@ def short(name):
 
 
 def is_conv(n):
-    return n.startswith("conv_mfma_kernel") or n.startswith("conv_direct_kernel") or n.startswith("splitk_reduce") or \
-        n.startswith("tail_reduce")
+    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "splitk_reduce", "tail_reduce"))
 
 
 def cmd_stats(a):
