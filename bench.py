@@ -285,15 +285,14 @@ def main():
 
 
 def layer_timings(ctx, net, reps=5):
-    import ctypes
     res = []
     src = net.act["net_input"]
-    for name, cin, h, w, cout, k, s, p in net.enc_geom:
+    for li, (name, cin, h, w, cout, k, s, p) in enumerate(net.enc_geom):
         t = ctx.timer()
-        net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+        net.encoder_layer(li, src)
         t.start()
         for _ in range(reps):
-            net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+            net.encoder_layer(li, src)
         t.stop()
         ms = t.elapsed_ms() / reps
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1

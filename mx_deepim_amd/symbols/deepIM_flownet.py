@@ -277,16 +277,20 @@ class deepIM_flownet(object):
             return self.encoder_fp16()
         A = self.act
         src = A["net_input"]
-        last = len(self.enc_geom) - 1
-        for li, (name, cin, h, w, cout, k, s, p) in enumerate(self.enc_geom):
-            if self.nc8:
-                lib.deepim_conv2d_forward_ex(self.ctx.handle, A[name], src, self.packed[name], self.params[name + "_bias"],
-                                             self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,
-                                             1 if li > 0 else 0, 1 if li < last else 0)
-            else:
-                self._conv(name, src, A[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
-            src = A[name]
+        for li in range(len(self.enc_geom)):
+            self.encoder_layer(li, src)
+            src = A[self.enc_geom[li][0]]
         self.act_layout = "nc8" if self.nc8 else "nchw"
+
+    def encoder_layer(self, li, src):
+        """One encoder conv (index into enc_geom) from `src` into its activation buffer, in the configured layout."""
+        name, cin, h, w, cout, k, s, p = self.enc_geom[li]
+        if self.nc8:
+            lib.deepim_conv2d_forward_ex(self.ctx.handle, self.act[name], src, self.packed[name], self.params[name + "_bias"],
+                                         self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,
+                                         1 if li > 0 else 0, 1 if li < len(self.enc_geom) - 1 else 0)
+        else:
+            self._conv(name, src, self.act[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
 
     def activation_nchw(self, name):
         """Encoder activation `name` as an NCHW device array (a converted copy when the encoder ran channel-blocked)."""

@@ -13,18 +13,20 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--layers", default="conv2,conv3,conv3_1")
 ap.add_argument("--plans", default="1,-2,-3,-4,-5,-6")
 ap.add_argument("--slots", type=int, default=1024)
+ap.add_argument("--nc8", type=int, default=1)
 a = ap.parse_args()
 ctx = Context.get(0)
 cfg = default_config()
 net = deepIM_flownet().get_symbol(cfg)
 net.bind(ctx, a.batch, net.init_weights(cfg, seed=1))
+net.nc8 = bool(a.nc8)
 lib.deepim_set_option(ctx.handle, b"conv_tail_slots", a.slots)
 rng = np.random.default_rng(0)
 net.act["net_input"].copyfrom(rng.standard_normal(net.act["net_input"].shape).astype(np.float32))
 net.encoder(); ctx.sync()
 plans = [int(x) for x in a.plans.split(",")]
 src = net.act["net_input"]
-for name, cin, h, w, cout, k, s, p in net.enc_geom:
+for li, (name, cin, h, w, cout, k, s, p) in enumerate(net.enc_geom):
     if name in a.layers.split(","):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         fl = 2.0 * cout * cin * k * k * ho * wo * net.B
@@ -32,7 +34,7 @@ for name, cin, h, w, cout, k, s, p in net.enc_geom:
         for rnd in range(a.rounds):
             for pl in plans:
                 lib.deepim_set_option(ctx.handle, b"conv_force_plan", pl)
-                run = lambda: net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+                run = lambda: net.encoder_layer(li, src)
                 run(); t = ctx.timer(); t.start()
                 for _ in range(a.reps):
                     run()

@@ -79,14 +79,9 @@ def main():
             run = lambda: lib.deepim_conv2d_f16_forward(ctx.handle, net.act[name + "_h"], src, net.packed_f16[name],
                                                         net.params[name + "_bias"], net.B, cpad, h, w, cout, k, k, s, p,
                                                         ctypes.c_float(0.1))
-        elif a.nc8:
-            li = [g[0] for g in net.enc_geom].index(name)
-            run = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, net.act[name], src, net.packed[name],
-                                                       net.params[name + "_bias"], net.B, cin, h, w, cout, k, k, s, p,
-                                                       ctypes.c_float(0.1), 0, 0, 1 if li > 0 else 0,
-                                                       1 if li < len(net.enc_geom) - 1 else 0)
         else:
-            run = lambda: net._conv(name, src, net.act[name], net.B, cin, h, w, cout, k, s, p, 0.1)
+            li = [g[0] for g in net.enc_geom].index(name)
+            run = lambda: net.encoder_layer(li, src)
         run()
         t.start()
         for _ in range(a.reps):
