@@ -642,6 +642,9 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 #ifndef NC8_OCC
 #define NC8_OCC 3
 #endif
+// (Tried: 64x128 tiles on 128-thread blocks for layers whose 128x128 tile count divides badly over 256 CUs, e.g. 2400 =
+// 9.375 per CU — identical throughput, so per-CU tile quantisation is not what separates conv3 (139 TF) from conv2 (144).
+// Note the 2nd __launch_bounds__ argument is waves per SIMD in HIP, not blocks per CU.)
 template <int OUT_NC8>
 __global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NG = NC8_RING, NPD = NG - 1;   // NG: groups per loop body = ring size
