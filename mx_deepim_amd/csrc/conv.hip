@@ -3,22 +3,21 @@
 //   MXNet Deconvolution k4 s2 + Crop       deepIM_flownet.py:127-165
 //   MXNet Deconvolution k32 s16 grouped    deepIM_flownet.py:185-200,326-340
 //
-// Design (CDNA4): implicit GEMM  D[co][pixel] = Σ_k Wp[co][k] · X[k][pixel],
-// k = (ci,ky,kx) in the natural MXNet order, on v_mfma_f32_32x32x2_f32 — exact fp32,
-// result bit-identical to a k-ordered fmaf chain, at the fp32 vector peak (157 TF) but
-// from one wave per SIMD, leaving the VALU free for the im2col gather.
-//   * block = 256 threads = 4 wavefronts in a 2×2 grid over a BM×BN output tile
-//     (BM output channels × BN output pixels, pixels flattened over (n,ho,wo));
-//   * K is consumed in chunks of 16: the weight chunk is a contiguous 16×BM slab of
-//     the pre-packed weights (one dwordx4 per thread, straight into LDS [k][m]); the
-//     activation chunk is gathered global→registers→LDS [k][pixel] with the
-//     per-thread pixel fixed for the whole K loop, the (ci,ky,kx)→offset table read
-//     through the scalar cache, and zero padding applied by per-thread ky/kx bitmasks;
-//   * LDS is double-buffered (one s_barrier per chunk); operand reads are
-//     conflict-free ds_read_b32 (lanes 0-31 → 32 consecutive dwords of row k, lanes
-//     32-63 → row k+1, matching the 32x32x2 A/B fragment layout);
-//   * epilogue fuses bias + LeakyReLU and writes NCHW with 128 B runs per row; the
-//     output may be a channel slice of a wider tensor (free Concat).
+// Implicit GEMM  D[co][pixel] = Σ_k Wp[co][k] · X[k][pixel]  on v_mfma_f32_32x32x2_f32 — exact fp32, each output a
+// single fmaf chain in the kernel's K order (bit-identical to the oracle run in that order), at the fp32 peak (157 TF).
+// Pixels are flattened over (n,ho,wo); 4 waves per block, each a 64x64 accumulator tile; zero padding by out-of-range
+// buffer offsets; XCD-aware 1-D tile order; deterministic split-K, autotuned per geometry; fused bias + LeakyReLU.
+// Three kernels:
+//   conv_nc8_kernel     LDS-free, channel-blocked (NC8) activations, K = (c/8,ky,kx,s,h): encoder conv2 … conv6_1
+//   conv_direct_kernel  LDS-free, NCHW input, K = (ci/2,ky,kx,ci%2): conv1 (writes NC8); the encoder with nc8 off
+//   conv_mfma_kernel    LDS-staged, canonical K = (ci,ky,kx): decoder deconvolutions, heads, odd Cin, bit-exact mode:
+//     * K is consumed in chunks of 16: the weight chunk is a contiguous 16×BM slab of the pre-packed weights (one
+//       dwordx4 per thread, straight into LDS [k][m]); the activation chunk is gathered global→registers→LDS
+//       [k][pixel] with the per-thread pixel fixed for the whole K loop, the (ci,ky,kx)→offset table read through the
+//       scalar cache;
+//     * LDS is double-buffered (one s_barrier per chunk); operand reads are conflict-free ds_read_b32 (lanes 0-31 → 32
+//       consecutive dwords of row k, lanes 32-63 → row k+1, matching the 32x32x2 A/B fragment layout);
+//     * the output may be a channel slice of a wider tensor (free Concat).
 // Roofline: MFMA-bound (arithmetic intensity ≈ 300 FLOP/B).
 #include "common.h"
 #include <stdlib.h>
@@ -445,12 +444,9 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
     vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
     split = vid / (p.gx * p.gy);
   }
-#ifndef DIRECT_MFAST
-#define DIRECT_MFAST 0
-#endif
   const int tvid = vid % (p.gx * p.gy);
-  const int bx = DIRECT_MFAST ? tvid / p.gy : tvid % p.gx;
-  const int mb = DIRECT_MFAST ? tvid % p.gy : tvid / p.gx;
+  const int bx = tvid % p.gx;      // pixel tiles fastest (M-fastest order measured the same)
+  const int mb = tvid / p.gx;
   const long n0 = (long)bx * BN;
   const int lrow = lane >> 5, lcol = lane & 31;
   const long npix = p.npix;
