@@ -264,7 +264,16 @@ __global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* 
   Taps t[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) t[i] = make_taps(a, h, w0 + i, H, W, gx_step, gy_step);
-  const long row0 = (long)t[0].y0 * W;
+  // taps outside the frame contribute 0 (BilinearSampler zero padding): load from a clamped in-frame address and select,
+  // so the 16 tap loads of a channel are unconditional (no exec-mask branches around them)
+  const int yc0 = min(max(t[0].y0, 0), H - 1), yc1 = min(max(t[0].y0 + 1, 0), H - 1);
+  const long row0 = (long)yc0 * W, row1 = (long)yc1 * W;
+  int xc0[4], xc1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xc0[i] = min(max(t[i].x0, 0), W - 1);
+    xc1[i] = min(max(t[i].x0 + 1, 0), W - 1);
+  }
   const long opix = (long)h * W + w0;
   const int sy0 = (int)floorf((float)H / 2 - 5), sy1 = (int)ceilf((float)H / 2 + 5);
   const int sx0 = (int)floorf((float)W / 2 - 5), sx1 = (int)ceilf((float)W / 2 + 5);
@@ -273,16 +282,15 @@ __global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* 
 #pragma unroll 2
   for (int c = 0; c < plan.n; ++c) {
     const Chan& ch = plan.ch[c];
-    const float* s = ch.src + (long)b * ch.src_bstride + row0;
+    const float* s = ch.src + (long)b * ch.src_bstride;
     const int fl = ch.flags;
     float tl[4], tr[4], bl[4], br[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int x0 = t[i].x0;
-      tl[i] = t[i].in00 ? s[x0] : 0.f;
-      tr[i] = t[i].in01 ? s[x0 + 1] : 0.f;
-      bl[i] = t[i].in10 ? s[x0 + W] : 0.f;
-      br[i] = t[i].in11 ? s[x0 + W + 1] : 0.f;
+      tl[i] = s[row0 + xc0[i]];
+      tr[i] = s[row0 + xc1[i]];
+      bl[i] = s[row1 + xc0[i]];
+      br[i] = s[row1 + xc1[i]];
     }
     float o[4];
 #pragma unroll
