@@ -142,10 +142,12 @@ def main():
     params["trans_weight"] = params["trans_weight"] * np.float32(0.02)
     params["trans_bias"] = params["trans_bias"] * np.float32(0.02)
     net.bind(ctx, B, params)
-    batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=NIT, with_depth=False)
+    # only the pre-staged mode needs the later frames ray-cast on the host; the closed loop renders them on the device
+    nfr = NIT if args.prestaged else 1
+    batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=nfr, with_depth=False)
     image_observed = ctx.array(batch["image_observed"])
     frames = [{"image_rendered": ctx.array(batch["image_rendered"][f]), "mask_rendered": ctx.array(batch["mask_rendered"][f]),
-               "mask_observed": ctx.array(batch["mask_observed_frames"][f])} for f in range(NIT)]
+               "mask_observed": ctx.array(batch["mask_observed_frames"][f])} for f in range(nfr)]
     pose_init = ctx.array(batch["src_pose"][0])
     pose_cur = ctx.empty((B, 3, 4))
     # closed loop (tester.py:420-455): re-render at the refined pose on the device between iterations
