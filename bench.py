@@ -101,8 +101,8 @@ def cpu_onednn_secondary(cfg, seconds=8.0, pairs=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU (bs32 of BASELINE.json's metric)")
     ap.add_argument("--iters", type=int, default=4, help="refinement iterations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
