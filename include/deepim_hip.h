@@ -47,7 +47,8 @@ int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_co
                          const float* src, int C, int B, size_t hw);
 void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
 /* integer tuning knobs. "conv_max_split": 0 = auto split-K (default), 1 = never split AND canonical order
- * (conv/deconv results are then a single (ci,ky,kx)-ordered fmaf chain, bit-identical to the oracle), n = cap.
+ * (conv/deconv results are then a single (ci,ky,kx)-ordered fmaf chain, bit-identical to the oracle; with NC8 input —
+ * deepim_conv2d_forward_ex — still a single chain, in that kernel's own (c/8,ky,kx,s,h) order), n = cap.
  * "conv_direct": 1 (default) = 128x128-tiled convs with even Cin run on the LDS-free register-fed kernel, whose
  * fmaf chain runs over (ci/2,ky,kx,ci%2) (differs from the canonical order in the last bits; the oracle has the
  * matching order switch); it steps aside when conv_max_split == 1; 2 = use it even then; 0 = never.
