@@ -271,7 +271,9 @@ def main():
                          "flop_per_launch_group": flops, "ms_per_launch_group": enc_ms},
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms},
+                              "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms,
+                              "note": "in practice VALU-bound: BilinearSampler's float/double blend restated bit-for-bit "
+                                      "(~13 fp64-rate ops per output), see DESIGN.md section 3"},
         }
         if not args.prestaged and NIT > 1:
             out["render_ms"] = float(np.mean([t.elapsed_ms() for row in render_timers for t in row]))
