@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5 mode: conv stack on the fp16 matrix cores "
                     "(NOT the headline: reduced precision; reported with dtype f16)")
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
+    ap.add_argument("--heads", action="store_true", help="BASELINE config 4 mode: full test graph (FAST_TEST off) with the "
+                    "FlowNetS decoder and the mask / flow heads in every iteration (NOT the headline)")
     ap.add_argument("--cpu-onednn", action="store_true", help="also time the network forward through torch-CPU (oneDNN) "
                     "as a labelled secondary CPU figure (imports torch: slow first import on a fresh box)")
     ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
@@ -136,6 +138,8 @@ def main():
     B, NIT = args.batch, args.iters
     cfg = default_config()
     cfg.network.FP16_CONV = bool(args.fp16)
+    if args.heads:
+        cfg.TEST.FAST_TEST = False
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=2333)
     # random-init translation head: damp it so 4 closed-loop iterations keep the object inside the frame
@@ -186,6 +190,9 @@ def main():
             net.encoder()
             if timers:
                 timers[it].stop()
+            if args.heads:
+                net.decoder()
+                net.heads()
             net.pose_head()
             net.pose_update(pose_cur, pose_cur)   # refined pose becomes the next iteration's src_pose
             if world > 1:                          # every rank/host gets all refined poses
@@ -260,7 +267,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, batch %d per GPU, %d refinement iters, 480x640, "
-                                   "FAST_TEST graph (8-ch input), %s" % (B, NIT, "pre-staged rendered frames (render excluded)"
+                                   "%s (8-ch input), %s" % (B, NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph", "pre-staged rendered frames (render excluded)"
                                    if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "iters": NIT, "parallelism": "pairs sharded across %d GPU(s), RCCL all-gather "
                                                                         "of refined poses per iteration" % world},
