@@ -802,6 +802,99 @@ __global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Convs with a handful of output channels (the flow / mask heads: Cout = 2 or 1 over 770-1026 input channels,
+// deepIM_flownet.py:123,145,176,317): on the MFMA kernels 62 of 64 tile rows would be padding, and the layer is a pure
+// stream over the input (118 MB at B = 32 for 0.5 GFLOP). VALU kernel: a block owns 64 consecutive output pixels
+// (lane = pixel, loads coalesced along the row), its 16 waves split the input channels into sixteenths, each wave runs
+// the (ci,ky,kx)-ordered fmaf chain of its share with wave-uniform weights from the scalar cache; the sixteen partial
+// sums are added in wave order through LDS (deterministic), then bias + LeakyReLU.
+// KS > 0: square kernel size known at compile time — the taps of a channel are unrolled so its KS*KS loads are in
+// flight together (the loop is latency-bound otherwise: 1.9 ms instead of 0.1 ms for the 770-channel heads)
+template <int COUT, int KS>
+__global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                          const float* __restrict__ wp, const float* __restrict__ bias,
+                                                          int Cin, int H, int W, int Ho, int Wo, int kh, int kw,
+                                                          int stride, int pad, long npix, int out_ctotal, int out_coff,
+                                                          float slope) {
+  constexpr int NW = 16;   // waves per block = channel shares
+  __shared__ float part[NW - 1][COUT][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long pix = (long)blockIdx.x * 64 + lane;
+  const bool live = pix < npix;
+  const int hw = Ho * Wo;
+  const long n = live ? pix / hw : 0;
+  const int r = live ? (int)(pix - n * hw) : 0;
+  const int ho = r / Wo, wo = r - ho * Wo;
+  const int hi0 = ho * stride - pad, wi0 = wo * stride - pad;
+  const int cq = (Cin + NW - 1) / NW;
+  const int c_lo = min(Cin, wave * cq), c_hi = min(Cin, c_lo + cq);
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  const float* ip = in + (n * Cin) * (long)H * W;
+  const int khw = kh * kw;
+  if constexpr (KS > 0) {
+    // tap addresses and validity are the same for every channel: hoisted
+    int off[KS * KS];
+    bool ok[KS * KS];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int hi = hi0 + ky, wi = wi0 + kx;
+        ok[ky * KS + kx] = live && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        off[ky * KS + kx] = min(max(hi, 0), H - 1) * W + min(max(wi, 0), W - 1);
+      }
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+      const float* plane = ip + (long)ci * H * W;
+      float v[KS * KS];
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t) v[t] = plane[off[t]];
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t) {
+        const float x = ok[t] ? v[t] : 0.f;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co)   // LDS-kernel packing, granule 0: wp[k*64 + co] = w[co][k], k = (ci,ky,kx)
+          acc[co] = fmaf(wp[((long)ci * (KS * KS) + t) * GRAN + co], x, acc[co]);
+      }
+    }
+  } else {
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+      const float* plane = ip + (long)ci * H * W;
+      for (int ky = 0; ky < kh; ++ky) {
+        const int hi = hi0 + ky;
+        const bool rowok = live && hi >= 0 && hi < H;
+        const float* row = plane + (long)min(max(hi, 0), H - 1) * W;
+        for (int kx = 0; kx < kw; ++kx) {
+          const int wi = wi0 + kx;
+          const float v = (rowok && wi >= 0 && wi < W) ? row[min(max(wi, 0), W - 1)] : 0.f;
+#pragma unroll
+          for (int co = 0; co < COUT; ++co)
+            acc[co] = fmaf(wp[((long)ci * khw + ky * kw + kx) * GRAN + co], v, acc[co]);
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) part[wave - 1][co][lane] = acc[co];
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float v = acc[co];
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) v += part[q][co][lane];
+      v = v + (bias ? bias[co] : 0.f);
+      v = v > 0.f ? v : v * slope;
+      out[(n * out_ctotal + out_coff + co) * hw + r] = v;
+    }
+  }
+}
+
 // split-K second pass: out[n][coff+c][hw] = lrelu(Σ_s partial[s][n][c][hw] + bias[c]) in fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                             const float* __restrict__ bias, long total, long stride,
@@ -1255,6 +1348,20 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
     p.wd8 = packed_w + 2 * half;
     p.wd_bytes = (unsigned)(half * sizeof(float));
     return launch_conv<MODE_CONV>(ctx, p, 1);
+  }
+  if (Cout <= 4 && ctx->conv_max_split != 1 && p.out_nc8 == 0) {   // heads: a stream over the input, not an MFMA problem
+    const dim3 grid(di_div_up(p.npix, 64));
+#define DI_FEWOUT(C, KS)                                                                                               \
+  hipLaunchKernelGGL((conv_fewout_kernel<C, KS>), grid, dim3(1024), 0, ctx->stream, out, in, packed_w, bias, Cin, H, W, p.Ho, \
+                     p.Wo, kh, kw, stride, pad, p.npix, p.out_ctotal, out_coff, slope)
+    const bool k3 = kh == 3 && kw == 3;   // the heads are all 3x3; other sizes take the generic loop
+    if (Cout == 1) { if (k3) DI_FEWOUT(1, 3); else DI_FEWOUT(1, 0); }
+    else if (Cout == 2) { if (k3) DI_FEWOUT(2, 3); else DI_FEWOUT(2, 0); }
+    else if (Cout == 3) { if (k3) DI_FEWOUT(3, 3); else DI_FEWOUT(3, 0); }
+    else { if (k3) DI_FEWOUT(4, 3); else DI_FEWOUT(4, 0); }
+#undef DI_FEWOUT
+    DI_LAUNCH_CHECK();
+    return 0;
   }
   // LDS-free kernel: 128x128-tiled layers with even Cin. conv_max_split = 1 asks for the canonical single
   // (ci,ky,kx)-ordered chain per output, which only the LDS kernel provides; conv_direct = 2 forces the LDS-free kernel

@@ -228,6 +228,28 @@ def test_conv_tail_split_plan(ctx):
         lib.deepim_set_option(ctx.handle, b"conv_tail_slots", 1024)
 
 
+@pytest.mark.parametrize("case", [(2, 770, 30, 40, 2, 3, 1, 1), (1, 1026, 15, 20, 2, 3, 1, 1), (3, 37, 19, 23, 3, 5, 2, 2),
+                                  (2, 5, 9, 70, 4, 7, 1, 3), (1, 3, 8, 8, 1, 1, 1, 0)])
+def test_conv_few_output_channels(ctx, case):
+    """Cout <= 4 (flow / mask heads) runs on the VALU streaming kernel by default: sixteen (ci,ky,kx)-ordered chains over
+    channel shares, added in order — within fp32 re-association distance of the canonical chain; writes into a channel slice too."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = onet.conv2d(x, w, b, s, p, 0.1)
+    got = _run_conv(ctx, x, w, b, s, p, 0.1)
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    Ho, Wo = ref.shape[2:]
+    out = ctx.zeros((B, cout + 5, Ho, Wo))
+    lib.deepim_conv2d_forward(ctx.handle, out, ctx.array(x), _pack_conv(ctx, w), ctx.array(b), B, cin, H, W, cout, k, k, s, p,
+                              cf(0.1), cout + 5, 3)
+    o = out.asnumpy()
+    np.testing.assert_array_equal(o[:, 3:3 + cout], got)
+    assert not o[:, :3].any() and not o[:, 3 + cout:].any()
+
+
 def test_conv_matches_torch_cpu(ctx):
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(11)
