@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
     for (int k = 0; k < 8; ++k)
       if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
   }
-  const unsigned nlo = ~(unsigned)m64, nhi = ~(unsigned)(m64 >> 32);
+  const unsigned long long ninv64 = ~m64;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
 
@@ -98,8 +98,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
     const int2* tp = p.tab + (kc) * HOCT + orow0;                                                        \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
       const int2 t = tp[e];                                                                              \
-      const unsigned word = (t.y & 32) ? nhi : nlo;                                                      \
-      const unsigned inv = __builtin_amdgcn_ubfe(word, (unsigned)t.y & 31u, 1u);                        \
+      const unsigned inv = (unsigned)(ninv64 >> t.y);   /* no SALU-produced VALU operand, see conv.hip */  \
       breg[e] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((inv << 31) | voff), t.x, 0)); \
     }                                                                                                    \
   }
