@@ -19,8 +19,8 @@ constexpr int FC_ROWS = 32; // output rows per block (4 waves)
 
 // partial[s][b][o] = Σ_{k in slice s} x[b][k]·w[o][k]
 __global__ __launch_bounds__(256) void fc_partial_kernel(float* __restrict__ partial, const float* __restrict__ x,
-                                                         const float* __restrict__ w, int B, int I, int O, int slice,
-                                                         int b0) {
+                                                         const float* __restrict__ w, int B, int I, int O, int slice) {
+  const int b0 = blockIdx.z * FC_BT;   // batch rows in groups of 16: concurrent blocks, the second group's weight reads hit L2/MALL
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int o0 = blockIdx.x * FC_ROWS + wave * FC_RW;
   const int s = blockIdx.y;
@@ -139,10 +139,8 @@ extern "C" int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, c
   int rc = deepim_scratch(ctx, (size_t)S * B * O * sizeof(float), &scratch);
   if (rc) return rc;
   float* partial = (float*)scratch;
-  for (int b0 = 0; b0 < B; b0 += FC_BT) {
-    hipLaunchKernelGGL(fc_partial_kernel, dim3(rowblocks, S), dim3(256), 0, ctx->stream, partial, in, w, B, I, O, slice,
-                       b0);
-  }
+  hipLaunchKernelGGL(fc_partial_kernel, dim3(rowblocks, S, di_div_up(B, FC_BT)), dim3(256), 0, ctx->stream, partial, in, w,
+                     B, I, O, slice);
   hipLaunchKernelGGL(fc_finalize_kernel, dim3(di_div_up((long)B * O, 16)), dim3(256), 0, ctx->stream, out, partial,
                      bias, B, O, S, slope);
   DI_LAUNCH_CHECK();
