@@ -195,6 +195,40 @@ def test_conv_nc8_kernel(ctx, case):
             lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
 
 
+def test_conv_nc8_kernel_random_geometries(ctx):
+    """Random geometries through the NC8 kernel (odd sizes, every kernel size / stride / pad the net uses, channel counts off
+    the chunk grid so the K padding and the even-chunk rule of split-K are exercised, forced split factors)."""
+    rng = np.random.default_rng(777)
+    for trial in range(14):
+        k = int(rng.choice([1, 3, 5, 7]))
+        s_ = int(rng.choice([1, 2]))
+        p_ = int(rng.integers(0, k // 2 + 1))
+        cin = 8 * int(rng.integers(1, 9))
+        cout = int(rng.choice([72, 96, 128, 136, 200, 256]))
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(k, 36)), int(rng.integers(k, 44))
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+        case = (B, cin, H, W, cout, k, s_, p_)
+        ref2 = onet.conv2d(x, w, b, s_, p_, 0.1, pair_order=2)
+        xin, pk, bias = ctx.array(_to_nc8(x)), _pack_conv(ctx, w), ctx.array(b)
+        for plan in (1, 2, 3, 5):
+            lib.deepim_set_option(ctx.handle, b"conv_force_plan", plan)
+            try:
+                out = ctx.zeros((B, cout, Ho, Wo))
+                lib.deepim_conv2d_forward_ex(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, k, k, s_, p_, cf(0.1), 0, 0, 1,
+                                             trial & 1)
+            finally:
+                lib.deepim_set_option(ctx.handle, b"conv_force_plan", 0)
+            got = _from_nc8(out.asnumpy(), (B, cout, Ho, Wo)) if trial & 1 else out.asnumpy()
+            if plan == 1:
+                np.testing.assert_array_equal(got, ref2, err_msg=str(case))
+            else:
+                assert np.abs(got - ref2).max() <= 1e-5 * max(1.0, np.abs(ref2).max()), (case, plan)
+
+
 def test_conv_nc8_argument_checks(ctx):
     x, pk = ctx.zeros((1, 12, 8, 8)), ctx.zeros((1 << 16,))
     out = ctx.zeros((1, 128, 8, 8))
