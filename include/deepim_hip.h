@@ -169,6 +169,10 @@ int deepim_zoom_concat_forward(deepim_ctx* ctx,
 /* debug/parity hook: the int32 source indices (x0,y0 = floor of the sampling
  * position) the resampler uses for every output pixel: idx (B,2,H,W) int32 */
 int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W);
+/* debug/parity hook: the affine (wx,wy,tx,ty) the b_inv_zoom ops sample with, i.e. zoom_flow.py:36-44 /
+ * zoom_mask_with_factor.py:43-52 applied to a stored factor (NumPy-1.x promotion: float64 chain, rounded once).
+ * zoom_factor, inv_factor: (B,4) device */
+int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_factor, float* inv_factor, int B, int H, int W);
 /* sticky status of the zoom-factor computations since the last read (reading clears it):
  * bit0 = an observed mask/image had no valid pixel — the reference raises ValueError there
  * (np.min of an empty array, zoom_mask.py:55); the zoom factor is NaN for that sample */

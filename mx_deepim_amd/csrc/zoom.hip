@@ -80,10 +80,11 @@ __global__ __launch_bounds__(256) void bbox_kernel(int* __restrict__ box, const 
 }
 
 // ---------------------------------------------------------- zoom factor ----
-// zoom_mask.py:47-103 / zoom_image.py:41-98, NumPy-1.x scalar promotion: K·t and the
-// centre are float32; distances to int64 box edges are float64; tx,ty are float32
-// when the centre is the projected one (float32 scalar / python int) and float64 in
-// the fallback branch; everything is stored to float32 at the end.
+// zoom_mask.py:47-103 / zoom_image.py:41-98 under NumPy-1.x ("legacy") scalar promotion, the
+// reference's era and the parity target (pinned by tests/golden/zoom_golden.npz, which runs the
+// reference's own lines): K·t and the centre cx = c0/c2 are float32; everything after that mixes the
+// float32 scalar with Python ints / int64 box edges and is therefore float64 — distances, crop, and
+// tx = cx / W * 2 - 1 — rounded once when stored to the float32 zoom_factor.
 __global__ void zoom_factor_kernel(float* __restrict__ zoom_factor, int* __restrict__ status,
                                    const int* __restrict__ box, const float* __restrict__ src_pose, Mat3 K, int B,
                                    int H, int W) {
@@ -117,8 +118,8 @@ __global__ void zoom_factor_kernel(float* __restrict__ zoom_factor, int* __restr
     osx = rend[0]; oex = rend[1]; osy = rend[2]; oey = rend[3];
     zcx = (double)cxf;
     zcy = (double)cyf;
-    txf = cxf / (float)W * 2.f - 1.f;
-    tyf = cyf / (float)H * 2.f - 1.f;
+    txf = (float)(zcx / W * 2 - 1);
+    tyf = (float)(zcy / H * 2 - 1);
   }
   const double left = fmax(zcx - osx, zcx - rsx);
   const double right = fmax(oex - zcx, rex - zcx);
@@ -163,13 +164,16 @@ __device__ __forceinline__ Affine load_affine(const float* __restrict__ zoom_fac
   Affine a;
   a.wx_in = wx_in;
   if (!inverse) { a.wx = wx_in; a.wy = wy_in; a.tx = tx_in; a.ty = ty_in; return a; }
-  a.wx = 1.f / wx_in;
-  a.wy = 1.f / wy_in;
-  const float crop_w = wx_in * (float)W, crop_h = wy_in * (float)H;
-  const double cx = (double)tx_in * 0.5 * W + 0.5 * W;
-  const double cy = (double)ty_in * 0.5 * H + 0.5 * H;
-  a.tx = (float)((W * 0.5 - cx) / (double)crop_w * 2);
-  a.ty = (float)((H * 0.5 - cy) / (double)crop_h * 2);
+  // zoom_flow.py:36-44 / zoom_mask_with_factor.py:43-52, legacy promotion: the float32 scalars meet Python
+  // ints/floats on every line, so the whole chain is float64, rounded once into the float32 affine matrix
+  const double wxi = wx_in, wyi = wy_in, txi = tx_in, tyi = ty_in;
+  a.wx = (float)(1 / wxi);
+  a.wy = (float)(1 / wyi);
+  const double crop_w = wxi * W, crop_h = wyi * H;
+  const double cx = txi * 0.5 * W + 0.5 * W;
+  const double cy = tyi * 0.5 * H + 0.5 * H;
+  a.tx = (float)((W * 0.5 - cx) / crop_w * 2);
+  a.ty = (float)((H * 0.5 - cy) / crop_h * 2);
   return a;
 }
 
@@ -326,6 +330,13 @@ __global__ __launch_bounds__(256) void indices_kernel(int32_t* __restrict__ idx,
   const long plane = (long)H * W;
   idx[((long)b * 2 + 0) * plane + (long)h * W + w] = t.x0;
   idx[((long)b * 2 + 1) * plane + (long)h * W + w] = t.y0;
+}
+
+__global__ void inverse_factor_kernel(float* __restrict__ out, const float* __restrict__ zoom_factor, int B, int H, int W) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const Affine a = load_affine(zoom_factor, b, 1, H, W);
+  out[b * 4 + 0] = a.wx; out[b * 4 + 1] = a.wy; out[b * 4 + 2] = a.tx; out[b * 4 + 3] = a.ty;
 }
 
 __global__ void zoom_trans_kernel(float* __restrict__ out, const float* __restrict__ zoom_factor,
@@ -541,6 +552,13 @@ extern "C" int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, in
   const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
   dim3 grid(di_div_up(W, 256), H, B);
   hipLaunchKernelGGL(indices_kernel, grid, dim3(256), 0, ctx->stream, idx, zoom_factor, H, W, gx, gy);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_factor, float* inv_factor, int B, int H, int W) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(inverse_factor_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, inv_factor, zoom_factor, B, H, W);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -87,8 +87,15 @@ def _bbox(valid):
     return nz_x, nz_y
 
 
-def zoom_factor_from_valid(valid_real, valid_rendered, src_pose, K, H, W):
-    """zoom_mask.py:47-103 / zoom_image.py:41-98 for one sample -> f32 (wx, wy, tx, ty)."""
+def zoom_factor_from_valid(valid_real, valid_rendered, src_pose, K, H, W, promotion="legacy"):
+    """zoom_mask.py:47-103 / zoom_image.py:41-98 for one sample -> f32 (wx, wy, tx, ty).
+
+    Scalar promotion (pinned by tests/golden/zoom_golden.npz, i.e. by the reference's own lines run under both
+    rules): the projected centre cx = c[0]/c[2] is a float32 scalar.  promotion="legacy" (NumPy 1.x, the
+    reference's era, THE PARITY TARGET): `cx / self.width * 2 - 1` promotes float32-scalar-op-Python-int to
+    float64, so tx, ty are a float64 chain rounded ONCE when stored into the float32 zoom_factor array.
+    promotion="numpy2": the same expression stays float32 (three roundings).  Box distances are float64 under
+    both (float32 scalar op int64 scalar)."""
     K = np.asarray(K, dtype=f32).reshape(3, 3)
     t = np.asarray(src_pose, dtype=f32)[:, 3]
     nz_x, nz_y = _bbox(valid_real)
@@ -108,8 +115,12 @@ def zoom_factor_from_valid(valid_real, valid_rendered, src_pose, K, H, W):
     else:
         osx, oex, osy, oey = f64(nz_x.min()), f64(nz_x.max()), f64(nz_y.min()), f64(nz_y.max())
         zcx, zcy = f64(cx), f64(cy)
-        tx = f32(f32(f32(cx / f32(W)) * f32(2)) - f32(1))   # float32 scalar op python int -> float32
-        ty = f32(f32(f32(cy / f32(H)) * f32(2)) - f32(1))
+        if promotion == "legacy":
+            tx = f32(f64(cx) / W * 2 - 1)                       # float64 chain, one rounding at the store
+            ty = f32(f64(cy) / H * 2 - 1)
+        else:
+            tx = f32(f32(f32(cx / f32(W)) * f32(2)) - f32(1))   # NumPy 2: float32 scalar op python int -> float32
+            ty = f32(f32(f32(cy / f32(H)) * f32(2)) - f32(1))
     left = max(zcx - osx, zcx - rsx)
     right = max(oex - zcx, rex - zcx)
     up = max(zcy - osy, zcy - rsy)
@@ -196,17 +207,36 @@ def zoom_depth(zoom_factor, depth_observed, depth_rendered):
     return o0, o1
 
 
-def inverse_factor(zf, H, W):
-    """zoom_flow.py:36-44 / zoom_mask_with_factor.py:43-52 with NumPy-1.x promotion -> f32 (wx,wy,tx,ty)."""
+def inverse_factor(zf, H, W, promotion="legacy"):
+    """zoom_flow.py:36-44 / zoom_mask_with_factor.py:43-52 -> f32 (wx, wy, tx, ty).
+
+    The four inputs are float32 scalars unpacked from `asnumpy()`.  promotion="legacy" (NumPy 1.x, THE PARITY
+    TARGET): every line mixes them with Python ints/floats, so the whole computation is float64 and is rounded
+    once when `mx.nd.array([[wx,0,tx],[0,wy,ty]])` makes the float32 affine matrix.  promotion="numpy2": every
+    line stays float32.  Both are pinned by tests/golden/zoom_golden.npz."""
     wx_in, wy_in, tx_in, ty_in = [f32(v) for v in zf]
-    wx = f32(f32(1) / wx_in)
-    wy = f32(f32(1) / wy_in)
-    crop_w = f32(wx_in * f32(W))
-    crop_h = f32(wy_in * f32(H))
-    cx = f64(tx_in) * 0.5 * W + 0.5 * W
-    cy = f64(ty_in) * 0.5 * H + 0.5 * H
-    tx = f32((W * 0.5 - cx) / f64(crop_w) * 2)
-    ty = f32((H * 0.5 - cy) / f64(crop_h) * 2)
+    if promotion == "legacy":
+        wx_in, wy_in, tx_in, ty_in = f64(wx_in), f64(wy_in), f64(tx_in), f64(ty_in)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            wx = 1 / wx_in
+            wy = 1 / wy_in
+            crop_w = wx_in * W
+            crop_h = wy_in * H
+            cx = tx_in * 0.5 * W + 0.5 * W
+            cy = ty_in * 0.5 * H + 0.5 * H
+            tx = (W * 0.5 - cx) / crop_w * 2
+            ty = (H * 0.5 - cy) / crop_h * 2
+        return f32(wx), f32(wy), f32(tx), f32(ty)
+    Wf, Hf, half, two = f32(W), f32(H), f32(0.5), f32(2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wx = f32(f32(1) / wx_in)
+        wy = f32(f32(1) / wy_in)
+        crop_w = f32(wx_in * Wf)
+        crop_h = f32(wy_in * Hf)
+        cx = f32(f32(f32(tx_in * half) * Wf) + f32(0.5 * W))
+        cy = f32(f32(f32(ty_in * half) * Hf) + f32(0.5 * H))
+        tx = f32(f32(f32(f32(W * 0.5) - cx) / crop_w) * two)
+        ty = f32(f32(f32(f32(H * 0.5) - cy) / crop_h) * two)
     return wx, wy, tx, ty
 
 
