@@ -108,7 +108,7 @@ int deepim_calc_KT(deepim_ctx* ctx, float* KT /*B,3,4*/, const float* pose_src,
 int deepim_depth_to_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n);
 /* "box_rendered" / "box_observed" rectangle of a mask (lib/pair_matching/data_pair.py:94-116, the INIT_MASK twin at
  * lib/utils/image.py:355-374): 1 inside [y_start:y_end, x_start:x_end] with start/end = first/last row and column holding a
- * non-zero — numpy slices, so the last row and column stay 0. An empty mask gives zeros and sets bit 1 of the status word
+ * non-zero — numpy slices, so the last row and column stay 0. An empty mask gives zeros and sets bit 2 (value 4) of the status word
  * (deepim_zoom_status) where the reference raises. mask, box: (B,1,H,W) device. */
 int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float* mask, int B, int H, int W);
 
@@ -173,9 +173,11 @@ int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx,
  * zoom_mask_with_factor.py:43-52 applied to a stored factor (NumPy-1.x promotion: float64 chain, rounded once).
  * zoom_factor, inv_factor: (B,4) device */
 int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_factor, float* inv_factor, int B, int H, int W);
-/* sticky status of the zoom-factor computations since the last read (reading clears it):
- * bit0 = an observed mask/image had no valid pixel — the reference raises ValueError there
- * (np.min of an empty array, zoom_mask.py:55); the zoom factor is NaN for that sample */
+/* sticky status word since the last read (reading clears it):
+ * bit0 (1) = a zoom-factor computation saw an observed mask/image with no valid pixel — the reference raises ValueError
+ *            there (np.min of an empty array, zoom_mask.py:55); the zoom factor is NaN for that sample
+ * bit1 (2) = GroupPicker index out of range
+ * bit2 (4) = deepim_mask_box_forward / deepim_render_update_forward saw an empty mask (data_pair.py:98 raises) */
 int deepim_zoom_status(deepim_ctx* ctx, int* status);
 
 /* ------------------------------------------ N-group: matching network ops -- */

@@ -8,6 +8,10 @@
 #include "../../include/deepim_hip.h"
 
 constexpr int DI_MAX_BOX_SAMPLES = 4096;
+// bits of the sticky status word (deepim_zoom_status)
+constexpr int DI_STATUS_ZOOM_EMPTY = 1;       // observed mask/image empty in a zoom-factor computation (zoom_mask.py:55 raises)
+constexpr int DI_STATUS_GROUP_RANGE = 2;      // GroupPicker index out of range
+constexpr int DI_STATUS_MASK_BOX_EMPTY = 4;   // mask_box / fused re-render: empty mask (data_pair.py:98 np.min raises)
 
 struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry
 
@@ -21,9 +25,8 @@ struct deepim_ctx {
   void* scratch;
   size_t scratch_bytes;
   std::vector<void*> retired_scratch;  // outgrown scratch buffers still referenced by captured graphs
-  int* status;  // persistent device status word (bit0: empty observed mask/image in a zoom op, bit1: empty mask in mask_box)
-  int* box_words;   // 2 x DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: double-buffered bbox accumulators of mask_box
-  int box_parity;
+  int* status;  // persistent device status word, bits DI_STATUS_*
+  int* box_words;   // DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: bbox accumulators of mask_box, armed inside every call
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
   std::vector<hipGraphExec_t> graphs;
@@ -54,6 +57,18 @@ void deepim_set_error_msg(const char* msg);
     }                                                    \
   } while (0)
 
+// Every extern "C" entry that takes a context starts with this: allocations, events and launches follow the CURRENT
+// device, not the stream's, and the reference drives several GPUs from one process (gpu_flow_wrapper(device_id),
+// one executor per context) — so each call makes its context's device current first.
+#define DI_DEVICE(ctx)                                   \
+  do {                                                   \
+    hipError_t _e = hipSetDevice((ctx)->device);         \
+    if (_e != hipSuccess) {                              \
+      deepim_set_error("hipSetDevice", _e);              \
+      return (int)_e;                                    \
+    }                                                    \
+  } while (0)
+
 #define DI_LAUNCH_CHECK()                                \
   do {                                                   \
     hipError_t _e = hipGetLastError();                   \
@@ -71,8 +86,8 @@ void deepim_set_error_msg(const char* msg);
     }                                                    \
   } while (0)
 
-// fill pass of the box_rendered rectangle from accumulated bbox words (csrc/flow.hip); re-arms `nxt`
-int deepim_mask_box_fill(deepim_ctx* ctx, float* box, int* cur, int* nxt, int B, int H, int W);
+// fill pass of the box_rendered rectangle from accumulated bbox words (csrc/flow.hip)
+int deepim_mask_box_fill(deepim_ctx* ctx, float* box, const int* words, int B, int H, int W);
 
 // Grow-only scratch; never reallocated while a graph capture is open.
 int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out);

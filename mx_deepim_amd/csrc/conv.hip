@@ -1205,9 +1205,13 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
             if (sN >= 2 && sN <= max(1, p.nchunk / 4) && nc < 16) cands[nc++] = -sN;
         }
       }
-      hipEvent_t e0, e1;
-      DI_CHECK(hipEventCreate(&e0));
-      DI_CHECK(hipEventCreate(&e1));
+      struct EventPair {   // destroyed on every exit path, including the DI_CHECK early returns below
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+      } ev;
+      DI_CHECK(hipEventCreate(&ev.a));
+      DI_CHECK(hipEventCreate(&ev.b));
+      const hipEvent_t e0 = ev.a, e1 = ev.b;
       float best = 1e30f;
       int best_ks = t.ksplit;
       for (int ci = 0; ci < nc; ++ci) {
@@ -1224,8 +1228,6 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
         DI_CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best * 0.985f) { best = ms; best_ks = cands[ci]; }  // prefer fewer splits on near-ties
       }
-      hipEventDestroy(e0);
-      hipEventDestroy(e1);
       if (getenv("DEEPIM_CONV_VERBOSE"))
         fprintf(stderr, "[deepim] conv plan B=%d Cin=%d %dx%d Cout=%d s%d: %d tiles, %s %d (%.3f ms)\n", p.B, p.Cin, p.H, p.W,
                 p.Cout, p.stride, tiles, best_ks < 0 ? "tail split" : "split-K", best_ks < 0 ? -best_ks : best_ks, best / 3);
@@ -1290,6 +1292,7 @@ extern "C" size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw) {
 
 extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh,
                                         int kw) {
+  DI_DEVICE(ctx);
   const int K = Cin * kh * kw, nchunk = chunk_count(K);
   const long total = (long)gran_count(Cout) * nchunk * KT * GRAN;
   hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
@@ -1305,6 +1308,7 @@ extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const 
 extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                      const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                      int stride, int pad, float slope, int out_ctotal, int out_coff) {
+  DI_DEVICE(ctx);
   return deepim_conv2d_forward_ex(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
                                   out_coff, 0, 0);
 }
@@ -1313,6 +1317,7 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
                                         const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                         int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8,
                                         int out_nc8) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
   ConvParams p;
@@ -1385,6 +1390,7 @@ extern "C" size_t deepim_deconv_packed_size(int Cin, int Cout) {
 }
 
 extern "C" int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cin, int Cout) {
+  DI_DEVICE(ctx);
   const int nchunk = chunk_count(Cin * 4), ngran = gran_count(Cout);
   const long total = (long)4 * ngran * nchunk * KT * GRAN;
   hipLaunchKernelGGL(pack_deconv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cin, Cout,
@@ -1397,6 +1403,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
                                                const float* bias, int B, int Cin, int H, int W, int Cout, int Ho,
                                                int Wo, int crop_y, int crop_x, float slope, int out_ctotal,
                                                int out_coff) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(Ho + crop_y <= (H - 1) * 2 + 4 && Wo + crop_x <= (W - 1) * 2 + 4, "deconv: crop exceeds output");
   ConvParams p;
@@ -1426,6 +1433,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
 extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const float* in, const float* w, int B,
                                               int C, int H, int W, int Ho, int Wo, int crop_y, int crop_x,
                                               float scale) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   dim3 grid(di_div_up(Wo, 256), Ho, B * C);
   hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
@@ -1435,6 +1443,7 @@ extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const
 }
 
 extern "C" int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, int C, size_t hw, int to_nc8) {
+  DI_DEVICE(ctx);
   if (B == 0 || C == 0) return 0;
   DI_REQUIRE((C & 7) == 0, "relayout_nc8: C must be a multiple of 8");
   const long total = (long)B * C * (long)hw;

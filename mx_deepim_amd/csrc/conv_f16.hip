@@ -249,6 +249,7 @@ inline int f16_chunks(int Cin_pad, int kh, int kw) { return di_div_up(kh * kw * 
 
 extern "C" int deepim_nchw_f32_to_nhwc_f16(deepim_ctx* ctx, void* out_f16, const float* in, int B, int C, int H, int W,
                                            int Cpad) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(Cpad >= C && (Cpad & 7) == 0, "nchw_to_nhwc_f16: Cpad must be a multiple of 8 and >= C");
   const long total = (long)B * H * W * (Cpad / 8);
   if (total == 0) return 0;
@@ -259,6 +260,7 @@ extern "C" int deepim_nchw_f32_to_nhwc_f16(deepim_ctx* ctx, void* out_f16, const
 }
 
 extern "C" int deepim_nhwc_f16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_f16, int B, int C, int H, int W) {
+  DI_DEVICE(ctx);
   const long total = (long)B * C * H * W;
   if (total == 0) return 0;
   hipLaunchKernelGGL(nhwc_f16_to_nchw_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out,
@@ -273,6 +275,7 @@ extern "C" size_t deepim_conv_f16_packed_size(int Cout, int Cin_pad, int kh, int
 
 extern "C" int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const float* w, int Cout, int Cin, int Cin_pad,
                                             int kh, int kw) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(Cin_pad >= Cin && (Cin_pad & 7) == 0, "conv_f16_pack: Cin_pad must be a multiple of 8 and >= Cin");
   const int nchunk = f16_chunks(Cin_pad, kh, kw);
   const long total = (long)di_div_up(Cout, HBM) * nchunk * HOCT * HBM * 8;
@@ -285,6 +288,7 @@ extern "C" int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const
 extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* in_nhwc_f16,
                                          const void* packed_w, const float* bias, int B, int Cin_pad, int H, int W,
                                          int Cout, int kh, int kw, int stride, int pad, float slope) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((Cin_pad & 7) == 0 && (Cout & 3) == 0, "conv2d_f16: Cin_pad % 8 and Cout % 4 must be 0");
   DI_REQUIRE(kh <= 7 && kw <= 7, "conv2d_f16: kernel larger than 7 not supported");

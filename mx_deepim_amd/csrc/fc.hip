@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void pose_head_kernel(float* __restrict__ se3, 
 
 extern "C" int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, const float* w, const float* bias,
                                  int B, int I, int O, float slope) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((I & 3) == 0, "fc: input width must be a multiple of 4");
   const int rowblocks = di_div_up(O, FC_ROWS);
@@ -150,6 +151,7 @@ extern "C" int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, c
 extern "C" int deepim_pose_head_forward(deepim_ctx* ctx, float* se3, const float* feat, const float* w_rot,
                                         const float* b_rot, const float* w_trans, const float* b_trans,
                                         const float* zoom_factor, int B, int F) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(pose_head_kernel, dim3(B), dim3(64), 0, ctx->stream, se3, feat, w_rot, b_rot, w_trans, b_trans,
                      zoom_factor, F);

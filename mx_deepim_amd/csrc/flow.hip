@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256) void depth_to_mask_kernel(float* __restrict__ 
 
 // rectangle of a mask the way the reference draws it (lib/pair_matching/data_pair.py:94-105, lib/utils/image.py:363-372):
 // x/y_start = first, x/y_end = last column/row holding a non-zero, filled [y_start:y_end, x_start:x_end] — numpy slices,
-// so the last row and column stay 0. words: {xmin, xmax, ymin, ymax} per sample, pre-set to {INT_MAX,-1,INT_MAX,-1}.
+// so the last row and column stay 0. words: {xmin, xmax, ymin, ymax} per sample, armed to {INT_MAX,-1,INT_MAX,-1} by
+// mask_box_arm_kernel (or by the project pass of the fused re-render) earlier in the same call, in stream order.
+__global__ void mask_box_arm_kernel(int* __restrict__ words, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) words[i] = (i & 1) ? -1 : INT_MAX;
+}
 __global__ __launch_bounds__(256) void mask_bbox_kernel(int* __restrict__ words, const float* __restrict__ mask, int H,
                                                         int W) {
   const int b = blockIdx.y;
@@ -231,15 +236,11 @@ __global__ __launch_bounds__(256) void mask_bbox_kernel(int* __restrict__ words,
   }
 }
 __global__ __launch_bounds__(256) void mask_box_fill_kernel(float* __restrict__ box, const int* __restrict__ words,
-                                                            int* __restrict__ next_words, int* __restrict__ status,
-                                                            int H, int W) {
+                                                            int* __restrict__ status, int H, int W) {
   const int b = blockIdx.y;
   const int xs = words[b * 4 + 0], xe = words[b * 4 + 1], ys = words[b * 4 + 2], ye = words[b * 4 + 3];
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) {   // arm the other word set for the next call (its last reader finished earlier in stream order)
-    next_words[b * 4 + 0] = INT_MAX; next_words[b * 4 + 1] = -1; next_words[b * 4 + 2] = INT_MAX; next_words[b * 4 + 3] = -1;
-    if (xe < 0) atomicOr(status, 2);   // empty mask: the reference's np.min of an empty array raises
-  }
+  if (i == 0 && xe < 0) atomicOr(status, DI_STATUS_MASK_BOX_EMPTY);   // the reference's np.min of an empty array raises
   if (i >= (long)H * W) return;
   const int y = (int)(i / W), x = (int)(i - (long)y * W);
   box[(long)b * H * W + i] = (xe >= 0 && y >= ys && y < ye && x >= xs && x < xe) ? 1.f : 0.f;
@@ -266,6 +267,7 @@ void inv3d(const float* K, double* o) {
 extern "C" int deepim_flow_forward(deepim_ctx* ctx, float* flow, float* valid, const float* depth_src,
                                    const float* depth_tgt, const float* KT, const float* Kinv_host,
                                    int B, int H, int W) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(B >= 0 && H > 0 && W > 0, "deepim_flow_forward: bad shape");
   if (B == 0) return 0;
   Mat3 Kinv = load_mat3(Kinv_host);
@@ -302,13 +304,18 @@ extern "C" void _flow(float* flow, float* valid, float* depth_src, float* depth_
     return;
   }
   deepim_ctx* c = ctxs[device_id];
+  if (hipSetDevice(device_id) != hipSuccess) {   // gpu_flow_kernel.cu:71-80 selects the device itself, so does the drop-in
+    deepim_set_error_msg("_flow: hipSetDevice failed");
+    fprintf(stderr, "_flow: %s\n", deepim_last_error());
+    return;
+  }
   const size_t plane = (size_t)height * width, n = (size_t)batch_size * plane;
   const size_t need = n * 5 + (size_t)batch_size * 12 + 16;  // src,tgt,flow(2),valid,KT
   if (need > caps[device_id]) {
     if (bufs[device_id]) hipFree(bufs[device_id]);
     bufs[device_id] = nullptr;
     caps[device_id] = 0;
-    if (hipSetDevice(device_id) != hipSuccess || hipMalloc((void**)&bufs[device_id], need * sizeof(float)) != hipSuccess) {
+    if (hipMalloc((void**)&bufs[device_id], need * sizeof(float)) != hipSuccess) {
       deepim_set_error_msg("_flow: hipMalloc failed");
       fprintf(stderr, "_flow: %s\n", deepim_last_error());
       return;
@@ -339,6 +346,7 @@ extern "C" void _flow(float* flow, float* valid, float* depth_src, float* depth_
 extern "C" int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow, float* visible, const float* depth_src,
                                         const float* depth_tgt, const float* KT, const float* Kinv_host, float thresh,
                                         int standard_rep, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   dim3 grid(di_div_up((long)W * H, 256), B);
   hipLaunchKernelGGL(calc_flow_kernel, grid, dim3(256), 0, ctx->stream, flow, visible, depth_src, depth_tgt, KT,
@@ -349,6 +357,7 @@ extern "C" int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow, float* vis
 
 extern "C" int deepim_calc_KT(deepim_ctx* ctx, float* KT, const float* pose_src, const float* pose_tgt,
                               const float* K_host, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(calc_KT_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, KT, pose_src, pose_tgt,
                      load_mat3(K_host), B);
@@ -359,6 +368,7 @@ extern "C" int deepim_calc_KT(deepim_ctx* ctx, float* KT, const float* pose_src,
 extern "C" int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow, float* flow_weights, const float* depth_src,
                                            const float* depth_tgt, const float* pose_src, const float* pose_tgt,
                                            const float* K_host, float thresh, int wh_rep, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   void* scratch;
   int rc = deepim_scratch(ctx, (size_t)B * 48, &scratch);
@@ -376,24 +386,25 @@ extern "C" int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow, float* 
 }
 
 // second half of the rectangle op, shared with the fused re-render (csrc/render.hip accumulates the bbox itself)
-int deepim_mask_box_fill(deepim_ctx* ctx, float* box, int* cur, int* nxt, int B, int H, int W) {
-  hipLaunchKernelGGL(mask_box_fill_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, box, cur, nxt,
+int deepim_mask_box_fill(deepim_ctx* ctx, float* box, const int* words, int B, int H, int W) {
+  hipLaunchKernelGGL(mask_box_fill_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, box, words,
                      ctx->status, H, W);
   DI_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int deepim_mask_box_forward(deepim_ctx* ctx, float* box, const float* mask, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(B <= DI_MAX_BOX_SAMPLES, "mask_box: batch too large");
-  int* cur = ctx->box_words + (ctx->box_parity ? DI_MAX_BOX_SAMPLES * 4 : 0);
-  int* nxt = ctx->box_words + (ctx->box_parity ? 0 : DI_MAX_BOX_SAMPLES * 4);
-  ctx->box_parity ^= 1;
-  hipLaunchKernelGGL(mask_bbox_kernel, dim3(di_div_up(H, 8), B), dim3(256), 0, ctx->stream, cur, mask, H, W);
-  return deepim_mask_box_fill(ctx, box, cur, nxt, B, H, W);
+  int* words = ctx->box_words;
+  hipLaunchKernelGGL(mask_box_arm_kernel, dim3(di_div_up(B * 4, 256)), dim3(256), 0, ctx->stream, words, B * 4);
+  hipLaunchKernelGGL(mask_bbox_kernel, dim3(di_div_up(H, 8), B), dim3(256), 0, ctx->stream, words, mask, H, W);
+  return deepim_mask_box_fill(ctx, box, words, B, H, W);
 }
 
 extern "C" int deepim_depth_to_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n) {
+  DI_DEVICE(ctx);
   if (n == 0) return 0;
   hipLaunchKernelGGL(depth_to_mask_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, mask, depth,
                      thresh, n);

@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void group_pick_kernel(float* __restrict__ out
   if (!backward) {  // out (B, cg) ← in (B, C)
     const int b = i / cg, c = i - b * cg;
     const int g = (int)group_idx[b];
-    if (g < 0 || g >= group_num) { atomicOr(status, 2); out[i] = 0.f; return; }
+    if (g < 0 || g >= group_num) { atomicOr(status, DI_STATUS_GROUP_RANGE); out[i] = 0.f; return; }
     out[i] = in[(long)b * C + g * cg + c];
   } else {          // out = in_grad (B, C) ← in = out_grad (B, cg)
     const int b = i / C, c = i - b * C;
     const int g = (int)group_idx[b];
-    if (g < 0 || g >= group_num) { atomicOr(status, 2); out[i] = 0.f; return; }
+    if (g < 0 || g >= group_num) { atomicOr(status, DI_STATUS_GROUP_RANGE); out[i] = 0.f; return; }
     out[i] = (c >= g * cg && c < (g + 1) * cg) ? in[(long)b * cg + (c - g * cg)] : 0.f;
   }
 }
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
 }  // namespace
 
 extern "C" int deepim_l2_normalize_forward(deepim_ctx* ctx, float* out, const float* in, int B, int D, float eps) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(l2norm_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, out, in, nullptr, B, D, eps, 0);
   DI_LAUNCH_CHECK();
@@ -156,6 +157,7 @@ extern "C" int deepim_l2_normalize_forward(deepim_ctx* ctx, float* out, const fl
 }
 extern "C" int deepim_l2_normalize_backward(deepim_ctx* ctx, float* d_in, const float* d_out, const float* in, int B,
                                             int D, float eps) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(l2norm_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, d_in, in, d_out, B, D, eps, 1);
   DI_LAUNCH_CHECK();
@@ -163,6 +165,7 @@ extern "C" int deepim_l2_normalize_backward(deepim_ctx* ctx, float* d_in, const 
 }
 extern "C" int deepim_rot_dist_loss(deepim_ctx* ctx, float* loss, float* d_q_est, const float* q_gt, const float* q_est,
                                     float grad_scale, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(rot_dist_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, loss, d_q_est, q_gt, q_est,
                      grad_scale, B);
@@ -171,6 +174,7 @@ extern "C" int deepim_rot_dist_loss(deepim_ctx* ctx, float* loss, float* d_q_est
 }
 
 extern "C" int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alpha, size_t n) {
+  DI_DEVICE(ctx);
   if (n == 0) return 0;
   hipLaunchKernelGGL(axpy_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, y, x, alpha, n);
   DI_LAUNCH_CHECK();
@@ -180,6 +184,7 @@ extern "C" int deepim_axpy(deepim_ctx* ctx, float* y, const float* x, float alph
 extern "C" int deepim_point_matching_loss(deepim_ctx* ctx, float* loss, float* loss_sum, float* d_est,
                                           const float* est, const float* gt, const float* weights, float normalize,
                                           int loss_type, float sigma, float grad_scale, int B, int N) {
+  DI_DEVICE(ctx);
   const size_t n = (size_t)B * 3 * N;
   if (n == 0) return 0;
   DI_REQUIRE(loss_type >= 0 && loss_type <= 2, "point_matching_loss: unknown loss type");
@@ -197,6 +202,7 @@ extern "C" int deepim_point_matching_loss(deepim_ctx* ctx, float* loss, float* l
 extern "C" int deepim_flow_loss(deepim_ctx* ctx, float* loss, float* loss_sum, float* d_est, const float* est,
                                 const float* gt, const float* weights, float normalize_flow, float grad_scale,
                                 size_t n) {
+  DI_DEVICE(ctx);
   if (n == 0) return 0;
   void* scratch;
   int rc = deepim_scratch(ctx, LOSS_BLOCKS * sizeof(float), &scratch);
@@ -211,6 +217,7 @@ extern "C" int deepim_flow_loss(deepim_ctx* ctx, float* loss, float* loss_sum, f
 
 extern "C" int deepim_mask_logistic(deepim_ctx* ctx, float* prob, float* d_logits, const float* logits,
                                     const float* label, float grad_scale, size_t n) {
+  DI_DEVICE(ctx);
   if (n == 0) return 0;
   DI_REQUIRE(!d_logits || label, "mask_logistic: label required for the gradient");
   hipLaunchKernelGGL(logistic_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, prob, d_logits, logits,
@@ -221,6 +228,7 @@ extern "C" int deepim_mask_logistic(deepim_ctx* ctx, float* prob, float* d_logit
 
 extern "C" int deepim_group_picker_forward(deepim_ctx* ctx, float* out, const float* in, const float* group_idx,
                                            int group_num, int B, int C) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(group_num > 0 && C % group_num == 0, "GroupPicker: channels not divisible by group_num");
   const int total = B * (C / group_num);
   if (total == 0) return 0;
@@ -232,6 +240,7 @@ extern "C" int deepim_group_picker_forward(deepim_ctx* ctx, float* out, const fl
 
 extern "C" int deepim_group_picker_backward(deepim_ctx* ctx, float* in_grad, const float* out_grad,
                                             const float* group_idx, int group_num, int B, int C) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(group_num > 0 && C % group_num == 0, "GroupPicker: channels not divisible by group_num");
   const int total = B * C;
   if (total == 0) return 0;

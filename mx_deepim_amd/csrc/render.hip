@@ -23,8 +23,12 @@ namespace {
 struct PV { float u, v, z; };
 
 __global__ __launch_bounds__(256) void project_kernel(PV* __restrict__ pv, const float* __restrict__ verts,
-                                                      const float* __restrict__ poses, Mat3 K, int V) {
+                                                      const float* __restrict__ poses, Mat3 K, int V,
+                                                      int* __restrict__ box_words) {
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  // arm this sample's bbox accumulator for the resolve pass of THIS call, in stream order (two launches earlier):
+  // no state survives between calls, so changing B between calls or replaying a captured graph is safe
+  if (box_words != nullptr && i < 4) box_words[b * 4 + i] = (i & 1) ? -1 : INT_MAX;
   if (i >= V) return;
   const float* P = poses + b * 12;
   const float x = verts[i * 3], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
@@ -199,21 +203,17 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
   for (int i = 0; i < 9; ++i) K.v[i] = K_host[i];
   Vec3 means = {{0, 0, 0}};
   if (pixel_means_host) for (int i = 0; i < 3; ++i) means.v[i] = pixel_means_host[i];
-  int *cur = nullptr, *nxt = nullptr;
-  if (mask_box) {
-    cur = ctx->box_words + (ctx->box_parity ? DI_MAX_BOX_SAMPLES * 4 : 0);
-    nxt = ctx->box_words + (ctx->box_parity ? 0 : DI_MAX_BOX_SAMPLES * 4);
-    ctx->box_parity ^= 1;
-  }
+  int* words = mask_box ? ctx->box_words : nullptr;
   DI_CHECK(hipMemsetAsync(zbuf, 0xff, zbytes, ctx->stream));
-  hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V);
+  hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V,
+                     words);
   hipLaunchKernelGGL(raster_kernel, dim3(di_div_up(F, 256), B), dim3(256), 0, ctx->stream, zbuf, pv, (const int*)faces, V,
                      F, H, W, znear, zfar);
   hipLaunchKernelGGL(resolve_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, image, depth, zbuf,
                      pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear, mask, mask_thresh,
-                     cur);
+                     words);
   DI_LAUNCH_CHECK();
-  if (mask_box) return deepim_mask_box_fill(ctx, mask_box, cur, nxt, B, H, W);
+  if (mask_box) return deepim_mask_box_fill(ctx, mask_box, words, B, H, W);
   return 0;
 }
 
@@ -222,6 +222,7 @@ extern "C" int deepim_render_forward(deepim_ctx* ctx, float* image, float* depth
                                      int tex_h, int tex_w, const float* poses, const float* K_host,
                                      const float* pixel_means_host, int V, int F, int B, int H, int W, float znear,
                                      float zfar) {
+  DI_DEVICE(ctx);
   return render_impl(ctx, image, depth, nullptr, nullptr, 0.f, vertices, vertex_attr, faces, texture, tex_h, tex_w, poses,
                      K_host, pixel_means_host, V, F, B, H, W, znear, zfar);
 }
@@ -232,6 +233,7 @@ extern "C" int deepim_render_update_forward(deepim_ctx* ctx, float* image, float
                                             int tex_h, int tex_w, const float* poses, const float* K_host,
                                             const float* pixel_means_host, int V, int F, int B, int H, int W,
                                             float znear, float zfar) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(mask_rendered != nullptr, "render_update: mask_rendered is NULL");
   return render_impl(ctx, image, depth, mask_rendered, mask_box, mask_thresh, vertices, vertex_attr, faces, texture, tex_h,
                      tex_w, poses, K_host, pixel_means_host, V, F, B, H, W, znear, zfar);

@@ -45,16 +45,12 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
     delete c;
     return (int)e;
   }
-  // status word + the bbox accumulators of deepim_mask_box_forward ({INT_MAX,-1,INT_MAX,-1} per sample, two sets)
-  const size_t box_bytes = (size_t)2 * DI_MAX_BOX_SAMPLES * 4 * sizeof(int);
+  // status word + the bbox accumulators of deepim_mask_box_forward
+  const size_t box_bytes = (size_t)DI_MAX_BOX_SAMPLES * 4 * sizeof(int);
   e = hipMalloc((void**)&c->status, 64 + box_bytes);
   if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 64, c->stream);
   if (e == hipSuccess) {
     c->box_words = c->status + 16;
-    c->box_parity = 0;
-    std::vector<int> init((size_t)2 * DI_MAX_BOX_SAMPLES * 4);
-    for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0x7fffffff; init[i + 1] = -1; }
-    e = hipMemcpy(c->box_words, init.data(), box_bytes, hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     deepim_set_error("hipMalloc(status)", e);
@@ -68,7 +64,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
 
 extern "C" int deepim_destroy(deepim_ctx* ctx) {
   if (!ctx) return 0;
-  hipSetDevice(ctx->device);
+  DI_DEVICE(ctx);
   hipStreamSynchronize(ctx->stream);
   for (auto g : ctx->graphs) hipGraphExecDestroy(g);
   for (auto e : ctx->timer_start) hipEventDestroy(e);
@@ -100,37 +96,42 @@ int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
 }
 
 extern "C" int deepim_malloc(deepim_ctx* ctx, size_t bytes, void** dptr) {
-  DI_CHECK(hipSetDevice(ctx->device));
+  DI_DEVICE(ctx);
   DI_CHECK(hipMalloc(dptr, bytes ? bytes : 4));
   return 0;
 }
 extern "C" int deepim_free(deepim_ctx* ctx, void* dptr) {
+  DI_DEVICE(ctx);
   if (!dptr) return 0;
-  DI_CHECK(hipSetDevice(ctx->device));
   DI_CHECK(hipStreamSynchronize(ctx->stream));
   DI_CHECK(hipFree(dptr));
   return 0;
 }
 extern "C" int deepim_memset(deepim_ctx* ctx, void* dptr, int value, size_t bytes) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipMemsetAsync(dptr, value, bytes, ctx->stream));
   return 0;
 }
 extern "C" int deepim_h2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   DI_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 extern "C" int deepim_d2h(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DI_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 extern "C" int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
 extern "C" int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff, const float* src, int C,
                                     int B, size_t hw) {
+  DI_DEVICE(ctx);
   if (B == 0 || C == 0) return 0;
   DI_CHECK(hipMemcpy2DAsync(dst + (size_t)dst_coff * hw, (size_t)dst_ctotal * hw * sizeof(float), src,
                             (size_t)C * hw * sizeof(float), (size_t)C * hw * sizeof(float), (size_t)B,
@@ -138,6 +139,7 @@ extern "C" int deepim_copy_channels(deepim_ctx* ctx, float* dst, int dst_ctotal,
   return 0;
 }
 extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
+  DI_DEVICE(ctx);
   if (strcmp(name, "conv_max_split") == 0) {
     DI_REQUIRE(value >= 0, "conv_max_split must be >= 0");
     ctx->conv_max_split = value;
@@ -160,12 +162,14 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   return -1;
 }
 extern "C" int deepim_sync(deepim_ctx* ctx) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 extern "C" void* deepim_stream(deepim_ctx* ctx) { return (void*)ctx->stream; }
 
 extern "C" int deepim_timer_create(deepim_ctx* ctx, int* timer_id) {
+  DI_DEVICE(ctx);
   hipEvent_t a, b;
   DI_CHECK(hipEventCreate(&a));
   DI_CHECK(hipEventCreate(&b));
@@ -175,16 +179,19 @@ extern "C" int deepim_timer_create(deepim_ctx* ctx, int* timer_id) {
   return 0;
 }
 extern "C" int deepim_timer_start(deepim_ctx* ctx, int id) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(id >= 0 && id < (int)ctx->timer_start.size(), "bad timer id");
   DI_CHECK(hipEventRecord(ctx->timer_start[id], ctx->stream));
   return 0;
 }
 extern "C" int deepim_timer_stop(deepim_ctx* ctx, int id) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(id >= 0 && id < (int)ctx->timer_stop.size(), "bad timer id");
   DI_CHECK(hipEventRecord(ctx->timer_stop[id], ctx->stream));
   return 0;
 }
 extern "C" int deepim_timer_elapsed_ms(deepim_ctx* ctx, int id, float* ms) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(id >= 0 && id < (int)ctx->timer_stop.size(), "bad timer id");
   DI_CHECK(hipEventSynchronize(ctx->timer_stop[id]));
   DI_CHECK(hipEventElapsedTime(ms, ctx->timer_start[id], ctx->timer_stop[id]));
@@ -192,12 +199,14 @@ extern "C" int deepim_timer_elapsed_ms(deepim_ctx* ctx, int id, float* ms) {
 }
 
 extern "C" int deepim_graph_begin(deepim_ctx* ctx) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(!ctx->capturing, "graph capture already open");
   DI_CHECK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   ctx->capturing = true;
   return 0;
 }
 extern "C" int deepim_graph_end(deepim_ctx* ctx, int* graph_id) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(ctx->capturing, "no graph capture open");
   hipGraph_t g;
   ctx->capturing = false;
@@ -214,6 +223,7 @@ extern "C" int deepim_graph_end(deepim_ctx* ctx, int* graph_id) {
   return 0;
 }
 extern "C" int deepim_graph_launch(deepim_ctx* ctx, int graph_id) {
+  DI_DEVICE(ctx);
   DI_REQUIRE(graph_id >= 0 && graph_id < (int)ctx->graphs.size(), "bad graph id");
   DI_CHECK(hipGraphLaunch(ctx->graphs[graph_id], ctx->stream));
   return 0;

@@ -452,6 +452,7 @@ Vec3 vec3_from(const float* h, float dflt) {
 extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
                                    const float* se3, const float* T_means_host, const float* T_stds_host,
                                    int rot_coord, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
   hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
@@ -463,6 +464,7 @@ extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pos
 extern "C" int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot, float* trans, const float* pose_src,
                                     const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
                                     int rot_coord, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "calc_rt_delta: unknown rot_coord");
   hipLaunchKernelGGL(calc_rt_delta_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rot, trans, pose_src,
@@ -473,6 +475,7 @@ extern "C" int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot, float* trans, c
 
 extern "C" int deepim_pose_error(deepim_ctx* ctx, float* out, const float* pose_est, const float* pose_gt,
                                  const float* points, int points_shared, const float* K_host, int B, int N) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(N > 0, "pose_error: need at least one model point");
   Mat3 K;
@@ -487,6 +490,7 @@ extern "C" int deepim_transform3d_forward(deepim_ctx* ctx, float* out, const flo
                                           const float* translation, const float* pose_src,
                                           const float* T_means_host, const float* T_stds_host, int rot_coord, int B,
                                           int N) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "transform3d: unknown rot_coord");
   void* scratch;
@@ -505,6 +509,7 @@ extern "C" int deepim_transform3d_backward(deepim_ctx* ctx, float* d_rotation, f
                                            const float* translation, const float* pose_src,
                                            const float* T_means_host, const float* T_stds_host, int rot_coord, int B,
                                            int N) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "transform3d: unknown rot_coord");
   hipLaunchKernelGGL(t3d_backward_kernel, dim3(B), dim3(256), 0, ctx->stream, d_rotation, d_translation, out_grad,

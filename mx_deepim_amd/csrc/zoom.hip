@@ -96,7 +96,7 @@ __global__ void zoom_factor_kernel(float* __restrict__ zoom_factor, int* __restr
   if (real[1] < 0) {  // reference raises ValueError (np.min of empty) — flag it
     const float nanv = __int_as_float(0x7fc00000);
     zf[0] = zf[1] = zf[2] = zf[3] = nanv;
-    atomicOr(status, 1);
+    atomicOr(status, DI_STATUS_ZOOM_EMPTY);
     return;
   }
   const double rsx = real[0], rex = real[1], rsy = real[2], rey = real[3];
@@ -400,6 +400,7 @@ extern "C" int deepim_zoom_mask_forward(deepim_ctx* ctx, const float* mask_obser
                                         const float* mask_rendered, const float* src_pose, const float* K_host,
                                         float* zoom_mask_observed, float* zoom_mask_gt_observed,
                                         float* zoom_mask_rendered, float* zoom_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   int rc = compute_zoom_factor(ctx, zoom_factor, mask_gt_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
                                src_pose, K_host, B, H, W);
@@ -425,6 +426,7 @@ extern "C" int deepim_zoom_image_forward(deepim_ctx* ctx, const float* image_obs
                                          const float* src_pose, const float* K_host, const float* pixel_means_host,
                                          float* zoom_image_observed, float* zoom_image_rendered, float* zoom_factor,
                                          int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   int rc = compute_zoom_factor(ctx, zoom_factor, image_observed, image_rendered, BB_IMAGE, BB_IMAGE, pixel_means_host,
                                src_pose, K_host, B, H, W);
@@ -441,6 +443,7 @@ extern "C" int deepim_zoom_image_with_factor_forward(deepim_ctx* ctx, const floa
                                                      const float* pixel_means_host, int high_light_center,
                                                      float* zoom_image_observed, float* zoom_image_rendered, int B,
                                                      int H, int W) {
+  DI_DEVICE(ctx);
   const long p = (long)H * W;
   Plan plan; plan.n = 6; plan.inverse = 0;
   image_plan(plan, 0, image_observed, zoom_image_observed, 3 * p, 3 * p, p, pixel_means_host, 0, 0);
@@ -451,6 +454,7 @@ extern "C" int deepim_zoom_image_with_factor_forward(deepim_ctx* ctx, const floa
 extern "C" int deepim_zoom_depth_forward(deepim_ctx* ctx, const float* zoom_factor, const float* depth_observed,
                                          const float* depth_rendered, float* zoom_depth_observed,
                                          float* zoom_depth_rendered, int B, int H, int W) {
+  DI_DEVICE(ctx);
   const long p = (long)H * W;
   Plan plan; plan.n = 2; plan.inverse = 0;
   plan.ch[0] = make_chan(depth_observed, zoom_depth_observed, p, p, 0.f, 0);
@@ -461,6 +465,7 @@ extern "C" int deepim_zoom_depth_forward(deepim_ctx* ctx, const float* zoom_fact
 extern "C" int deepim_zoom_flow_forward(deepim_ctx* ctx, const float* zoom_factor, const float* flow,
                                         const float* flow_weights, float* zoom_flow, float* zoom_flow_weights,
                                         int b_inv_zoom, int B, int H, int W) {
+  DI_DEVICE(ctx);
   const long p = (long)H * W;
   Plan plan; plan.n = 2; plan.inverse = b_inv_zoom ? 1 : 0;
   const int fl = b_inv_zoom ? CF_POST_MUL_WX : CF_POST_DIV_WX;
@@ -477,6 +482,7 @@ extern "C" int deepim_zoom_flow_forward(deepim_ctx* ctx, const float* zoom_facto
 
 extern "C" int deepim_zoom_mask_with_factor_forward(deepim_ctx* ctx, const float* zoom_factor, const float* mask,
                                                     float* zoom_mask, int b_inv_zoom, int B, int H, int W) {
+  DI_DEVICE(ctx);
   const long p = (long)H * W;
   Plan plan; plan.n = 1; plan.inverse = b_inv_zoom ? 1 : 0;
   plan.ch[0] = make_chan(mask, zoom_mask, p, p, 0.f, CF_PRE_BIN02 | CF_POST_ROUND);
@@ -486,6 +492,7 @@ extern "C" int deepim_zoom_mask_with_factor_forward(deepim_ctx* ctx, const float
 // mask head test path, fused: sigmoid → (>0.2) → inverse zoom → round → round (deepIM_flownet.py:647-666)
 extern "C" int deepim_mask_head_forward(deepim_ctx* ctx, float* mask_pred, float* prob, const float* logits,
                                         const float* zoom_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
   const long p = (long)H * W;
   Plan plan; plan.n = 1; plan.inverse = 1;
   plan.ch[0] = make_chan(logits, mask_pred, p, p, 0.f, CF_PRE_SIGMOID | CF_PRE_BIN02 | CF_POST_ROUND);
@@ -496,6 +503,7 @@ extern "C" int deepim_mask_head_forward(deepim_ctx* ctx, float* mask_pred, float
 
 extern "C" int deepim_zoom_trans_forward(deepim_ctx* ctx, const float* zoom_factor, const float* trans_delta,
                                          float* zoom_trans_delta, int b_inv_zoom, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(zoom_trans_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, zoom_trans_delta,
                      zoom_factor, trans_delta, b_inv_zoom ? 1 : 0, 1, B);
@@ -504,6 +512,7 @@ extern "C" int deepim_zoom_trans_forward(deepim_ctx* ctx, const float* zoom_fact
 }
 extern "C" int deepim_zoom_trans_backward(deepim_ctx* ctx, const float* zoom_factor, const float* out_grad,
                                           float* in_grad, int b_inv_zoom, int b_zoom_grad, int B) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(zoom_trans_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, in_grad, zoom_factor,
                      out_grad, b_inv_zoom ? 1 : 0, b_zoom_grad ? 1 : 0, B);
@@ -516,6 +525,7 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
                                           const float* depth_observed, const float* depth_rendered,
                                           const float* src_pose, const float* K_host, const float* pixel_means_host,
                                           float* net_input, float* zoom_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((mask_observed == nullptr) == (mask_rendered == nullptr), "zoom_concat: pass both masks or neither");
   const bool with_mask = mask_observed != nullptr;
@@ -548,6 +558,7 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
 }
 
 extern "C" int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
   dim3 grid(di_div_up(W, 256), H, B);
@@ -557,6 +568,7 @@ extern "C" int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, in
 }
 
 extern "C" int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_factor, float* inv_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
   if (B == 0) return 0;
   hipLaunchKernelGGL(inverse_factor_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, inv_factor, zoom_factor, B, H, W);
   DI_LAUNCH_CHECK();
@@ -566,6 +578,7 @@ extern "C" int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_fac
 // status word of the last zoom-factor computation: bit0 = an observed mask/image was empty
 // (sticky until read; reading clears it)
 extern "C" int deepim_zoom_status(deepim_ctx* ctx, int* status) {
+  DI_DEVICE(ctx);
   DI_CHECK(hipMemcpyAsync(status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   DI_CHECK(hipMemsetAsync(ctx->status, 0, sizeof(int), ctx->stream));
   DI_CHECK(hipStreamSynchronize(ctx->stream));

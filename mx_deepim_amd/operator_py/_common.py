@@ -45,3 +45,7 @@ def check_zoom_status(ctx, what):
                          "observed mask/image has no valid pixel)" % what)
     if st.value & 2:
         raise AssertionError("%s: group index out of range" % what)
+    if st.value & 4:
+        # data_pair.py:98 / utils/image.py:366: np.min of the empty nonzero() of the rendered mask
+        raise ValueError("zero-size array to reduction operation minimum which has no identity (%s: "
+                         "rendered mask is empty, no box_rendered rectangle)" % what)

@@ -191,7 +191,7 @@ def test_updater_closes_the_loop_on_device(ctx, small_batch):
 
 def test_mask_box_matches_reference_rectangle(ctx):
     """deepim_mask_box_forward == the [y_start:y_end, x_start:x_end] rectangle of data_pair.py:94-105 (exclusive ends),
-    twice in a row (the bbox accumulators are double-buffered and re-armed on the device)."""
+    repeatedly and with changing batch sizes (the bbox accumulators are armed on the device inside every call)."""
     from oracle import flow as oflow
     rng = np.random.default_rng(8)
     B, H, W = 5, 48, 70
@@ -208,17 +208,50 @@ def test_mask_box_matches_reference_rectangle(ctx):
         for b in range(B):
             np.testing.assert_array_equal(got[b, 0], oflow.mask_box(masks[b, 0]))
         masks = np.ascontiguousarray(masks[::-1])         # different boxes next time: stale accumulators would show
+    # alternating batch sizes (class runs of 3 then 5 samples, a partial batch followed by a full one): the accumulators are
+    # armed inside every call, so entries beyond the previous call's B never carry an old box
+    for n in (3, 5, 2, 5, 1, 4):
+        sub = np.ascontiguousarray(masks[rng.permutation(B)[:n]])
+        box = ctx.empty((n, 1, H, W))
+        lib.deepim_mask_box_forward(ctx.handle, box, ctx.array(sub), n, H, W)
+        got = box.asnumpy()
+        for b in range(n):
+            np.testing.assert_array_equal(got[b, 0], oflow.mask_box(sub[b, 0]))
     st = ctypes.c_int(-1)
     lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
     assert st.value == 0
-    # empty mask: zeros + status bit 1 (the reference raises on np.min of an empty array)
+    # empty mask: zeros + status bit 2 (value 4; the reference raises on np.min of an empty array)
     masks[2] = 0
     box = ctx.empty((B, 1, H, W))
     lib.deepim_mask_box_forward(ctx.handle, box, ctx.array(masks), B, H, W)
     assert not box.asnumpy()[2].any()
     lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
-    assert st.value & 2
+    assert st.value == 4
     lib.deepim_mask_box_forward(ctx.handle, box, box, 0, H, W)   # B = 0 no-op
+
+
+def test_fused_render_update_with_changing_batch_sizes(ctx, small_batch):
+    """update_test_batch draws one launch group per run of equal class ids, so consecutive fused render+rectangle calls
+    see different B (advisor finding, round 1): every call must produce the rectangle of ITS OWN rendered mask."""
+    from oracle import flow as oflow
+    H, W = 480, 640
+    mesh = synthetic.ellipsoid_mesh(AXES, 16, 32)
+    mesh.pop("uv")
+    rm = Render_Py("unused", ["obj"], K, W, H, meshes={"obj": mesh}, ctx=ctx, pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
+    rng = np.random.default_rng(12)
+    base = small_batch["pose_tgt"][0]
+    for n in (3, 5, 1, 5, 2):
+        poses = np.repeat(base[None], n, 0).astype(np.float32)
+        poses[:, 0, 3] += rng.uniform(-0.12, 0.12, n).astype(np.float32)
+        poses[:, 1, 3] += rng.uniform(-0.08, 0.08, n).astype(np.float32)
+        img, dep = ctx.empty((n, 3, H, W)), ctx.empty((n, 1, H, W))
+        mr, mb = ctx.empty((n, 1, H, W)), ctx.empty((n, 1, H, W))
+        rm.render_into(img, dep, 0, ctx.array(poses), mask_rendered=mr, mask_box=mb)
+        m, box = mr.asnumpy(), mb.asnumpy()
+        np.testing.assert_array_equal(m, (dep.asnumpy() > 0.2).astype(np.float32))
+        for b in range(n):
+            assert m[b].any()
+            np.testing.assert_array_equal(box[b, 0], oflow.mask_box(m[b, 0]))
 
 
 def test_update_test_batch_mirrors_tester_loop(ctx, small_batch):
