@@ -57,9 +57,9 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * size in 128x128 blocks (default 1024 = 256 CUs x 4); "conv_force_plan": dev knob, n > 0 uniform split-K,
  * n < 0 tail split with -n slices, 0 = heuristic/autotuner.
  * "conv_xcd_swizzle": 1 (default) = XCD-aware tile order, 0 = plain block order.
- * "conv_autotune": 1 (default) = on the first call of a conv geometry, time a few split-K factors and keep
- * the fastest; 0 = heuristic only ("conv_split_below"/"conv_split_target": split when the grid has fewer
- * than `below` blocks, aiming at `target`). "conv_tile256": 1 = 256x128 tiles on 512-thread blocks when
+ * "conv_autotune": 0 (default) = the split-K factor of an under-filled conv grid comes from a deterministic cost
+ * model (same geometry → same summation order in every run, process and rank); 1 = on the first call of a conv
+ * geometry, time a few split-K factors and keep the fastest (plans then depend on timing noise). "conv_tile256": 1 = 256x128 tiles on 512-thread blocks when
  * Cout % 256 == 0 (default 0: measured no faster than 128x128). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
@@ -71,6 +71,22 @@ int deepim_timer_elapsed_ms(deepim_ctx* ctx, int timer_id, float* ms);  /* syncs
 int deepim_graph_begin(deepim_ctx* ctx);
 int deepim_graph_end(deepim_ctx* ctx, int* graph_id);
 int deepim_graph_launch(deepim_ctx* ctx, int graph_id);
+
+/* ------------------------------------------------ multi-GPU: pose all-gather over RCCL/xGMI -- */
+/* pairs shard across GPUs with no data-path collective except ONE all-gather of the refined poses per
+ * refinement iteration, so that every rank/host holds all poses for the next render/update — the role of the per-device
+ * executor group's merged outputs in the reference (deepim/core/DataParallelExecutorGroup.py:364-388, deepim/test.py:135).
+ * One process per GPU; librccl.so is dlopen'ed on first use; no PyTorch. Bootstrap: rank 0 makes the id, ships the bytes
+ * out of band (mx_deepim_amd/parallel.py does it over a TCP rendezvous), every rank calls deepim_comm_init. */
+#define DEEPIM_COMM_ID_BYTES 128
+int deepim_comm_unique_id(void* id_bytes /* DEEPIM_COMM_ID_BYTES, host */);
+int deepim_comm_init(deepim_ctx* ctx, int rank, int world, const void* id_bytes);
+int deepim_comm_destroy(deepim_ctx* ctx);
+/* all_poses (world*B,3,4) device <- poses (B,3,4) device of every rank, rank-major; one asynchronous enqueue on the
+ * context stream (a plain copy when no communicator is set) */
+int deepim_allgather_poses(deepim_ctx* ctx, float* all_poses, const float* poses, int B);
+/* in-place all-reduce of n device doubles on the context stream: op 0 = max, 1 = sum (bench.py's max-over-ranks time) */
+int deepim_comm_allreduce_f64(deepim_ctx* ctx, double* buf, int n, int op);
 
 /* ------------------------------------------------ F-group: depth warp / flow -- */
 /* B2 drop-in. Same symbol, argument list and host-pointer contract as

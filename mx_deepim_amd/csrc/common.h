@@ -26,6 +26,8 @@ struct deepim_ctx {
   size_t scratch_bytes;
   std::vector<void*> retired_scratch;  // outgrown scratch buffers still referenced by captured graphs
   int* status;  // persistent device status word, bits DI_STATUS_*
+  void* comm;        // ncclComm_t of this rank (csrc/comm.hip), NULL in a single-GPU process
+  int comm_rank, comm_world;
   int* box_words;   // DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: bbox accumulators of mask_box, armed inside every call
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
@@ -39,10 +41,9 @@ struct deepim_ctx {
   int conv_force_plan;  // dev: 0 = off, n > 0 = uniform split-K n, n < 0 = tail split with -n slices
   int conv_tail_slots;  // resident 128x128 blocks of the LDS-free kernel on the whole chip (256 CUs x 4): round size for the tail split
   int conv_tile256;   // 1: 256x128 tiles (512-thread blocks) when Cout % 256 == 0 (default 0)
-  int conv_autotune;  // 1 (default): time split-K candidates on the first call of a geometry
+  int conv_autotune;  // 1: time split-K candidates on the first call of a geometry (default 0: deterministic cost-model plan)
   int conv_max_split;  // 0 auto, 1 off, n cap
   int conv_xcd_swizzle;  // 1: XCD-aware tile order (default), 0: plain
-  int conv_split_below, conv_split_target;  // split K when blocks < below, aiming at ~target blocks
 };
 
 void deepim_set_error(const char* where, hipError_t e);

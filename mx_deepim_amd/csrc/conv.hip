@@ -1088,18 +1088,32 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
 }
 
 struct TileChoice { int bm, bn, ksplit, tail_s; };
-// Tile/split heuristic for 256 CUs × 3 resident blocks: 128x128 (best MFMA density per LDS byte and per
-// gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the chip under-filled, split K
-// across grid.z (deterministic two-pass reduction) before shrinking the tile.
+// Tile/split plan, deterministic (the same geometry gets the same summation order in every run, process and rank):
+// 128x128 tiles (best MFMA density per gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the
+// chip under-filled, split K across grid.z (fixed-order two-pass reduction). The split factor minimises a cost model
+// fitted to what the timing autotuner picked on MI355X at B = 1 … 32 (profiles/r02_conv_plans.md):
+//   cost(s) = ceil(tiles·s / 256) · ceil(nchunk / s)        MFMA time: blocks sharing a CU share its matrix pipes, so what
+//                                                            counts is the most loaded CU, in units of one K chunk (≈1 µs)
+//           + [s > 1] · (3 + 0.016 · tiles · s)             split-K reduce: launch + 64 KB of partial sums per block
+// over s ∈ {1,2,3,4,6,8,10,12,16,20,24}, s ≤ nchunk/4, tiles·s ≤ 4096; ties go to the smaller s.
+int plan_ksplit(long tiles, int nchunk) {
+  const int cands[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24};
+  float best = 1e30f;
+  int best_s = 1;
+  for (int s : cands) {
+    if (s > 1 && (tiles * s > 4096 || s > max(1, nchunk / 4))) continue;
+    const float cost = (float)di_div_up(tiles * s, 256) * (float)di_div_up(nchunk, s) +
+                       (s > 1 ? 3.f + 0.016f * (float)(tiles * s) : 0.f);
+    if (cost < best * 0.985f) { best = cost; best_s = s; }
+  }
+  return best_s;
+}
 TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, int classes, bool wide64 = false) {
-  const int below = ctx->conv_split_below, target = ctx->conv_split_target;
   int bm = 128, bn = 128;
   if (Cout <= 64) { bm = 64; bn = (wide64 || npix >= 256L * 1024) ? 256 : 128; }   // wide64: the only 64-row LDS-free shape
   else if (ctx->conv_tile256 && Cout % 256 == 0) bm = 256;   // 8-wave block: every gathered activation feeds 256 channels
-  const long blocks = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
-  int ks = 1;
-  if (blocks < below) ks = (int)min((long)di_div_up(target, blocks), (long)max(1, nchunk / 8));
-  return {bm, bn, ks, 0};
+  const long tiles = (long)di_div_up(Cout, bm) * di_div_up(npix, bn) * classes;
+  return {bm, bn, plan_ksplit(tiles, nchunk), 0};
 }
 
 template <int MODE>
@@ -1170,14 +1184,15 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   return 0;
 }
 
-// First call of a geometry (outside graph capture): time a few split-K factors around the heuristic with
-// HIP events and remember the fastest. The kernel is idempotent, so the trial launches only rewrite `out`.
+// Opt-in ("conv_autotune" = 1; default 0 so that plans never depend on wall-clock noise): on the first call of a
+// geometry (outside graph capture) time a few split-K factors with HIP events and remember the fastest. The kernel is
+// idempotent, so the trial launches only rewrite `out`.
 template <int MODE>
 int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
   TileChoice t = choose_tile(ctx, p.Cout, p.npix, p.nchunk, classes, p.out_nc8 != 0);
   const ConvPlanKey key = {MODE, p.B, p.Cin, p.H, p.W, p.Cout, p.Ho, p.Wo, p.stride, p.pad, p.nchunk,
-                           ctx->conv_split_below * 16 + ctx->conv_tail_split * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0) + 1024 * (p.in_nc8 * 2 + p.out_nc8),
-                           ctx->conv_split_target};
+                           ctx->conv_tail_split * 8 + ctx->conv_tile256 * 4 + (p.tab2 != nullptr ? ctx->conv_direct : 0) + 1024 * (p.in_nc8 * 2 + p.out_nc8),
+                           0};
   if (ctx->conv_autotune && ctx->conv_max_split != 1) {
     bool found = false;
     for (auto& e : ctx->conv_plans)
@@ -1320,6 +1335,24 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
+  {
+    // the kernels address the input through one raw-buffer descriptor with bit 31 of the offset as the padding marker,
+    // so a launch sees < 2 GiB of input; larger batches run as consecutive sub-batches (samples are independent)
+    const size_t per_sample = (size_t)Cin * H * W * 4, limit = 0x7fffffffUL - (size_t)(pad * W + pad) * 4;
+    if ((size_t)B * per_sample >= limit) {
+      const int Bc = (int)((limit - 1) / per_sample);
+      DI_REQUIRE(Bc >= 1, "conv2d: one sample exceeds 2 GiB");
+      const int Ho_ = (H + 2 * pad - kh) / stride + 1, Wo_ = (W + 2 * pad - kw) / stride + 1;
+      const size_t out_sample = (size_t)(out_ctotal > 0 ? out_ctotal : Cout) * Ho_ * Wo_;
+      for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int rc = deepim_conv2d_forward_ex(ctx, out + (size_t)b0 * out_sample, in + (size_t)b0 * Cin * H * W, packed_w, bias,
+                                                min(Bc, B - b0), Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
+                                                out_coff, in_nc8, out_nc8);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   ConvParams p;
   p.in = in; p.wp = packed_w; p.bias = bias; p.out = out;
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;

@@ -28,17 +28,18 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->capturing = false;
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
   c->conv_max_split = 0;
   c->conv_xcd_swizzle = 1;
-  c->conv_autotune = 1;
+  c->conv_autotune = 0;
   c->conv_direct = 1;
   c->conv_tail_slots = 1024;
   c->conv_force_plan = 0;
   c->fc_slices = 0;
   c->conv_tail_split = 0;
   c->conv_tile256 = 0;   // measured: 113.1 vs 113.7 TF for 128x128 — kept as an option, off by default
-  c->conv_split_below = 512;
-  c->conv_split_target = 768;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     deepim_set_error("hipStreamCreate", e);
@@ -66,6 +67,7 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
   if (!ctx) return 0;
   DI_DEVICE(ctx);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) deepim_comm_destroy(ctx);
   for (auto g : ctx->graphs) hipGraphExecDestroy(g);
   for (auto e : ctx->timer_start) hipEventDestroy(e);
   for (auto e : ctx->timer_stop) hipEventDestroy(e);
@@ -145,8 +147,6 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
     ctx->conv_max_split = value;
     return 0;
   }
-  if (strcmp(name, "conv_split_below") == 0) { ctx->conv_split_below = value; return 0; }
-  if (strcmp(name, "conv_split_target") == 0) { ctx->conv_split_target = value > 0 ? value : 1; return 0; }
   if (strcmp(name, "conv_direct") == 0) { ctx->conv_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (strcmp(name, "fc_slices") == 0) { ctx->fc_slices = value > 0 ? value : 0; return 0; }
   if (strcmp(name, "conv_tail_split") == 0) { ctx->conv_tail_split = value ? 1 : 0; return 0; }

@@ -59,7 +59,7 @@ def _cases(small_batch):
 def test_flow_bit_exact_vs_reference_kernel_without_contraction(ctx, small_batch):
     for name, src, tgt, KT, Kinv in _cases(small_batch):
         rf, rv = _ref_flow("nofma", src, tgt, KT, Kinv)
-        assert rv.sum() > 50, name
+        assert rv.sum() > 20, name
         f, v = gpu_flow(src, tgt, KT, Kinv)                       # the `_flow` drop-in (host pointers)
         np.testing.assert_array_equal(v, rv, err_msg=name)
         np.testing.assert_array_equal(f.view(np.uint32), rf.view(np.uint32), err_msg=name)

@@ -361,3 +361,46 @@ def test_copy_channels(ctx):
     got = dst.asnumpy()
     np.testing.assert_array_equal(got[:, 2:7], src)
     assert not got[:, :2].any() and not got[:, 7:].any()
+
+
+def test_conv_input_over_2gib_runs_as_sub_batches(ctx):
+    """A conv2-shaped launch whose input tensor exceeds 2 GiB (B = 112 at 64x240x320; the raw-buffer descriptor of one
+    launch addresses < 2 GiB) is run as consecutive sub-batches: every sample equals the same sample run alone."""
+    rng = np.random.default_rng(21)
+    B, cin, H, W, cout, k, s, pd = 112, 64, 240, 320, 128, 5, 2, 2
+    assert B * cin * H * W * 4 > 2 ** 31
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    pk, db = _pack_conv(ctx, w), ctx.array(bias)
+    base = rng.standard_normal((4, cin, H, W)).astype(np.float32)
+    x = ctx.empty((B, cin, H, W))
+    per = cin * H * W * 4
+    for b in range(B):   # samples cycle through 4 patterns, scaled so every sample differs
+        lib.deepim_h2d(ctx.handle, ctypes.c_void_p(x.ptr + b * per), np.ascontiguousarray(base[b % 4] * np.float32(1 + b // 4)), per)
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)   # one canonical chain per output: independent of B
+    try:
+        ho, wo = 120, 160
+        out = ctx.empty((B, cout, ho, wo))
+        lib.deepim_conv2d_forward(ctx.handle, out, x, pk, db, B, cin, H, W, cout, k, k, s, pd, cf(0.1), 0, 0)
+        one = ctx.empty((1, cout, ho, wo))
+        full = out.asnumpy()
+        for b in (0, 53, 54, 108, 109, 111):   # both sides of the sub-batch boundaries (108 samples fit in 2 GiB)
+            xb = ctx.array(np.ascontiguousarray(base[b % 4] * np.float32(1 + b // 4))[None])
+            lib.deepim_conv2d_forward(ctx.handle, one, xb, pk, db, 1, cin, H, W, cout, k, k, s, pd, cf(0.1), 0, 0)
+            np.testing.assert_array_equal(full[b], one.asnumpy()[0])
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+
+
+def test_default_split_k_plan_is_deterministic(ctx):
+    """The default plan comes from a cost model, not from timings: two fresh contexts' worth of calls (here: the same
+    geometry launched repeatedly, and after an unrelated geometry) give bit-identical split-K results."""
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((2, 512, 15, 20)).astype(np.float32)
+    w = (rng.standard_normal((512, 512, 3, 3)) / 68).astype(np.float32)
+    a = _run_conv(ctx, x, w, None, 1, 1, 0.1)
+    _run_conv(ctx, rng.standard_normal((1, 8, 40, 40)).astype(np.float32), (rng.standard_normal((64, 8, 3, 3)) / 8).astype(np.float32), None, 1, 1, 0.1)
+    b = _run_conv(ctx, x, w, None, 1, 1, 0.1)
+    np.testing.assert_array_equal(a, b)
+    ref = onet.conv2d(x, w, None, 1, 1, 0.1)
+    assert np.abs(a - ref).max() <= 1e-5 * np.abs(ref).max()

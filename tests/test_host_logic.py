@@ -75,29 +75,55 @@ def test_shard_bounds_cover_all_pairs():
     assert s["image_observed"].shape[0] == 2 and s["image_rendered"].shape[:2] == (2, 2) and s["K"].shape == (3, 3)
 
 
-def _gather_worker(rank, world, port, counts, q):
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = parallel.shard_bounds(sum(counts), world, rank)
-    allp = torch.arange(sum(counts) * 12, dtype=torch.float32).reshape(-1, 3, 4)
-    got = parallel.all_gather_poses(allp[lo:hi].clone(), dist, counts)
-    q.put((rank, bool(torch.equal(got, allp))))
-    dist.destroy_process_group()
+def _rdzv_worker(rank, world, port, counts, q):
+    try:
+        rd = parallel.Rendezvous(rank, world, "127.0.0.1", port)
+        allp = np.arange(sum(counts) * 12, dtype=np.float32).reshape(-1, 3, 4)
+        lo, hi = parallel.shard_bounds(sum(counts), world, rank)
+        got = parallel.gather_padded(rd, allp[lo:hi], counts)
+        uid = rd.broadcast(bytes(range(128)) if rank == 0 else None)          # the RCCL unique-id bootstrap
+        ok = np.array_equal(got, allp) and uid == bytes(range(128)) and rd.max(rank * 1.5) == (world - 1) * 1.5
+        rd.barrier()
+        rd.close()
+        q.put((rank, bool(ok)))
+    except Exception as e:   # surface the failure instead of a queue timeout
+        q.put((rank, repr(e)))
 
 
 @pytest.mark.parametrize("counts", [[4, 4], [3, 2]])
-def test_all_gather_poses_gloo_world2(counts):
-    import torch.multiprocessing as mp
+def test_rendezvous_all_gather_world2(counts):
+    """The N > 1 host path without torch: two processes, TCP star on 127.0.0.1, even and ragged pose shards."""
+    import multiprocessing as mp
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29500 + os.getpid() % 2000 + len(set(counts))
-    procs = [ctxm.Process(target=_gather_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+    port = 31000 + os.getpid() % 2000 + len(set(counts))
+    procs = [ctxm.Process(target=_rdzv_worker, args=(r, 2, port, counts, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_rendezvous_single_rank_is_a_no_op():
+    rd = parallel.Rendezvous(0, 1)
+    assert rd.all_gather("x") == ["x"] and rd.max(2.5) == 2.5 and rd.broadcast(b"id") == b"id"
+    rd.barrier()
+    rd.close()
+
+
+@pytest.mark.parametrize("counts", ["2,2", "3,2"])
+def test_rendezvous_under_torchrun_matches_gloo(counts):
+    """Launched the way the driver launches bench.py (torch.distributed.run, 2 ranks): the Rendezvous picks up RANK /
+    WORLD_SIZE / MASTER_* from the launcher and its pose gather equals torch.distributed's gloo all-gather."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 33000 + os.getpid() % 2000 + len(counts) + int(counts[0])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_rdzv_worker.py"),
+                        counts], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -22,8 +22,6 @@ def main():
     ap.add_argument("--swizzle", type=int, default=1)
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--tile256", type=int, default=0)
-    ap.add_argument("--below", type=int, default=512)
-    ap.add_argument("--target", type=int, default=768)
     ap.add_argument("--direct", type=int, default=0, help="1: LDS-free register-fed conv kernel")
     ap.add_argument("--maxsplit", type=int, default=0)
     ap.add_argument("--nc8", type=int, default=1, help="1: channel-blocked activations between the layers (default)")
@@ -40,8 +38,6 @@ def main():
     from mx_deepim_amd.runtime import lib
     lib.deepim_set_option(ctx.handle, b"conv_xcd_swizzle", a.swizzle)
     lib.deepim_set_option(ctx.handle, b"conv_tile256", a.tile256)
-    lib.deepim_set_option(ctx.handle, b"conv_split_below", a.below)
-    lib.deepim_set_option(ctx.handle, b"conv_split_target", a.target)
     lib.deepim_set_option(ctx.handle, b"conv_max_split", a.maxsplit)
     if a.check and not a.fp16:
         rng = np.random.default_rng(0)
