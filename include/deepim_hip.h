@@ -267,6 +267,22 @@ int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, co
 int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot /*B,4*/, float* trans /*B,3*/, const float* pose_src,
                          const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
                          int rot_coord, int B);
+/* RT_transform with an Euler-angle rotation (ROT_TYPE EULER: r.shape[0] == 3 → euler2mat(r0, r1, r2), static xyz axes,
+ * RT_transform.py:130-131, :240-307): euler_trans (B,6) = [euler(3) | trans(3)]. */
+int deepim_rt_transform_euler(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
+                              const float* euler_trans, const float* T_means_host, const float* T_stds_host,
+                              int rot_coord, int B);
+/* calc_RT_delta with the reference's rot_type switch (RT_transform.py:34-41): 0 QUAT → rot (B,4), 1 EULER (mat2euler
+ * sxyz, :310-373) → rot (B,3), 2 MATRIX → rot (B,9). */
+int deepim_calc_rt_delta_ex(deepim_ctx* ctx, float* rot, float* trans, const float* pose_src, const float* pose_tgt,
+                            const float* T_means_host, const float* T_stds_host, int rot_coord, int rot_type, int B);
+/* the rotation converters of RT_transform.py as batched ops, float64 results like the reference's:
+ * op 0 quat2mat (:383-429; in (B,4) → out (B,9)), 1 mat2quat (:432-509; (B,9) → (B,4), w >= 0),
+ * 2 euler2mat sxyz (:240-307; (B,3) → (B,9)), 3 mat2euler sxyz (:310-373; (B,9) → (B,3)) */
+int deepim_rot_convert(deepim_ctx* ctx, double* out, const float* in, int op, int B);
+/* calc_se3 (RT_transform.py:176-187): se3_mul(pose_tgt, se3_inverse(pose_src)) in float32 (lib/utils/projection.py:12-43)
+ * → rotm (B,3,3), t (B,3) */
+int deepim_calc_se3(deepim_ctx* ctx, float* rotm, float* t, const float* pose_src, const float* pose_tgt, int B);
 /* Pose-error metrics of lib/utils/pose_error.py (used by the evaluate_pose functions of LM6D_REFINE.py:278-512 and by
  * tester.py:401): per pair out[b] = { re (:118-124, geodesic angle in degrees; == calc_rt_dist_m's rd_deg),
  * te (:127-145, ||t_gt - t_est||), add (:55-69), adi (:72-88, nearest-neighbour mean, brute force instead of a

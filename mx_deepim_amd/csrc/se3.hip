@@ -44,22 +44,56 @@ __device__ void t_transform_f64(const float* Tsrc, const float* Td, const Vec3d&
   }
 }
 
+// euler2mat(ai, aj, ak, 'sxyz') (RT_transform.py:240-307, the default axes RT_transform calls it with at :131):
+// math.sin/cos take Python floats, so everything is float64
+__device__ void euler2mat_sxyz_f64(double ai, double aj, double ak, double* M) {
+  const double si = sin(ai), sj = sin(aj), sk = sin(ak);
+  const double ci = cos(ai), cj = cos(aj), ck = cos(ak);
+  const double cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  M[0] = cj * ck; M[1] = sj * sc - cs; M[2] = sj * cc + ss;
+  M[3] = cj * sk; M[4] = sj * ss + cc; M[5] = sj * cs - sc;
+  M[6] = -sj;     M[7] = cj * si;      M[8] = cj * ci;
+}
+
+// mat2euler(M, 'sxyz') (RT_transform.py:310-373), float64
+__device__ void mat2euler_sxyz_f64(const double* M, double* e) {
+  const double eps4 = 2.220446049250313e-16 * 4.0;
+  const double cy = sqrt(M[0] * M[0] + M[3] * M[3]);
+  if (cy > eps4) {
+    e[0] = atan2(M[7], M[8]);
+    e[1] = atan2(-M[6], cy);
+    e[2] = atan2(M[3], M[0]);
+  } else {
+    e[0] = atan2(-M[5], M[4]);
+    e[1] = atan2(-M[6], cy);
+    e[2] = 0.0;
+  }
+}
+
+// quat2mat (RT_transform.py:383-429) on float32 scalars: eye(3) when Nq < _FLOAT_EPS (:236,412)
+__device__ void quat2mat_checked_f64(float w, float x, float y, float z, double* Rd) {
+  const float Nq = ((w * w + x * x) + y * y) + z * z;
+  if (!((double)Nq < 2.220446049250313e-16)) quat2mat_f64(w, x, y, z, Rd);
+  else for (int i = 0; i < 9; ++i) Rd[i] = (i % 4 == 0) ? 1.0 : 0.0;
+}
+
+// r_len = 4: se3 rows are [quat(4) | trans(3)] (ROT_TYPE QUAT); r_len = 3: [euler(3) | trans(3)] (ROT_TYPE EULER, :130-131)
 __global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __restrict__ pose_est64,
                                     const float* __restrict__ pose_src, const float* __restrict__ se3, Vec3d mu,
-                                    Vec3d sd, int rc, int B) {
+                                    Vec3d sd, int rc, int B, int r_len) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* P = pose_src + b * 12;
-  const float* q = se3 + b * 7;
-  const float* t = q + 4;
-  // quat = r / LA.norm(r)  (float32)
-  const float nrm = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
-  const float w = q[0] / nrm, x = q[1] / nrm, y = q[2] / nrm, z = q[3] / nrm;
+  const float* q = se3 + b * (r_len + 3);
+  const float* t = q + r_len;
   double Rd[9];
-  const float Nq = ((w * w + x * x) + y * y) + z * z;
-  // quat2mat returns eye(3) when Nq < _FLOAT_EPS (RT_transform.py:236,412)
-  if (!((double)Nq < 2.220446049250313e-16)) quat2mat_f64(w, x, y, z, Rd);
-  else for (int i = 0; i < 9; ++i) Rd[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (r_len == 3) {
+    euler2mat_sxyz_f64((double)q[0], (double)q[1], (double)q[2], Rd);
+  } else {
+    // quat = r / LA.norm(r)  (float32)
+    const float nrm = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    quat2mat_checked_f64(q[0] / nrm, q[1] / nrm, q[2] / nrm, q[3] / nrm, Rd);
+  }
   double out[12];
   if (rc == RC_NAIVE) {
     // se3_mul(se3_mx, pose_src): float64·float32 products, result cast to float32 (projection.py:26-43)
@@ -127,9 +161,41 @@ __device__ void sym4_max_eigvec(double A[4][4], double* vec) {
   for (int k = 0; k < 4; ++k) vec[k] = V[k][best];
 }
 
+// mat2quat (RT_transform.py:432-509) of a float32 3x3: float64 quaternion, w >= 0
+__device__ void mat2quat_f64(const float* Rd, double* q) {
+  // K from the 3x3 (Q_ab = contribution of input a to output b = M[b][a])
+  const double Qxx = Rd[0], Qyx = Rd[1], Qzx = Rd[2], Qxy = Rd[3], Qyy = Rd[4], Qzy = Rd[5], Qxz = Rd[6], Qyz = Rd[7],
+               Qzz = Rd[8];
+  double K[4][4] = {{Qxx - Qyy - Qzz, Qyx + Qxy, Qzx + Qxz, Qyz - Qzy},
+                    {Qyx + Qxy, Qyy - Qxx - Qzz, Qzy + Qyz, Qzx - Qxz},
+                    {Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, Qxy - Qyx},
+                    {Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz}};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) K[i][j] /= 3.0;
+  double v[4];
+  sym4_max_eigvec(K, v);
+  q[0] = v[3]; q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+  if (q[0] < 0)
+    for (int i = 0; i < 4; ++i) q[i] = -q[i];
+}
+
+// se3_mul(tgt, se3_inverse(src)) in float32 (lib/utils/projection.py:12-43): Rd (3x3), td (3)
+__device__ void se3_src2tgt_f32(const float* S, const float* T, float* Rd, float* td) {
+  float Ri[9], ti[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = S[j * 4 + i];
+  for (int i = 0; i < 3; ++i) ti[i] = -1.f * ((Ri[i * 3 + 0] * S[3] + Ri[i * 3 + 1] * S[7]) + Ri[i * 3 + 2] * S[11]);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      Rd[i * 3 + j] = (T[i * 4 + 0] * Ri[0 * 3 + j] + T[i * 4 + 1] * Ri[1 * 3 + j]) + T[i * 4 + 2] * Ri[2 * 3 + j];
+    td[i] = ((T[i * 4 + 0] * ti[0] + T[i * 4 + 1] * ti[1]) + T[i * 4 + 2] * ti[2]) + T[i * 4 + 3];
+  }
+}
+
+// rot_type (RT_transform.py:34-41): 0 QUAT → rot (B,4), 1 EULER → rot (B,3), 2 MATRIX → rot (B,9)
 __global__ void calc_rt_delta_kernel(float* __restrict__ rot, float* __restrict__ trans,
                                      const float* __restrict__ pose_src, const float* __restrict__ pose_tgt, Vec3d mu,
-                                     Vec3d sd, int rc, int B) {
+                                     Vec3d sd, int rc, int B, int rot_type) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* S = pose_src + b * 12;
@@ -137,15 +203,9 @@ __global__ void calc_rt_delta_kernel(float* __restrict__ rot, float* __restrict_
   float Rd[9];
   double Td[3];
   if (rc == RC_NAIVE) {  // se3_mul(tgt, se3_inverse(src)), float32 (projection.py)
-    float Ri[9], ti[3];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Ri[i * 3 + j] = S[j * 4 + i];
-    for (int i = 0; i < 3; ++i) ti[i] = -1.f * ((Ri[i * 3 + 0] * S[3] + Ri[i * 3 + 1] * S[7]) + Ri[i * 3 + 2] * S[11]);
-    for (int i = 0; i < 3; ++i) {
-      for (int j = 0; j < 3; ++j)
-        Rd[i * 3 + j] = (T[i * 4 + 0] * Ri[0 * 3 + j] + T[i * 4 + 1] * Ri[1 * 3 + j]) + T[i * 4 + 2] * Ri[2 * 3 + j];
-      Td[i] = (double)(((T[i * 4 + 0] * ti[0] + T[i * 4 + 1] * ti[1]) + T[i * 4 + 2] * ti[2]) + T[i * 4 + 3]);
-    }
+    float td[3];
+    se3_src2tgt_f32(S, T, Rd, td);
+    for (int i = 0; i < 3; ++i) Td[i] = (double)td[i];
   } else {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
@@ -166,22 +226,45 @@ __global__ void calc_rt_delta_kernel(float* __restrict__ rot, float* __restrict_
     d[2] = (double)logf(sz / tz);
     for (int i = 0; i < 3; ++i) Td[i] = (d[i] - mu.v[i]) / sd.v[i];
   }
-  // mat2quat: K from the 3x3 (Q_ab = contribution of input a to output b = M[b][a])
-  const double Qxx = Rd[0], Qyx = Rd[1], Qzx = Rd[2], Qxy = Rd[3], Qyy = Rd[4], Qzy = Rd[5], Qxz = Rd[6], Qyz = Rd[7],
-               Qzz = Rd[8];
-  double K[4][4] = {{Qxx - Qyy - Qzz, Qyx + Qxy, Qzx + Qxz, Qyz - Qzy},
-                    {Qyx + Qxy, Qyy - Qxx - Qzz, Qzy + Qyz, Qzx - Qxz},
-                    {Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, Qxy - Qyx},
-                    {Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz}};
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) K[i][j] /= 3.0;
-  double v[4];
-  sym4_max_eigvec(K, v);
-  double q[4] = {v[3], v[0], v[1], v[2]};
-  if (q[0] < 0)
-    for (int i = 0; i < 4; ++i) q[i] = -q[i];
-  for (int i = 0; i < 4; ++i) rot[b * 4 + i] = (float)q[i];
+  if (rot_type == 0) {
+    double q[4];
+    mat2quat_f64(Rd, q);
+    for (int i = 0; i < 4; ++i) rot[b * 4 + i] = (float)q[i];
+  } else if (rot_type == 1) {
+    double Md[9], e[3];
+    for (int i = 0; i < 9; ++i) Md[i] = (double)Rd[i];
+    mat2euler_sxyz_f64(Md, e);
+    for (int i = 0; i < 3; ++i) rot[b * 3 + i] = (float)e[i];
+  } else {
+    for (int i = 0; i < 9; ++i) rot[b * 9 + i] = Rd[i];
+  }
   for (int i = 0; i < 3; ++i) trans[b * 3 + i] = (float)Td[i];
+}
+
+// quat2mat / mat2quat / euler2mat / mat2euler / calc_se3 as stand-alone batched ops (the reference-named Python entries of
+// lib/pair_matching/RT_transform.py bind to these). op: 0 quat2mat (B,4)->(B,9) f64, 1 mat2quat (B,9)->(B,4) f64,
+// 2 euler2mat (B,3)->(B,9) f64, 3 mat2euler (B,9)->(B,3) f64
+__global__ void rot_convert_kernel(double* __restrict__ out, const float* __restrict__ in, int op, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (op == 0) {
+    const float* q = in + b * 4;
+    quat2mat_checked_f64(q[0], q[1], q[2], q[3], out + b * 9);
+  } else if (op == 1) {
+    mat2quat_f64(in + b * 9, out + b * 4);
+  } else if (op == 2) {
+    euler2mat_sxyz_f64((double)in[b * 3], (double)in[b * 3 + 1], (double)in[b * 3 + 2], out + b * 9);
+  } else {
+    double Md[9];
+    for (int i = 0; i < 9; ++i) Md[i] = (double)in[b * 9 + i];
+    mat2euler_sxyz_f64(Md, out + b * 3);
+  }
+}
+__global__ void calc_se3_kernel(float* __restrict__ rotm, float* __restrict__ t, const float* __restrict__ pose_src,
+                                const float* __restrict__ pose_tgt, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  se3_src2tgt_f32(pose_src + b * 12, pose_tgt + b * 12, rotm + b * 9, t + b * 3);
 }
 
 // --- Transform3D --------------------------------------------------------------
@@ -456,7 +539,37 @@ extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pos
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
   hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
-                     pose_src, se3, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+                     pose_src, se3, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B, 4);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_rt_transform_euler(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,
+                                         const float* euler_trans, const float* T_means_host, const float* T_stds_host,
+                                         int rot_coord, int B) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
+  hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
+                     pose_src, euler_trans, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B, 3);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_rot_convert(deepim_ctx* ctx, double* out, const float* in, int op, int B) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(op >= 0 && op <= 3, "rot_convert: unknown op");
+  hipLaunchKernelGGL(rot_convert_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, out, in, op, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_calc_se3(deepim_ctx* ctx, float* rotm, float* t, const float* pose_src, const float* pose_tgt,
+                               int B) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(calc_se3_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rotm, t, pose_src, pose_tgt, B);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -468,7 +581,20 @@ extern "C" int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot, float* trans, c
   if (B == 0) return 0;
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "calc_rt_delta: unknown rot_coord");
   hipLaunchKernelGGL(calc_rt_delta_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rot, trans, pose_src,
-                     pose_tgt, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B);
+                     pose_tgt, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B, 0);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_calc_rt_delta_ex(deepim_ctx* ctx, float* rot, float* trans, const float* pose_src,
+                                       const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
+                                       int rot_coord, int rot_type, int B) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "calc_rt_delta: unknown rot_coord");
+  DI_REQUIRE(rot_type >= 0 && rot_type <= 2, "calc_rt_delta: unknown rot_type");
+  hipLaunchKernelGGL(calc_rt_delta_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, rot, trans, pose_src,
+                     pose_tgt, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B, rot_type);
   DI_LAUNCH_CHECK();
   return 0;
 }

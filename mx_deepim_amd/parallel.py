@@ -37,15 +37,17 @@ def shard_counts(n_pairs, world_size):
     return [shard_bounds(n_pairs, world_size, r)[1] - shard_bounds(n_pairs, world_size, r)[0] for r in range(world_size)]
 
 
-def shard_pairs(batch, world_size, rank, n_pairs=None):
+def shard_pairs(batch, world_size, rank, n_pairs=None, replicated=("K",)):
     """Slice every per-pair array of a batch dict (leading axis = pairs; frame-major arrays have the pair
-    axis second) to this rank's block."""
+    axis second) to this rank's block. Keys in `replicated` (the intrinsics) are handed to every rank whole."""
     n_pairs = n_pairs if n_pairs is not None else batch["image_observed"].shape[0]
     lo, hi = shard_bounds(n_pairs, world_size, rank)
     out = {}
     for k, v in batch.items():
         a = np.asarray(v)
-        if a.ndim >= 1 and a.shape[0] == n_pairs:
+        if k in replicated:
+            out[k] = v
+        elif a.ndim >= 1 and a.shape[0] == n_pairs:
             out[k] = a[lo:hi]
         elif a.ndim >= 2 and a.shape[1] == n_pairs:
             out[k] = a[:, lo:hi]

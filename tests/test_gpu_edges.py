@@ -38,8 +38,9 @@ def test_error_returns_are_raised_not_printed(ctx):
         lib.deepim_rt_transform(h, d, None, d, d, None, None, 9, 1)
     with pytest.raises(RuntimeError, match="larger than 7"):
         lib.deepim_conv2d_forward(h, d, d, d, None, 1, 1, 16, 16, 1, 9, 9, 1, 4, cf(1.0), 0, 0)
-    with pytest.raises(RuntimeError, match="2 GiB"):   # 0x80000000 is the hardware-OOB marker of the gather
-        lib.deepim_conv2d_forward(h, d, d, d, None, 64, 64, 480, 640, 64, 3, 3, 1, 1, cf(1.0), 0, 0)
+    with pytest.raises(RuntimeError, match="2 GiB"):   # 0x80000000 is the hardware-OOB marker of the gather; convs split
+        # such batches into sub-batches (test_conv_input_over_2gib_runs_as_sub_batches), the deconv entry still refuses
+        lib.deepim_deconv4x4s2_crop_forward(h, d, d, d, None, 4096, 1024, 16, 20, 2, 30, 38, 1, 1, cf(1.0), 0, 0)
     with pytest.raises(RuntimeError, match="crop exceeds"):
         lib.deepim_deconv4x4s2_crop_forward(h, d, d, d, None, 1, 2, 4, 4, 2, 10, 10, 1, 1, cf(1.0), 0, 0)
     with pytest.raises(RuntimeError):

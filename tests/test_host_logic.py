@@ -73,6 +73,8 @@ def test_shard_bounds_cover_all_pairs():
     batch = {"image_observed": np.zeros((6, 3, 4, 4)), "image_rendered": np.zeros((2, 6, 3, 4, 4)), "K": np.eye(3)}
     s = parallel.shard_pairs(batch, 4, 1)
     assert s["image_observed"].shape[0] == 2 and s["image_rendered"].shape[:2] == (2, 2) and s["K"].shape == (3, 3)
+    three = {"image_observed": np.zeros((3, 3, 4, 4)), "K": np.eye(3)}        # 3 pairs: K (3,3) must not be taken for a per-pair array
+    assert parallel.shard_pairs(three, 2, 1)["K"].shape == (3, 3) and parallel.shard_pairs(three, 2, 1)["image_observed"].shape[0] == 1
 
 
 def _rdzv_worker(rank, world, port, counts, q):
