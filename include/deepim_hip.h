@@ -110,6 +110,16 @@ int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow /*B,H,W,2*/, float* vi
                              const float* depth_src, const float* depth_tgt,
                              const float* KT, const float* Kinv_host, float thresh,
                              int standard_rep, int B, int H, int W);
+/* Loader-side flow labels (lib/utils/image.py:402-450 get_pair_flow, called from get_data_pair_train_batch,
+ * lib/pair_matching/data_pair.py:170-176): calc_flow(depth_rendered, pose_rendered, pose_observed, K, depth_observed)
+ * per pair, laid out (B,2,H,W) as the loader hands it to the network, with flow_weights by TRAIN.FLOW_WEIGHT_TYPE:
+ * weight_type 0 'all', 1 'viz', 2 'valid', tiled over the two channels. Poses (B,3,4) device, K host. */
+int deepim_pair_flow_labels(deepim_ctx* ctx, float* flow /*B,2,H,W*/, float* flow_weights /*B,2,H,W*/,
+                            const float* depth_rendered, const float* depth_observed, const float* pose_rendered,
+                            const float* pose_observed, const float* K_host, float thresh, int standard_rep,
+                            int weight_type, int B, int H, int W);
+/* image.py:381-387: mask_rendered = depth_rendered with values > thresh set to 1 (others kept) */
+int deepim_depth_clip_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n);
 /* deepim/operator_py/flow_updater.py:42-102 `FlowUpdater` forward: integer flow
  * from rounded+clamped coords; pose_src/pose_tgt (B,3,4); K, Kinv host 3x3 */
 int deepim_flow_updater_forward(deepim_ctx* ctx, float* flow /*B,2,H,W*/, float* flow_weights /*B,2,H,W*/,
@@ -280,6 +290,8 @@ int deepim_calc_rt_delta_ex(deepim_ctx* ctx, float* rot, float* trans, const flo
  * op 0 quat2mat (:383-429; in (B,4) → out (B,9)), 1 mat2quat (:432-509; (B,9) → (B,4), w >= 0),
  * 2 euler2mat sxyz (:240-307; (B,3) → (B,9)), 3 mat2euler sxyz (:310-373; (B,9) → (B,3)) */
 int deepim_rot_convert(deepim_ctx* ctx, double* out, const float* in, int op, int B);
+/* get_point_cloud_observed (lib/pair_matching/data_pair.py): out (B,3,N) = R·points + T for pose (B,3,4) */
+int deepim_points_transform(deepim_ctx* ctx, float* out, const float* points, const float* pose, int B, int N);
 /* calc_se3 (RT_transform.py:176-187): se3_mul(pose_tgt, se3_inverse(pose_src)) in float32 (lib/utils/projection.py:12-43)
  * → rotm (B,3,3), t (B,3) */
 int deepim_calc_se3(deepim_ctx* ctx, float* rotm, float* t, const float* pose_src, const float* pose_tgt, int B);

@@ -96,18 +96,16 @@ __global__ __launch_bounds__(256) void flow_kernel_scalar(float* __restrict__ fl
 
 // F2: flow.py:12-63. float64 arithmetic like numpy: X = d·(Kinv·[w,h,1]) with Kinv f32→f64,
 // Xp = KT(f32→f64)·[X;1]; np.round = half-to-even (rint); flow from UN-rounded projections.
-__global__ __launch_bounds__(256) void calc_flow_kernel(float* __restrict__ flow, float* __restrict__ visible,
-                                                        const float* __restrict__ depth_src,
-                                                        const float* __restrict__ depth_tgt,
-                                                        const float* __restrict__ KT_all, Mat3 Kinv,
-                                                        float thresh, int standard_rep, int height, int width) {
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+struct CalcFlowOut { float f0, f1, vis; };
+__device__ __forceinline__ CalcFlowOut calc_flow_pixel(int b, int p, const float* __restrict__ depth_src,
+                                                       const float* __restrict__ depth_tgt,
+                                                       const float* __restrict__ KT_all, const Mat3& Kinv, float thresh,
+                                                       int standard_rep, int height, int width, float* dsf_out) {
   const int plane = height * width;
-  if (p >= plane) return;
   const int h = p / width, w = p - h * width;
   const float* KT = KT_all + b * 12;
   const float dsf = depth_src[(size_t)b * plane + p];
+  *dsf_out = dsf;
   const double d = (double)dsf;
   const double rx = (double)Kinv.v[0] * w + (double)Kinv.v[1] * h + (double)Kinv.v[2];
   const double ry = (double)Kinv.v[3] * w + (double)Kinv.v[4] * h + (double)Kinv.v[5];
@@ -127,14 +125,56 @@ __global__ __launch_bounds__(256) void calc_flow_kernel(float* __restrict__ flow
     const double dt = (double)depth_tgt[(size_t)b * plane + phc * width + pwc];
     if (within && fabs(dt - pz) < (double)thresh && fabs(dt) > 1e-10) vis = 1.f;
   }
-  float f0 = 0.f, f1 = 0.f;
+  CalcFlowOut o = {0.f, 0.f, vis};
   if (vis == 1.f) {
     const float fw = (float)(pw - (double)w), fh = (float)(ph - (double)h);
-    if (standard_rep) { f0 = fw; f1 = fh; } else { f0 = fh; f1 = fw; }
+    if (standard_rep) { o.f0 = fw; o.f1 = fh; } else { o.f0 = fh; o.f1 = fw; }
   }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void calc_flow_kernel(float* __restrict__ flow, float* __restrict__ visible,
+                                                        const float* __restrict__ depth_src,
+                                                        const float* __restrict__ depth_tgt,
+                                                        const float* __restrict__ KT_all, Mat3 Kinv,
+                                                        float thresh, int standard_rep, int height, int width) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int plane = height * width;
+  if (p >= plane) return;
+  float dsf;
+  const CalcFlowOut o = calc_flow_pixel(b, p, depth_src, depth_tgt, KT_all, Kinv, thresh, standard_rep, height, width, &dsf);
   float2* fo = reinterpret_cast<float2*>(flow + ((size_t)b * plane + p) * 2);
-  *fo = make_float2(f0, f1);
-  visible[(size_t)b * plane + p] = vis;
+  *fo = make_float2(o.f0, o.f1);
+  visible[(size_t)b * plane + p] = o.vis;
+}
+
+// Loader-side flow labels, lib/utils/image.py:402-450 (get_pair_flow): calc_flow per pair, flow.transpose((2,0,1)) →
+// (B,2,H,W), weights by TRAIN.FLOW_WEIGHT_TYPE — 0 'all' (ones), 1 'viz' (visible), 2 'valid' (depth_rendered == 0 or
+// visible) — tiled over the two channels. One pass: 8 B read + 16 B written per pixel.
+__global__ __launch_bounds__(256) void pair_flow_labels_kernel(float* __restrict__ flow, float* __restrict__ weights,
+                                                               const float* __restrict__ depth_src,
+                                                               const float* __restrict__ depth_tgt,
+                                                               const float* __restrict__ KT_all, Mat3 Kinv, float thresh,
+                                                               int standard_rep, int weight_type, int height, int width) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int plane = height * width;
+  if (p >= plane) return;
+  float dsf;
+  const CalcFlowOut o = calc_flow_pixel(b, p, depth_src, depth_tgt, KT_all, Kinv, thresh, standard_rep, height, width, &dsf);
+  const float wgt = weight_type == 0 ? 1.f : (weight_type == 1 ? o.vis : ((dsf == 0.f || o.vis == 1.f) ? 1.f : 0.f));
+  const size_t o0 = ((size_t)b * 2 + 0) * plane + p, o1 = o0 + plane;
+  flow[o0] = o.f0; flow[o1] = o.f1;
+  weights[o0] = wgt; weights[o1] = wgt;
+}
+
+// image.py:381-387: mask_rendered = depth_rendered with every value > thresh set to 1 (smaller values are KEPT, not zeroed;
+// ZoomMask binarises later)
+__global__ __launch_bounds__(256) void depth_clip_mask_kernel(float* __restrict__ mask, const float* __restrict__ depth,
+                                                              float thresh, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float d = depth[i]; mask[i] = d > thresh ? 1.f : d; }
 }
 
 // F3: flow_updater.py:42-102. f32 MXNet ops; R = f32(Kinv64·[w,h,1]); round = half away from zero.
@@ -351,6 +391,39 @@ extern "C" int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow, float* vis
   dim3 grid(di_div_up((long)W * H, 256), B);
   hipLaunchKernelGGL(calc_flow_kernel, grid, dim3(256), 0, ctx->stream, flow, visible, depth_src, depth_tgt, KT,
                      load_mat3(Kinv_host), thresh, standard_rep, H, W);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_pair_flow_labels(deepim_ctx* ctx, float* flow, float* flow_weights, const float* depth_rendered,
+                                       const float* depth_observed, const float* pose_rendered,
+                                       const float* pose_observed, const float* K_host, float thresh, int standard_rep,
+                                       int weight_type, int B, int H, int W) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(weight_type >= 0 && weight_type <= 2, "pair_flow_labels: unknown FLOW_WEIGHT_TYPE");
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)B * 48, &scratch);
+  if (rc) return rc;
+  float* KT = (float*)scratch;
+  rc = deepim_calc_KT(ctx, KT, pose_rendered, pose_observed, K_host, B);   // np.matmul(K, se3_mul(tgt, se3_inverse(src))), f32
+  if (rc) return rc;
+  double kinv[9];
+  inv3d(K_host, kinv);                    // np.linalg.inv(np.matrix(K)): float32 result for a float32 K
+  Mat3 Kinv;
+  for (int i = 0; i < 9; ++i) Kinv.v[i] = (float)kinv[i];
+  dim3 grid(di_div_up((long)W * H, 256), B);
+  hipLaunchKernelGGL(pair_flow_labels_kernel, grid, dim3(256), 0, ctx->stream, flow, flow_weights, depth_rendered,
+                     depth_observed, KT, Kinv, thresh, standard_rep, weight_type, H, W);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_depth_clip_mask(deepim_ctx* ctx, float* mask, const float* depth, float thresh, size_t n) {
+  DI_DEVICE(ctx);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(depth_clip_mask_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, mask, depth, thresh,
+                     n);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -324,6 +324,22 @@ __global__ __launch_bounds__(256) void t3d_apply_kernel(float* __restrict__ out,
   for (int i = 0; i < 3; ++i) o[i * N + n] = ((R[i * 4 + 0] * x + R[i * 4 + 1] * y) + R[i * 4 + 2] * z) + R[i * 4 + 3];
 }
 
+// get_point_cloud_observed (lib/pair_matching/data_pair.py): np.dot(R, points_model) + T — float64 (the model points
+// are float64 there), stored float32
+__global__ __launch_bounds__(256) void points_transform_kernel(float* __restrict__ out, const float* __restrict__ pts,
+                                                               const float* __restrict__ pose, int N) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* R = pose + b * 12;
+  const float* p = pts + (long)b * 3 * N;
+  const double x = p[n], y = p[N + n], z = p[2 * N + n];
+  float* o = out + (long)b * 3 * N;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    o[i * N + n] = (float)((((double)R[i * 4 + 0] * x + (double)R[i * 4 + 1] * y) + (double)R[i * 4 + 2] * z) + (double)R[i * 4 + 3]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -561,6 +577,14 @@ extern "C" int deepim_rot_convert(deepim_ctx* ctx, double* out, const float* in,
   if (B == 0) return 0;
   DI_REQUIRE(op >= 0 && op <= 3, "rot_convert: unknown op");
   hipLaunchKernelGGL(rot_convert_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, out, in, op, B);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_points_transform(deepim_ctx* ctx, float* out, const float* points, const float* pose, int B, int N) {
+  DI_DEVICE(ctx);
+  if (B == 0 || N == 0) return 0;
+  hipLaunchKernelGGL(points_transform_kernel, dim3(di_div_up(N, 256), B), dim3(256), 0, ctx->stream, out, points, pose, N);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -135,3 +135,44 @@ def pose_error_golden():
                   PE.arp_2d(Re, te, Rg, tg, P, K)]
     np.savez_compressed(os.path.join(HERE, "pose_error_golden.npz"), pose_est=est, pose_gt=gt,
                         points=pts.transpose(0, 2, 1).copy(), K=K.astype(np.float32), metrics=out)
+
+
+def se3_extra_golden():
+    """tests/golden/se3_extra_golden.npz (round 2): the Euler / matrix branches of the reference's RT_transform.py —
+    RT_transform with a 3-element r (euler2mat, :130-131), calc_RT_delta with rot_type EULER / MATRIX (:34-41),
+    euler2mat / mat2euler themselves — from float32 inputs, the dtype the device entries take.
+    Run: python -c "import sys; sys.path.insert(0, 'tests/golden'); import make_golden as m; m.se3_extra_golden()" """
+    RT, _, _ = load_reference()
+
+    class _Np1Array(object):
+        """NumPy-2 shim no. 4 (module attribute only, the reference file is untouched): mat2euler calls
+        np.array(mat, dtype=float64, copy=False) (:347), which NumPy 1.x reads as "copy only if needed"."""
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        def array(self, *a, **k):
+            if k.get("copy") is False:
+                k["copy"] = None
+            return np.array(*a, **k)
+    RT.np = _Np1Array()
+    rng = np.random.default_rng(4242)
+    n = 24
+    src = np.stack([rand_pose(rng) for _ in range(n)]).astype(np.float32)
+    tgt = np.stack([rand_pose(rng) for _ in range(n)]).astype(np.float32)
+    e = (rng.standard_normal((n, 3)) * 0.4).astype(np.float32)
+    t = (rng.standard_normal((n, 3)) * 0.1).astype(np.float32)
+    mu, sd = np.array([0.01, -0.02, 0.03]), np.array([0.9, 1.1, 1.2])
+    out = dict(src=src, tgt=tgt, euler=e, t=t, T_means=mu, T_stds=sd)
+    for coord in ("MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"):
+        out["RT_transform_euler_%s" % coord] = np.stack([RT.RT_transform(src[i], e[i], t[i], mu, sd, coord) for i in range(n)])
+    for coord in ("MODEL", "CAMERA", "CAMERA_NEW", "NAIVE"):
+        for rtype in ("EULER", "MATRIX", "QUAT"):
+            rt = [RT.calc_RT_delta(src[i], tgt[i], mu, sd, coord, rtype) for i in range(n)]
+            out["calc_RT_delta_%s_%s_r" % (rtype, coord)] = np.stack([np.asarray(a, np.float64).reshape(-1) for a, _ in rt])
+            out["calc_RT_delta_%s_%s_t" % (rtype, coord)] = np.stack([np.asarray(b, np.float64) for _, b in rt])
+    out["euler2mat"] = np.stack([RT.euler2mat(e[i, 0], e[i, 1], e[i, 2]) for i in range(n)])
+    out["mat2euler"] = np.stack([np.array(RT.mat2euler(src[i][:, :3])) for i in range(n)])
+    out["mat2quat_f32"] = np.stack([RT.mat2quat(src[i][:, :3]) for i in range(n)])
+    out["quat2mat_f32"] = np.stack([RT.quat2mat(out["mat2quat_f32"][i].astype(np.float32)) for i in range(n)])
+    np.savez_compressed(os.path.join(HERE, "se3_extra_golden.npz"), **out)
+    print("wrote se3_extra_golden.npz:", sorted(out)[:6], "...")
