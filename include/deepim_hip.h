@@ -256,6 +256,13 @@ int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const float* in,
 /* FullyConnected y = x·Wᵀ + b [+LeakyReLU] (deepIM_flownet.py:112-116,211-215) */
 int deepim_fc_forward(deepim_ctx* ctx, float* out, const float* in, const float* w /*O,I*/,
                       const float* bias, int B, int I, int O, float slope);
+/* fc6 on the fp32 matrix cores, one pass over the weights for up to 32 batch rows (v_mfma_f32_32x32x2_f32 split-K GEMM
+ * with a fixed-order reduction): the (O,I) MXNet weight is re-packed once into MFMA operand order, then
+ * out (B,O) = lrelu(in (B,I) · wᵀ + bias). Built for O == 256 (fc6, fc7), I % 8 == 0. */
+size_t deepim_fc_packed_size(int O, int I);
+int deepim_fc_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int O, int I);
+int deepim_fc_forward_packed(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
+                             int B, int I, int O, float slope);
 /* fc7-input → rot(4), trans(3) FCs + ZoomTrans(inverse) + Concat → se3 (B,7)
  * (deepIM_flownet.py:715-726) */
 int deepim_pose_head_forward(deepim_ctx* ctx, float* se3 /*B,7*/, const float* feat /*B,F*/,

@@ -193,6 +193,10 @@ class deepIM_flownet(object):
                 pk = DeviceArray(ctx, (nb // 4,))
                 lib.deepim_conv_pack_weights(h, pk, self.params[name], cout, cin, kh, kw)
             self.packed[base] = pk
+        # fc6: the 84 MB weight in MFMA operand order, so the layer is one pass over the weights on the matrix cores
+        nb = lib.load().deepim_fc_packed_size(256, 1024 * 8 * 10)
+        self.packed["fc6"] = DeviceArray(ctx, (nb // 4,))
+        lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
         if self.fp16_conv:   # fp16 weights in MFMA octet order, one-time
             self.packed_f16 = {}
             cin = self.cin
@@ -308,8 +312,8 @@ class deepIM_flownet(object):
     def pose_head(self):
         A, P, h, B = self.act, self.params, self.ctx.handle, self.B
         flat = A["conv6_1"].reshape((B, -1))
-        lib.deepim_fc_forward(h, A["fc6"], flat, P["fc6_weight"], P["fc6_bias"], B, flat.shape[1], 256,
-                              ctypes.c_float(SLOPE))
+        lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256,
+                                     ctypes.c_float(SLOPE))
         lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256,
                               ctypes.c_float(SLOPE))
         lib.deepim_pose_head_forward(h, A["se3"], A["fc7"], P["rot_weight"], P["rot_bias"], P["trans_weight"],

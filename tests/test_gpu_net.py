@@ -353,6 +353,29 @@ def test_fc(ctx, shape):
     np.testing.assert_allclose(out.asnumpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(32, 81920, 256), (16, 81920, 256), (1, 81920, 256), (40, 81920, 256), (5, 256, 256),
+                                   (3, 1000 * 8, 256)])
+def test_fc_packed_mfma(ctx, shape):
+    """fc6 on the matrix cores (one weight pass per 32 batch rows, fixed-order split-K reduction) vs the oracle, and
+    bit-reproducible from call to call."""
+    B, I, O = shape
+    rng = np.random.default_rng(B + I)
+    x = rng.standard_normal((B, I)).astype(np.float32)
+    w = (rng.standard_normal((O, I)) / np.sqrt(I)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    pk = DeviceArray(ctx, (lib.load().deepim_fc_packed_size(O, I) // 4,))
+    lib.deepim_fc_pack_weights(ctx.handle, pk, ctx.array(w), O, I)
+    out = ctx.empty((B, O))
+    dx, db = ctx.array(x), ctx.array(b)
+    lib.deepim_fc_forward_packed(ctx.handle, out, dx, pk, db, B, I, O, cf(0.1))
+    got = out.asnumpy()
+    np.testing.assert_allclose(got, onet.fc(x, w, b, 0.1), rtol=1e-5, atol=1e-5)
+    lib.deepim_fc_forward_packed(ctx.handle, out, dx, pk, db, B, I, O, cf(0.1))
+    np.testing.assert_array_equal(out.asnumpy(), got)
+    with pytest.raises(RuntimeError):
+        lib.deepim_fc_forward_packed(ctx.handle, out, dx, pk, db, B, I, 128, cf(0.1))
+
+
 def test_copy_channels(ctx):
     rng = np.random.default_rng(4)
     src = rng.standard_normal((3, 5, 6, 7)).astype(np.float32)
