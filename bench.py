@@ -290,8 +290,9 @@ def main():
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms,
-                              "note": "in practice VALU-bound: BilinearSampler's float/double blend restated bit-for-bit "
-                                      "(~13 fp64-rate ops per output), see DESIGN.md section 3"},
+                              "note": "algorithmic bytes = read + write of every zoomed channel once (SURVEY 8d); the fused "
+                                      "front end keeps BilinearSampler's float/double blend bit for bit (VALU work ~ the "
+                                      "HBM time), see DESIGN.md section 3"},
         }
         if not args.prestaged and NIT > 1:
             out["render_ms"] = float(np.mean([t.elapsed_ms() for row in render_timers for t in row]))

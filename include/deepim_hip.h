@@ -192,6 +192,10 @@ int deepim_zoom_concat_forward(deepim_ctx* ctx,
                                const float* pixel_means_host,
                                float* net_input, float* zoom_factor,
                                int B, int H, int W);
+/* parity hook: runs all 2^32 float bit patterns through the kernel's 5-op replacement of `v / 255.0f`
+ * (deepIM_flownet.py:35-36 divides the zoomed images by 255) against the IEEE division on the device and returns the
+ * number of patterns whose results differ in any bit (NaN results compare equal). Must be 0. */
+int deepim_selfcheck_div255(deepim_ctx* ctx, unsigned long long* mismatches_host);
 /* debug/parity hook: the int32 source indices (x0,y0 = floor of the sampling
  * position) the resampler uses for every output pixel: idx (B,2,H,W) int32 */
 int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W);

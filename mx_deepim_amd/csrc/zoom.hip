@@ -207,6 +207,18 @@ __device__ __forceinline__ Taps make_taps(const Affine& a, int h, int w, int H, 
   return t;
 }
 
+// v / 255.0f, bit for bit, in 5 VALU ops instead of the ~12 of an IEEE division sequence: Markstein's correction of
+// q0 = v·RN(1/255) with the exact FMA residual. Checked against true division for ALL 2^32 float bit patterns
+// (deepim_selfcheck_div255 on the device, tests/test_oracle_thirdparty.py on the host): the only inputs where the
+// corrected quotient differs are ±0 and ±inf, for which q0 itself is the exact answer.
+__device__ __forceinline__ float div255(float v) {
+  const float c = 1.0f / 255.0f;
+  const float q0 = v * c;
+  const float r = fmaf(-255.0f, q0, v);
+  const float q1 = fmaf(r, c, q0);
+  return __builtin_amdgcn_classf(v, 0x264) ? q0 : q1;   // class mask: -inf | -0 | +0 | +inf
+}
+
 __device__ __forceinline__ float pre_op(float v, float mean, int flags) {
   if (flags & CF_PRE_SIGMOID) v = 1.0f / (1.0f + expf(-v));
   if (flags & CF_PRE_BIN02) v = v > 0.2f ? 1.f : (v <= 0.2f ? 0.f : v);
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256) void resample_kernel(Plan plan, const float* _
     if (fl & CF_HIGHLIGHT) v = fmaxf(v, ((fl & CF_HIGHLIGHT_RED) && spot) ? 255.f : 0.f);
     v = v - ch.mean;
     if (fl & CF_POST_ROUND) v = roundf(v);
-    if (fl & CF_POST_DIV255) v = v / 255.0f;
+    if (fl & CF_POST_DIV255) v = div255(v);
     if (fl & CF_POST_MUL_WX) v = v * a.wx_in;
     if (fl & CF_POST_DIV_WX) v = v / a.wx_in;
     if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
@@ -254,9 +266,73 @@ __global__ __launch_bounds__(256) void resample_kernel(Plan plan, const float* _
   }
 }
 
-// 4 consecutive output pixels per thread (W % 4 == 0): the row taps are shared, the 16 tap loads of a
-// channel are issued together, results leave as one dwordx4 store; 1-D grid over pixel quads so no lane is
-// idle on the 640-wide rows. Same arithmetic, operation by operation, as resample_kernel.
+// 4 consecutive output pixels per thread (W % 4 == 0): the row taps are shared, the 16 tap loads of a channel are issued
+// together, results leave as one dwordx4 store; 1-D grid over pixel quads so no lane is idle on the 640-wide rows. Same
+// arithmetic, operation by operation, as resample_kernel.
+struct Quad {             // everything of a pixel quad that does not depend on the channel
+  Taps t[4];
+  long row0, row1, opix;
+  int xc0[4], xc1[4];
+  int h, w0;
+};
+__device__ __forceinline__ Quad make_quad(const Affine& a, int h, int w0, int H, int W, float gx_step, float gy_step) {
+  Quad q;
+  q.h = h; q.w0 = w0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q.t[i] = make_taps(a, h, w0 + i, H, W, gx_step, gy_step);
+  // taps outside the frame contribute 0 (BilinearSampler zero padding): load from a clamped in-frame address and select,
+  // so the 16 tap loads of a channel are unconditional (no exec-mask branches around them)
+  const int yc0 = min(max(q.t[0].y0, 0), H - 1), yc1 = min(max(q.t[0].y0 + 1, 0), H - 1);
+  q.row0 = (long)yc0 * W; q.row1 = (long)yc1 * W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    q.xc0[i] = min(max(q.t[i].x0, 0), W - 1);
+    q.xc1[i] = min(max(q.t[i].x0 + 1, 0), W - 1);
+  }
+  q.opix = (long)h * W + w0;
+  return q;
+}
+
+// One channel of a quad. FLS >= 0: the channel's flags are a compile-time constant (the fused front end: every flag test
+// folds away); FLS < 0: flags come from the plan at run time (the generic Z ops).
+template <int FLS>
+__device__ __forceinline__ void resample_channel4(const float* __restrict__ s, float* __restrict__ d, float mean, int fl_dyn,
+                                                  const Quad& q, const Affine& a, int H, int W) {
+  const int fl = FLS >= 0 ? FLS : fl_dyn;
+  float tl[4], tr[4], bl[4], br[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    tl[i] = s[q.row0 + q.xc0[i]];
+    tr[i] = s[q.row0 + q.xc1[i]];
+    bl[i] = s[q.row1 + q.xc0[i]];
+    br[i] = s[q.row1 + q.xc1[i]];
+  }
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const Taps& t = q.t[i];
+    const float ptl = t.in00 ? pre_op(tl[i], mean, fl) : 0.f;
+    const float ptr_ = t.in01 ? pre_op(tr[i], mean, fl) : 0.f;
+    const float pbl = t.in10 ? pre_op(bl[i], mean, fl) : 0.f;
+    const float pbr = t.in11 ? pre_op(br[i], mean, fl) : 0.f;
+    float v = blend(ptl, ptr_, pbl, pbr, t.wy0, t.wx0);
+    if (fl & CF_HIGHLIGHT) {
+      const int sy0 = (int)floorf((float)H / 2 - 5), sy1 = (int)ceilf((float)H / 2 + 5);
+      const int sx0 = (int)floorf((float)W / 2 - 5), sx1 = (int)ceilf((float)W / 2 + 5);
+      const bool spot = q.h >= sy0 && q.h < sy1 && q.w0 + i >= sx0 && q.w0 + i < sx1;
+      v = fmaxf(v, ((fl & CF_HIGHLIGHT_RED) && spot) ? 255.f : 0.f);
+    }
+    v = v - mean;
+    if (fl & CF_POST_ROUND) v = roundf(v);
+    if (fl & CF_POST_DIV255) v = div255(v);
+    if (fl & CF_POST_MUL_WX) v = v * a.wx_in;
+    if (fl & CF_POST_DIV_WX) v = v / a.wx_in;
+    if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
+    o[i] = v;
+  }
+  *reinterpret_cast<float4*>(d + q.opix) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* __restrict__ zoom_factor, int H, int W,
                                                         float gx_step, float gy_step) {
   const int qpr = W >> 2;
@@ -265,59 +341,65 @@ __global__ __launch_bounds__(256) void resample4_kernel(Plan plan, const float* 
   if (qid >= qpr * H) return;
   const int h = qid / qpr, w0 = (qid - h * qpr) << 2;
   const Affine a = load_affine(zoom_factor, b, plan.inverse, H, W);
-  Taps t[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) t[i] = make_taps(a, h, w0 + i, H, W, gx_step, gy_step);
-  // taps outside the frame contribute 0 (BilinearSampler zero padding): load from a clamped in-frame address and select,
-  // so the 16 tap loads of a channel are unconditional (no exec-mask branches around them)
-  const int yc0 = min(max(t[0].y0, 0), H - 1), yc1 = min(max(t[0].y0 + 1, 0), H - 1);
-  const long row0 = (long)yc0 * W, row1 = (long)yc1 * W;
-  int xc0[4], xc1[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xc0[i] = min(max(t[i].x0, 0), W - 1);
-    xc1[i] = min(max(t[i].x0 + 1, 0), W - 1);
-  }
-  const long opix = (long)h * W + w0;
-  const int sy0 = (int)floorf((float)H / 2 - 5), sy1 = (int)ceilf((float)H / 2 + 5);
-  const int sx0 = (int)floorf((float)W / 2 - 5), sx1 = (int)ceilf((float)W / 2 + 5);
-  // VALU-bound, not HBM-bound: the reference's float/double blend costs ~13 fp64-rate ops per output (≈60 of the
-  // 90 µs at B = 16); two channels in flight hide the tap-load latency behind it
+  const Quad q = make_quad(a, h, w0, H, W, gx_step, gy_step);
 #pragma unroll 2
   for (int c = 0; c < plan.n; ++c) {
     const Chan& ch = plan.ch[c];
-    const float* s = ch.src + (long)b * ch.src_bstride;
-    const int fl = ch.flags;
-    float tl[4], tr[4], bl[4], br[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      tl[i] = s[row0 + xc0[i]];
-      tr[i] = s[row0 + xc1[i]];
-      bl[i] = s[row1 + xc0[i]];
-      br[i] = s[row1 + xc1[i]];
-    }
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float ptl = t[i].in00 ? pre_op(tl[i], ch.mean, fl) : 0.f;
-      const float ptr_ = t[i].in01 ? pre_op(tr[i], ch.mean, fl) : 0.f;
-      const float pbl = t[i].in10 ? pre_op(bl[i], ch.mean, fl) : 0.f;
-      const float pbr = t[i].in11 ? pre_op(br[i], ch.mean, fl) : 0.f;
-      float v = blend(ptl, ptr_, pbl, pbr, t[i].wy0, t[i].wx0);
-      if (fl & CF_HIGHLIGHT) {
-        const bool spot = h >= sy0 && h < sy1 && w0 + i >= sx0 && w0 + i < sx1;
-        v = fmaxf(v, ((fl & CF_HIGHLIGHT_RED) && spot) ? 255.f : 0.f);
-      }
-      v = v - ch.mean;
-      if (fl & CF_POST_ROUND) v = roundf(v);
-      if (fl & CF_POST_DIV255) v = v / 255.0f;
-      if (fl & CF_POST_MUL_WX) v = v * a.wx_in;
-      if (fl & CF_POST_DIV_WX) v = v / a.wx_in;
-      if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
-      o[i] = v;
-    }
-    *reinterpret_cast<float4*>(ch.dst + (long)b * ch.dst_bstride + opix) = make_float4(o[0], o[1], o[2], o[3]);
+    resample_channel4<-1>(ch.src + (long)b * ch.src_bstride, ch.dst + (long)b * ch.dst_bstride, ch.mean, ch.flags, q, a, H, W);
   }
+}
+
+// The fused front end of the test graph (deepIM_flownet.py:563-622 + :33-62: ZoomMask / ZoomImageWithFactor / ZoomDepth +
+// /255 + Concat) with every channel's pre/post op known at compile time: the generic plan kernel spends more instructions
+// on run-time flag tests and IEEE divisions than on the blend itself (85 VALU ops per output there).
+struct ConcatArgs {
+  const float* image_observed; const float* image_rendered;   // (B,3,H,W)
+  const float* depth_observed; const float* depth_rendered;   // (B,1,H,W) or unused
+  const float* mask_observed;  const float* mask_rendered;    // (B,1,H,W) or unused
+  float* net_input;                                           // (B,C,H,W)
+  Vec3 means;
+  int C;
+};
+template <bool DEPTH, bool MASK>
+__global__ __launch_bounds__(256) void zoom_concat4_kernel(ConcatArgs g, const float* __restrict__ zoom_factor, int H, int W,
+                                                           float gx_step, float gy_step) {
+  const int qpr = W >> 2;
+  const int qid = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (qid >= qpr * H) return;
+  const int h = qid / qpr, w0 = (qid - h * qpr) << 2;
+  const Affine a = load_affine(zoom_factor, b, 0, H, W);
+  const Quad q = make_quad(a, h, w0, H, W, gx_step, gy_step);
+  const long p = (long)H * W;
+  float* out = g.net_input + (long)b * g.C * p;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4<CF_POST_DIV255>(g.image_observed + ((long)b * 3 + c) * p, out + c * p, g.means.v[c], 0, q, a, H, W);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4<CF_POST_DIV255>(g.image_rendered + ((long)b * 3 + c) * p, out + (3 + c) * p, g.means.v[c], 0, q, a, H, W);
+  int n = 6;
+  if (DEPTH) {
+    resample_channel4<CF_POST_DIV255>(g.depth_observed + (long)b * p, out + (long)n * p, 0.f, 0, q, a, H, W);
+    resample_channel4<CF_POST_DIV255>(g.depth_rendered + (long)b * p, out + (long)(n + 1) * p, 0.f, 0, q, a, H, W);
+    n += 2;
+  }
+  if (MASK) {
+    resample_channel4<CF_POST_ROUND>(g.mask_observed + (long)b * p, out + (long)n * p, 0.f, 0, q, a, H, W);
+    resample_channel4<CF_PRE_BIN02 | CF_POST_ROUND>(g.mask_rendered + (long)b * p, out + (long)(n + 1) * p, 0.f, 0, q, a, H, W);
+  }
+}
+
+// every float bit pattern through div255 against the IEEE division (parity hook)
+__global__ __launch_bounds__(256) void selfcheck_div255_kernel(unsigned long long* __restrict__ bad) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long n = 0;
+  for (unsigned long long u = i; u < (1ull << 32); u += (unsigned long long)gridDim.x * 256) {
+    const float v = __uint_as_float((unsigned)u);
+    const float x = v / 255.0f, y = div255(v);
+    if (__float_as_uint(x) != __float_as_uint(y) && !(x != x && y != y)) ++n;
+  }
+  if (n) atomicAdd(bad, n);
 }
 
 __global__ __launch_bounds__(256) void indices_kernel(int32_t* __restrict__ idx, const float* __restrict__ zoom_factor,
@@ -539,9 +621,28 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
     rc = compute_zoom_factor(ctx, zoom_factor, image_observed, image_rendered, BB_IMAGE, BB_IMAGE, pixel_means_host,
                              src_pose, K_host, B, H, W);
   if (rc) return rc;
+  const long db = (long)C * p;
+  if ((W & 3) == 0 && ((size_t)net_input & 15) == 0) {   // the fused, compile-time-specialised front end
+    ConcatArgs g;
+    g.image_observed = image_observed; g.image_rendered = image_rendered;
+    g.depth_observed = depth_observed; g.depth_rendered = depth_rendered;
+    g.mask_observed = mask_observed; g.mask_rendered = mask_rendered;
+    g.net_input = net_input; g.C = C;
+    for (int i = 0; i < 3; ++i) g.means.v[i] = pixel_means_host ? pixel_means_host[i] : 0.f;
+    const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
+    dim3 grid(di_div_up((long)(W / 4) * H, 256), B);
+    const bool dep = depth_observed != nullptr;
+#define DI_CONCAT(D, M) hipLaunchKernelGGL((zoom_concat4_kernel<D, M>), grid, dim3(256), 0, ctx->stream, g, zoom_factor, H, W, gx, gy)
+    if (dep && with_mask) DI_CONCAT(true, true);
+    else if (dep) DI_CONCAT(true, false);
+    else if (with_mask) DI_CONCAT(false, true);
+    else DI_CONCAT(false, false);
+#undef DI_CONCAT
+    DI_LAUNCH_CHECK();
+    return 0;
+  }
   Plan plan; plan.inverse = 0;
   int n = 0;
-  const long db = (long)C * p;
   image_plan(plan, 0, image_observed, net_input, 3 * p, db, p, pixel_means_host, CF_POST_DIV255, 0);
   image_plan(plan, 3, image_rendered, net_input + 3 * p, 3 * p, db, p, pixel_means_host, CF_POST_DIV255, 0);
   n = 6;
@@ -555,6 +656,19 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
   }
   plan.n = n;
   return launch_resample(ctx, plan, zoom_factor, B, H, W);
+}
+
+extern "C" int deepim_selfcheck_div255(deepim_ctx* ctx, unsigned long long* mismatches_host) {
+  DI_DEVICE(ctx);
+  void* scratch;
+  int rc = deepim_scratch(ctx, 64, &scratch);
+  if (rc) return rc;
+  DI_CHECK(hipMemsetAsync(scratch, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(selfcheck_div255_kernel, dim3(4096), dim3(256), 0, ctx->stream, (unsigned long long*)scratch);
+  DI_LAUNCH_CHECK();
+  DI_CHECK(hipMemcpyAsync(mismatches_host, scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DI_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 extern "C" int deepim_zoom_indices(deepim_ctx* ctx, const float* zoom_factor, int32_t* idx, int B, int H, int W) {

@@ -28,6 +28,7 @@ _CTYPE = {
     "double": ctypes.c_double,
     "size_t": ctypes.c_size_t,
     "long": ctypes.c_long,
+    "unsigned long long": ctypes.c_ulonglong,
     "void": None,
 }
 

@@ -159,3 +159,11 @@ def test_resample_scalar_path_unaligned_width(ctx):
     r0, _ = oz.zoom_depth(zf, x, x)
     np.testing.assert_array_equal(o0.asnumpy(), r0)
     np.testing.assert_array_equal(o1.asnumpy(), r0)
+
+
+def test_div255_replacement_is_exact_for_every_float(ctx):
+    """The fused front end divides by 255 with a 5-op FMA-corrected reciprocal instead of an IEEE division sequence:
+    all 2^32 float bit patterns, on the device, bit for bit."""
+    n = ctypes.c_ulonglong(12345)
+    lib.deepim_selfcheck_div255(ctx.handle, ctypes.byref(n))
+    assert n.value == 0
