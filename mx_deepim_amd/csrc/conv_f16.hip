@@ -26,11 +26,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HOCT = 8;   // octets per chunk (K chunk = 8 octets x 8 halves = 64)
-constexpr int HBM = 128, HBN = 128;
+
+// Tile shapes. A 32x32x16 MFMA is 32 cycles; a wave tile of TM x TN MFMA tiles reads (TM + TN) KB of fragments from LDS
+// per TM·TN MFMAs. With the 2x2 tile of the first version that is 1 KB per MFMA and wave = 128 B/clk per CU at full MFMA
+// rate: the whole LDS bandwidth, before the stores (measured 440 TFLOP/s = 18 %), and a K chunk lasted only 512 cycles, less
+// than an L2 hit, with the next chunk's loads just one chunk ahead. The shapes below halve the LDS bytes per MFMA
+// (2x4: 768 B, 4x4: 512 B) and make a chunk 1024 / 2048 cycles long:
+//   Cout <= 64 (conv1)        waves 1x4, wave tile 2x4:  64 x 512 block
+//   Cout % 256 != 0 (conv2)   waves 2x2, wave tile 2x4: 128 x 256 block
+//   Cout % 256 == 0           waves 2x2, wave tile 4x4: 256 x 256 block (256 accumulator registers, one wave per SIMD)
+inline int f16_bm(int Cout) { return Cout <= 64 ? 64 : ((Cout & 255) == 0 ? 256 : 128); }
+inline int f16_bn(int Cout) { return Cout <= 64 ? 512 : 256; }
 
 struct ConvF16Params {
   const void* in;       // NHWC fp16 (B,H,W,Cin)
-  const h8* wp;         // packed [mtile][chunk][octet][128][8]
+  const h8* wp;         // packed [mtile][chunk][octet][BM][8]
   const int2* tab;      // per k-octet: {byte offset ((ky*W+kx)*Cin + ci0)*2, tap bit ky*8+kx}; padding → bit 63
   const float* bias;
   _Float16* out;        // NHWC fp16 (B,Ho,Wo,Cout)
@@ -42,14 +52,20 @@ struct ConvF16Params {
   unsigned in_bytes;
   int ksplit, chunks_per_split;  // split-K across grid slices for under-filled grids
   float* partial;                // [ksplit][npix][Cout] fp32 partial sums when ksplit > 1
+  int stride_kw;                 // (kh << 16) | kw, for the DMA kernel's scalar tap counters
 };
 
-__global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
-  __shared__ __attribute__((aligned(16))) h8 As[2][HOCT * HBM];
-  __shared__ __attribute__((aligned(16))) h8 Bs[2][HOCT * HBN];
+template <int WGM, int WGN, int TM, int TN, bool UT>   // UT: uniform tap per chunk (Cin_pad % 64 == 0)
+__global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int NA = BM * HOCT / 256;      // weight dwordx4 per thread per chunk
+  static_assert(WGM * WGN == 4 && BN % 256 == 0 && NA >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) h8 smem[];   // [2][HOCT*BM] weights, then [2][HOCT*BN] activations
+  h8* As = smem;
+  h8* Bs = smem + 2 * HOCT * BM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave / WGN) * (TM * 32), wn0 = (wave % WGN) * (TN * 32);
   // XCD-aware tile order (see csrc/conv.hip)
   int vid;
   {
@@ -58,63 +74,99 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
     vid = xcd * qn + min(xcd, rn) + (bid >> 3);
   }
   const int bx = vid % p.gx, mb = (vid / p.gx) % p.gy, split = vid / (p.gx * p.gy);
-  const long n0 = (long)bx * HBN;
+  const long n0 = (long)bx * BN;
   const int kc_begin = split * p.chunks_per_split, kc_end = min(p.nchunk, kc_begin + p.chunks_per_split);
 
-  // per-thread gather state: one pixel, 4 octet rows per chunk
-  const int gp = tid & (HBN - 1);
-  const int orow0 = __builtin_amdgcn_readfirstlane((tid >> 7) * 4);
-  const long pix = n0 + gp;
-  unsigned voff = 0x80000000u;  // bit 31 set = out of range (threads beyond the last pixel)
-  unsigned long long m64 = 0;
-  if (pix < p.npix) {
-    const int hw = p.Ho * p.Wo;
-    const int n = (int)(pix / hw);
-    const int r = (int)(pix - (long)n * hw);
-    const int ho = r / p.Wo, wo = r - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    voff = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
-    unsigned mky = 0, mkx = 0;
+  // Activation gather. One load instruction of a wave covers 8 pixels x the 8 octets of the chunk: lane = (pixel l>>3,
+  // octet l&7). With Cin_pad % 64 == 0 the 8 octets of a pixel are 128 contiguous bytes = ONE cache line per 8 lanes,
+  // 8 lines per wave-instruction. (The first version gave every lane its own pixel: 64 lines per instruction, and the L1's
+  // one-tag-lookup-per-line rate, not bytes, bounded the kernel — measured: with the MFMAs removed it ran 20 % faster,
+  // with the loads removed 60 %.) Per thread: a fixed octet, NR = BN/32 pixels.
+  constexpr int NR = BN / 32;
+  const int oct = tid & 7;
+  unsigned voff[NR];
+  unsigned long long ninv64[NR];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
-      if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+  for (int r = 0; r < NR; ++r) {
+    const long pix = n0 + r * 32 + (tid >> 3);
+    voff[r] = 0x80000000u;  // bit 31 set = out of range (threads beyond the last pixel)
+    unsigned long long m64 = 0;
+    if (pix < p.npix) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int rr = (int)(pix - (long)n * hw);
+      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      voff[r] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
+      unsigned mky = 0, mkx = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
+        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+    ninv64[r] = ~m64;
   }
-  const unsigned long long ninv64 = ~m64;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
 
-  const h8* wblk = p.wp + (long)mb * p.nchunk * (HOCT * HBM) + tid;
-  i32x4 areg[4], breg[4];
+  const h8* wblk = p.wp + (long)mb * p.nchunk * (HOCT * BM) + tid;
+  i32x4 areg[NA], breg[NR];
+  // Tap-table entry {byte offset, tap bit} of this thread's octet. With Cin_pad % 64 == 0 the 8 octets of a chunk are one
+  // tap and 64 consecutive channels: the entry of octet 0 is wave-uniform (scalar load) and the lane adds oct*16 bytes.
+  // Otherwise (conv1) every octet is its own tap: a per-lane entry, loaded one chunk ahead and issued BEFORE that chunk's
+  // gathers — vmcnt counts in order, so a table load issued after the gathers would make its first use wait for all of them.
+  constexpr bool uniform_tap = UT;
+  int2 tnext = p.tab[kc_begin * HOCT + (uniform_tap ? 0 : oct)];
+  const unsigned lane_off = uniform_tap ? (unsigned)oct * 16u : 0u;
 
+#if defined(F16_ABL_NOA)
+#define F16_NA_LOAD 0
+#else
+#define F16_NA_LOAD NA
+#endif
+#if defined(F16_ABL_NOB)
+#define F16_NB_LOAD 0
+#else
+#define F16_NB_LOAD NR
+#endif
 #define LOAD_CHUNK(kc)                                                                                   \
   {                                                                                                      \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
-      areg[e] = *reinterpret_cast<const i32x4*>(wblk + (long)(kc) * (HOCT * HBM) + e * 256);             \
-    const int2* tp = p.tab + (kc) * HOCT + orow0;                                                        \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-      const int2 t = tp[e];                                                                              \
-      const unsigned inv = (unsigned)(ninv64 >> t.y);   /* no SALU-produced VALU operand, see conv.hip */  \
-      breg[e] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((inv << 31) | voff), t.x, 0)); \
+    _Pragma("unroll") for (int e = 0; e < F16_NA_LOAD; ++e)                                              \
+      areg[e] = *reinterpret_cast<const i32x4*>(wblk + (long)(kc) * (HOCT * BM) + e * 256);              \
+    int2 t;                                                                                              \
+    if (uniform_tap) {                                                                                   \
+      t = p.tab[(kc) * HOCT];                              /* wave-uniform: s_load */                    \
+    } else {                                                                                             \
+      t = tnext;                                                                                         \
+      tnext = p.tab[min((kc) + 1, p.nchunk - 1) * HOCT + oct];                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }                                                                                                    \
+    const unsigned toff = (unsigned)t.x + lane_off;                                                      \
+    _Pragma("unroll") for (int r = 0; r < F16_NB_LOAD; ++r) {                                            \
+      const unsigned inv = (unsigned)(ninv64[r] >> t.y);                                                 \
+      /* the tap offset is per lane, so it goes into the VGPR offset (a divergent soffset would be waterfalled) */ \
+      breg[r] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((inv << 31) | voff[r]) + toff), 0, 0)); \
     }                                                                                                    \
   }
 #define STORE_CHUNK(buf)                                                                                 \
   {                                                                                                      \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
-      *reinterpret_cast<i32x4*>(&As[buf][tid + e * 256]) = areg[e];                                      \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                        \
-      *reinterpret_cast<i32x4*>(&Bs[buf][(orow0 + e) * HBN + gp]) = breg[e];                             \
+    _Pragma("unroll") for (int e = 0; e < NA; ++e)                                                       \
+      *reinterpret_cast<i32x4*>(&As[(buf) * HOCT * BM + tid + e * 256]) = areg[e];                       \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                     \
+      const int px = r * 32 + (tid >> 3);                                                                \
+      *reinterpret_cast<i32x4*>(&Bs[(buf) * HOCT * BN + px * 8 + (oct ^ ((px >> 1) & 7))]) = breg[r];    \
+    }                                                                                                    \
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -126,40 +178,256 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(ConvF16Params p) {
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const int buf = (kc - kc_begin) & 1;
     const bool more = kc + 1 < kc_end;
+#if defined(F16_ABL_NOLOAD)
+    (void)0;
+#else
     if (more) LOAD_CHUNK(kc + 1);
-    const h8* as = &As[buf][lrow * HBM + wm0 + lcol];
-    const h8* bs = &Bs[buf][lrow * HBN + wn0 + lcol];
+#endif
+    const h8* as = &As[buf * HOCT * BM + lrow * BM + wm0 + lcol];
+    const h8* bs = &Bs[buf * HOCT * BN + (wn0 + lcol) * 8];
+    const int sw = (lcol >> 1) & 7;   // == ((pixel >> 1) & 7): wn0 and j*32 are multiples of 16
+    // fragments of k-step t+1 are read while the MFMAs of k-step t run (two fragment sets, statically indexed)
+    h8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = bs[j * 256 + (lrow ^ sw)];
 #pragma unroll
     for (int t = 0; t < HOCT / 2; ++t) {
-      h8 a[2], b[2];
+      if (t + 1 < HOCT / 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = as[t * 2 * HBM + i * 32];
+        for (int i = 0; i < TM; ++i) af[(t + 1) & 1][i] = as[(t + 1) * 2 * BM + i * 32];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = bs[t * 2 * HBN + j * 32];
+        for (int j = 0; j < TN; ++j) bf[(t + 1) & 1][j] = bs[j * 256 + (((t + 1) * 2 + lrow) ^ sw)];
+      }
+      // the next chunk goes to the other LDS buffer before the last k-step, so its ds_writes overlap these MFMAs
+#if !defined(F16_ABL_NOSTORE)
+      if (t == HOCT / 2 - 1 && more) STORE_CHUNK(buf ^ 1);
+#endif
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+#if defined(F16_ABL_NOMFMA)
+          acc[i][j][0] += (float)af[t & 1][i][0] + (float)bf[t & 1][j][0];
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i], bf[t & 1][j], acc[i][j], 0, 0, 0);
+#endif
     }
-    if (more) STORE_CHUNK(buf ^ 1);
+#if !defined(F16_ABL_NOSYNC)
     __syncthreads();
+#endif
   }
 #undef LOAD_CHUNK
 #undef STORE_CHUNK
 
   // epilogue: bias + LeakyReLU in fp32, NHWC fp16 store (offset = pixel*Cout + co; 4 channels = 8 bytes per store)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TN; ++j) {
     const long op = n0 + wn0 + j * 32 + lcol;
     if (op >= p.npix) continue;
     _Float16* orow = p.out + op * p.Cout;
     float* prow = p.partial ? p.partial + ((long)split * p.npix + op) * p.Cout : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co0 = mb * HBM + wm0 + i * 32 + 8 * g + 4 * lrow;
+        const int co0 = mb * BM + wm0 + i * 32 + 8 * g + 4 * lrow;
         if (co0 < p.Cout && prow) {  // split-K: raw fp32 partial sums, reduced by splitk_f16_reduce_kernel
+          *reinterpret_cast<float4*>(prow + co0) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        } else if (co0 < p.Cout) {
+          h4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][4 * g + r] + (p.bias ? p.bias[co0 + r] : 0.f);
+            x = x > 0.f ? x : x * p.slope;
+            v[r] = (_Float16)x;
+          }
+          *reinterpret_cast<h4*>(orow + co0) = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 tiles with LDS-DMA and a 4-stage ring (layers with Cout % 256 == 0 and Cin_pad % 64 == 0: conv3 … conv6_1).
+// Register staging keeps exactly one K chunk of loads in flight per wave and every chunk then ends in "wait for the loads,
+// ds_write, barrier": measured, the kernel above spends about half its time in that wait (MFMAs removed: 20 % faster; loads
+// issued but never waited for: as fast as with no loads at all). Here the loads go global → LDS directly
+// (`buffer_load_dwordx4 … lds`, 1 KB per wave-instruction, hardware zero fill for padding taps), no staging registers and
+// no ds_write pass; a K chunk is 32 (4 octets: 16 KB of weights + 16 KB of activations), the ring holds 4 chunks, so three
+// chunks (3072 MFMA cycles) of loads are in flight behind the one being multiplied. The DMA is issued from inline asm:
+// through the builtin the compiler cannot tell the ring stages apart and drains vmcnt(0) before every ds_read.
+//   weights     stage image [octet 0..3][row 0..255][8 halves]  = 16 KB contiguous in the packed buffer (chunk32 c at c·16 KB)
+//   activations stage image [pixel 0..255][slot 0..3][8 halves], slot = octet ^ ((pixel >> 2) & 3): the DMA writes lanes
+//               linearly, so the swizzle is applied to WHICH 16 bytes of the pixel's 64-byte run a lane fetches; a
+//               ds_read_b128 lane group (16 pixels, one octet) then covers all 64 banks once.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
+  constexpr int BM = 256, BN = 256, TM = 4, TN = 4;
+  constexpr int STAGE = 2048;              // h8 per stage: 1024 weights + 1024 activations
+  extern __shared__ __attribute__((aligned(16))) h8 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
+  int vid;
+  {
+    const int total = p.gx * p.gy * p.ksplit, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+    vid = xcd * qn + min(xcd, rn) + (bid >> 3);
+  }
+  const int bx = vid % p.gx, mb = (vid / p.gx) % p.gy, split = vid / (p.gx * p.gy);
+  const long n0 = (long)bx * BN;
+  // chunk32 range of this K slice (chunks_per_split counts 64-wide chunks)
+  const int c_begin = split * p.chunks_per_split * 2, c_end = min(p.nchunk, (split + 1) * p.chunks_per_split) * 2;
+
+  // activation gather: instruction i of wave w fills pixels (w*4+i)*16 .. +15 of the stage, lane = (pixel l>>2, slot l&3)
+  unsigned voff[4];
+  unsigned long long ninv64[4];
+  unsigned lane_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int P = (wave * 4 + i) * 16 + (lane >> 2);
+    const long pix = n0 + P;
+    voff[i] = 0x80000000u;
+    unsigned long long m64 = 0;
+    if (pix < p.npix) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int rr = (int)(pix - (long)n * hw);
+      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      voff[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
+      unsigned mky = 0, mkx = 0;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
+        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+    }
+    ninv64[i] = ~m64;
+    lane_off[i] = (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 16);   // the octet this lane fetches into its slot
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
+  // weights of this M tile: nchunk 64-wide chunks x 8 octets x 256 rows x 16 B, chunk32 c at c*16 KB
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.wp + (long)mb * p.nchunk * (HOCT * BM)), 0, (int)((long)p.nchunk * HOCT * BM * 16), 0x00020000);
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const unsigned w_voff = (unsigned)((wave * 4) * 1024 + lane * 16);          // + i*1024 + c*16384
+
+#define DMA(ldsaddr, voffset, rsrc)                                                                      \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                 \
+               :: "s"(ldsaddr), "v"(voffset), "s"(rsrc) : "memory")
+  // Issue stream: chunk32 numbers c_begin, c_begin+1, … in order. K order is (64-channel group, ky, kx, 32-channel half)
+  // and the position is kept in scalar counters — a tap-table load inside the loop would be a VECTOR load here (the asm
+  // statements clobber memory, so the compiler cannot prove the table invariant) whose wait drains the whole DMA ring.
+  const int kw_ = p.stride_kw & 0xffff, kh_ = p.stride_kw >> 16;
+  int ic = c_begin;                                   // next chunk32 to issue
+  int i_half, i_kx, i_ky, i_cg;
+  {
+    const int kc = c_begin >> 1, ntaps = kh_ * kw_;
+    const int tap = kc % ntaps;
+    i_half = c_begin & 1; i_cg = kc / ntaps; i_ky = tap / kw_; i_kx = tap - i_ky * kw_;
+  }
+  // one chunk's 8 DMA pieces are issued one at a time (piece q: 0-3 weights, 4-7 activations) so that the main loop can
+  // place one piece after every fourth MFMA: a DMA piece costs ~100 issue cycles next to ds_reads and almost nothing in the
+  // shadow of an MFMA, and eight of them back to back after the barrier left the matrix pipe idle for most of a chunk
+  unsigned i_sbase = 0, i_toff = 0, i_wbase = 0;
+  int i_tbit = 0;
+  auto issue_begin = [&]() {
+    i_sbase = lds0 + (unsigned)((ic - c_begin) & 3) * (STAGE * 16);
+    i_toff = (unsigned)(((i_ky * p.W + i_kx) * p.Cin + i_cg * 64 + i_half * 32) * 2);
+    i_tbit = i_ky * 8 + i_kx;
+    i_wbase = (unsigned)min(ic, c_end - 1) * 16384u;
+  };
+  auto issue_piece = [&](int q) {
+    if (q < 4) {
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * 4 + q) * 1024));
+      DMA(la, w_voff + (unsigned)q * 1024u + i_wbase, rsrc_w);
+    } else {
+      const int i = q - 4;
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + 16384u + (unsigned)((wave * 4 + i) * 1024));
+      const unsigned inv = (unsigned)(ninv64[i] >> i_tbit);
+      DMA(la, ((inv << 31) | voff[i]) + i_toff + lane_off[i], rsrc_in);
+    }
+  };
+  auto issue_end = [&]() {
+    if (ic < c_end - 1) {                             // past the end: keep re-issuing the last chunk (ring slot is free)
+      i_half ^= 1;
+      if (i_half == 0) {
+        if (++i_kx == kw_) {
+          i_kx = 0;
+          if (++i_ky == kh_) { i_ky = 0; ++i_cg; }
+        }
+      }
+    }
+    ++ic;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int pre = 0; pre < 3; ++pre) {
+    issue_begin();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue_piece(q);
+    issue_end();
+  }
+  const int lrow = lane >> 5, lcol = lane & 31;
+  const int sw = (lcol >> 2) & 3;
+  for (int c = c_begin; c < c_end; ++c) {
+    // chunk c has landed once at most the 16 loads of chunks c+1, c+2 are outstanding; then every wave's part is visible
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_begin();                                  // chunk c+3 goes into the slot chunk c-1 was read from (all waves are past it)
+    const h8* as = smem + ((c - c_begin) & 3) * STAGE + lrow * 256 + wm0 + lcol;
+    const h8* bs = smem + ((c - c_begin) & 3) * STAGE + 1024 + (wn0 + lcol) * 4;
+    h8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[t][i] = as[t * 512 + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[t][j] = bs[j * 128 + ((t * 2 + lrow) ^ sw)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i], bf[t][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(t * 4 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    issue_end();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef DMA
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = n0 + wn0 + j * 32 + lcol;
+    if (op >= p.npix) continue;
+    _Float16* orow = p.out + op * p.Cout;
+    float* prow = p.partial ? p.partial + ((long)split * p.npix + op) * p.Cout : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co0 = mb * BM + wm0 + i * 32 + 8 * g + 4 * lrow;
+        if (co0 < p.Cout && prow) {
           *reinterpret_cast<float4*>(prow + co0) =
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         } else if (co0 < p.Cout) {
@@ -189,28 +457,51 @@ __global__ __launch_bounds__(256) void splitk_f16_reduce_kernel(_Float16* __rest
   out[i] = (_Float16)v;
 }
 
-// packed[mt][kc][o][m][h] = f16(w[mt*128+m][ci0+h][ky][kx]); k-octet q = kc*8+o → tap = q / (Cin_pad/8)
+// K order. A k-octet q is 8 consecutive input channels of one tap. With Cin_pad a multiple of 64 the octets run
+// (channel group of 64, tap, octet in group): a K chunk is one tap of one 64-channel group — 128 contiguous bytes per
+// pixel — and the kh·kw chunks of a group re-read the same haloed input region back to back, so the taps' re-reads hit in
+// L2 (tap-major order swept the whole Cin·2-byte pixel records once per tap: 9-25x the input from HBM; measured
+// 6.6 TB/s of loads, the bound of the first version). Otherwise (conv1: Cin_pad 8/16) octets run (tap, octet).
+__host__ __device__ inline void f16_octet(int q, int Cin_pad, int ntaps, int* tap, int* ci0) {
+  const int opt = Cin_pad / 8;
+  if ((opt & 7) == 0) {
+    const int o = q & 7, g = q >> 3;           // g = cg * ntaps + tap
+    *tap = g % ntaps;
+    *ci0 = ((g / ntaps) * 8 + o) * 8;
+  } else {
+    *tap = q / opt;
+    *ci0 = (q % opt) * 8;
+  }
+}
+
+// packed[mt][kc][o][m][h] = f16(w[mt*BM+m][ci0+h][ky][kx]) for k-octet q = kc*8+o (order: f16_octet)
 __global__ void pack_f16_kernel(_Float16* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin,
-                                int Cin_pad, int kh, int kw, int nchunk, long total) {
+                                int Cin_pad, int kh, int kw, int nchunk, int BM, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int h = (int)(i & 7);
-  const int m = (int)((i >> 3) & 127);
-  const int o = (int)((i >> 10) & 7);
-  const int kc = (int)((i >> 13) % nchunk);
-  const int mt = (int)((i >> 13) / nchunk);
-  const int opt = Cin_pad / 8;
-  const int q = kc * HOCT + o, tap = q / opt, ci = (q % opt) * 8 + h, co = mt * HBM + m;
+  const long r1 = i >> 3;
+  const int m = (int)(r1 % BM);
+  const long r2 = r1 / BM;
+  const int o = (int)(r2 & 7);
+  const long r3 = r2 >> 3;
+  const int kc = (int)(r3 % nchunk);
+  const int mt = (int)(r3 / nchunk);
+  int tap, ci0;
+  f16_octet(kc * HOCT + o, Cin_pad, kh * kw, &tap, &ci0);
+  const int ci = ci0 + h, co = mt * BM + m;
   float v = 0.f;
   if (co < Cout && ci < Cin && tap < kh * kw) v = w[(((long)co * Cin + ci) * kh + tap / kw) * kw + tap % kw];
   packed[i] = (_Float16)v;
 }
 
-__global__ void build_f16_tab_kernel(int2* __restrict__ tab, int noct, int noct_pad, int Cin_pad, int kw, int W) {
+__global__ void build_f16_tab_kernel(int2* __restrict__ tab, int noct, int noct_pad, int Cin_pad, int kh, int kw, int W) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= noct_pad) return;
   if (q >= noct) { tab[q] = make_int2(0, 63); return; }
-  const int opt = Cin_pad / 8, tap = q / opt, ci0 = (q % opt) * 8, ky = tap / kw, kx = tap % kw;
+  int tap, ci0;
+  f16_octet(q, Cin_pad, kh * kw, &tap, &ci0);
+  const int ky = tap / kw, kx = tap % kw;
   tab[q] = make_int2(((ky * W + kx) * Cin_pad + ci0) * 2, ky * 8 + kx);
 }
 
@@ -270,7 +561,8 @@ extern "C" int deepim_nhwc_f16_to_nchw_f32(deepim_ctx* ctx, float* out, const vo
 }
 
 extern "C" size_t deepim_conv_f16_packed_size(int Cout, int Cin_pad, int kh, int kw) {
-  return (size_t)di_div_up(Cout, HBM) * f16_chunks(Cin_pad, kh, kw) * HOCT * HBM * 8 * sizeof(_Float16);
+  const int BM = f16_bm(Cout);
+  return (size_t)di_div_up(Cout, BM) * f16_chunks(Cin_pad, kh, kw) * HOCT * BM * 8 * sizeof(_Float16);
 }
 
 extern "C" int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const float* w, int Cout, int Cin, int Cin_pad,
@@ -278,9 +570,10 @@ extern "C" int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const
   DI_DEVICE(ctx);
   DI_REQUIRE(Cin_pad >= Cin && (Cin_pad & 7) == 0, "conv_f16_pack: Cin_pad must be a multiple of 8 and >= Cin");
   const int nchunk = f16_chunks(Cin_pad, kh, kw);
-  const long total = (long)di_div_up(Cout, HBM) * nchunk * HOCT * HBM * 8;
+  const int BM = f16_bm(Cout);
+  const long total = (long)di_div_up(Cout, BM) * nchunk * HOCT * BM * 8;
   hipLaunchKernelGGL(pack_f16_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)packed, w, Cout,
-                     Cin, Cin_pad, kh, kw, nchunk, total);
+                     Cin, Cin_pad, kh, kw, nchunk, BM, total);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -298,6 +591,7 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   p.Ho = (H + 2 * pad - kh) / stride + 1;
   p.Wo = (W + 2 * pad - kw) / stride + 1;
   p.stride = stride; p.pad = pad; p.slope = slope;
+  p.stride_kw = (kh << 16) | kw;
   p.nchunk = f16_chunks(Cin_pad, kh, kw);
   p.npix = (long)B * p.Ho * p.Wo;
   p.pad_bytes = (pad * W + pad) * Cin_pad * 2;
@@ -313,14 +607,25 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     const int noct = kh * kw * (Cin_pad / 8), noct_pad = p.nchunk * HOCT;
     DI_CHECK(hipMalloc((void**)&tab, (size_t)noct_pad * sizeof(int2)));
     hipLaunchKernelGGL(build_f16_tab_kernel, dim3(di_div_up(noct_pad, 256)), dim3(256), 0, ctx->stream, tab, noct,
-                       noct_pad, Cin_pad, kw, W);
+                       noct_pad, Cin_pad, kh, kw, W);
     ctx->conv_tabs.push_back({2, Cin_pad, kh, kw, H, W, (void*)tab});
   }
   p.tab = tab;
-  p.gx = di_div_up(p.npix, HBN); p.gy = di_div_up(Cout, HBM);
+  const int BM = f16_bm(Cout), BN = f16_bn(Cout);
+  p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   const int blocks = p.gx * p.gy;
+  // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when
+  // the grid cannot fill the 256 CUs; deterministic (cost model of csrc/conv.hip's plan_ksplit, one slot per CU)
   int ks = 1;
-  if (blocks < 384 && ctx->conv_max_split != 1) ks = min(min(di_div_up(512, blocks), max(1, p.nchunk / 4)), 16);
+  if (ctx->conv_max_split != 1) {
+    float best = 1e30f;
+    for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
+      if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
+      const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
+                         (s_ > 1 ? 1.5f + 0.004f * (float)((long)blocks * s_) * (float)(BM * BN) / 16384.f : 0.f);
+      if (cost < best * 0.985f) { best = cost; ks = s_; }
+    }
+  }
   if (ctx->conv_max_split > 1) ks = min(ks, ctx->conv_max_split);
   p.chunks_per_split = di_div_up(p.nchunk, ks);
   p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
@@ -331,7 +636,38 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     if (rc) return rc;
     p.partial = (float*)scratch;
   }
-  hipLaunchKernelGGL(conv_f16_kernel, dim3(blocks * p.ksplit), dim3(256), 0, ctx->stream, p);
+  const size_t lds = (size_t)2 * HOCT * (BM + BN) * 16;
+  const bool ut = ((Cin_pad >> 3) & 7) == 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define DI_F16_ATTR(A, B2, C, D, BMv, BNv)                                                                                  \
+  DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_kernel<A, B2, C, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               2 * HOCT * (BMv + BNv) * 16));                                                              \
+  DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_kernel<A, B2, C, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               2 * HOCT * (BMv + BNv) * 16));
+    DI_F16_ATTR(1, 4, 2, 4, 64, 512)
+    DI_F16_ATTR(2, 2, 2, 4, 128, 256)
+    DI_F16_ATTR(2, 2, 4, 4, 256, 256)
+#undef DI_F16_ATTR
+    attr_set = true;
+  }
+  const dim3 grid(blocks * p.ksplit);
+#define DI_F16_LAUNCH(A, B2, C, D)                                                                                 \
+  {                                                                                                                \
+    if (ut) hipLaunchKernelGGL((conv_f16_kernel<A, B2, C, D, true>), grid, dim3(256), lds, ctx->stream, p);         \
+    else hipLaunchKernelGGL((conv_f16_kernel<A, B2, C, D, false>), grid, dim3(256), lds, ctx->stream, p);           \
+  }
+  static bool dma_attr = false;
+  if (!dma_attr) {
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    dma_attr = true;
+  }
+  if (BM == 64) DI_F16_LAUNCH(1, 4, 2, 4)
+  else if (BM == 128) DI_F16_LAUNCH(2, 2, 2, 4)
+  else if (ut && !getenv("DEEPIM_F16_NO_DMA"))
+    hipLaunchKernelGGL(conv_f16_dma_kernel<0>, grid, dim3(256), 131072, ctx->stream, p);
+  else DI_F16_LAUNCH(2, 2, 4, 4)
+#undef DI_F16_LAUNCH
   if (p.ksplit > 1) {
     const long total = p.npix * Cout;
     hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out,
