@@ -32,11 +32,12 @@ constexpr int HOCT = 8;   // octets per chunk (K chunk = 8 octets x 8 halves = 6
 // rate: the whole LDS bandwidth, before the stores (measured 440 TFLOP/s = 18 %), and a K chunk lasted only 512 cycles, less
 // than an L2 hit, with the next chunk's loads just one chunk ahead. The shapes below halve the LDS bytes per MFMA
 // (2x4: 768 B, 4x4: 512 B) and make a chunk 1024 / 2048 cycles long:
-//   Cout <= 64 (conv1)        waves 1x4, wave tile 2x4:  64 x 512 block
+//   Cout <= 64 (conv1)        waves 1x4, wave tile 2x2:  64 x 256 block, 2-3 blocks per CU (7 K chunks only: prologue and
+//                             epilogue of one block overlap the main loop of another)
 //   Cout % 256 != 0 (conv2)   waves 2x2, wave tile 2x4: 128 x 256 block
 //   Cout % 256 == 0           waves 2x2, wave tile 4x4: 256 x 256 block (256 accumulator registers, one wave per SIMD)
 inline int f16_bm(int Cout) { return Cout <= 64 ? 64 : ((Cout & 255) == 0 ? 256 : 128); }
-inline int f16_bn(int Cout) { return Cout <= 64 ? 512 : 256; }
+inline int f16_bn(int Cout, bool dma) { return (f16_bm(Cout) == 128 && dma) ? 512 : 256; }
 
 struct ConvF16Params {
   const void* in;       // NHWC fp16 (B,H,W,Cin)
@@ -54,6 +55,18 @@ struct ConvF16Params {
   float* partial;                // [ksplit][npix][Cout] fp32 partial sums when ksplit > 1
   int stride_kw;                 // (kh << 16) | kw, for the DMA kernel's scalar tap counters
 };
+
+// validity of the (ky,kx) taps of a pixel as a 64-bit word (bit ky*8+kx), kh,kw <= 7: rows/columns hi0+k, wi0+k inside the frame
+__device__ __forceinline__ unsigned long long tap_mask64(int hi0, int wi0, int H, int W) {
+  auto range7 = [](int lo0, int n) -> unsigned {          // bits k in [0,7) with 0 <= lo0 + k < n
+    const int lo = max(0, -lo0), hi = min(7, n - lo0);
+    return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+  };
+  const unsigned mky = range7(hi0, H), mkx = range7(wi0, W);
+  // spread the 7 row bits to byte positions, then every set byte gets the column mask
+  const unsigned long long rows = ((unsigned long long)mky * 0x0002040810204081ull) & 0x0101010101010101ull;
+  return rows * (unsigned long long)mkx;
+}
 
 template <int WGM, int WGN, int TM, int TN, bool UT>   // UT: uniform tap per chunk (Cin_pad % 64 == 0)
 __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
@@ -86,29 +99,26 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
   const int oct = tid & 7;
   unsigned voff[NR];
   unsigned long long ninv64[NR];
+  {
+    // the thread's pixels are 32 apart: one division for the first, then (n, ho, wo) advance incrementally
+    const int hw = p.Ho * p.Wo;
+    long pix = n0 + (tid >> 3);
+    int n = (int)(pix / hw);
+    int rr = (int)(pix - (long)n * hw);
+    int ho = rr / p.Wo, wo = rr - ho * p.Wo;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const long pix = n0 + r * 32 + (tid >> 3);
-    voff[r] = 0x80000000u;  // bit 31 set = out of range (threads beyond the last pixel)
-    unsigned long long m64 = 0;
-    if (pix < p.npix) {
-      const int hw = p.Ho * p.Wo;
-      const int n = (int)(pix / hw);
-      const int rr = (int)(pix - (long)n * hw);
-      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      voff[r] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
-      unsigned mky = 0, mkx = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
-        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
+    for (int r = 0; r < NR; ++r) {
+      voff[r] = 0x80000000u;  // bit 31 set = out of range (threads beyond the last pixel)
+      unsigned long long m64 = 0;
+      if (pix < p.npix) {
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        voff[r] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
+        m64 = tap_mask64(hi0, wi0, p.H, p.W);
       }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+      ninv64[r] = ~m64;
+      pix += 32; wo += 32;
+      while (wo >= p.Wo) { wo -= p.Wo; if (++ho == p.Ho) { ho = 0; ++n; } }
     }
-    ninv64[r] = ~m64;
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
@@ -123,19 +133,9 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
   int2 tnext = p.tab[kc_begin * HOCT + (uniform_tap ? 0 : oct)];
   const unsigned lane_off = uniform_tap ? (unsigned)oct * 16u : 0u;
 
-#if defined(F16_ABL_NOA)
-#define F16_NA_LOAD 0
-#else
-#define F16_NA_LOAD NA
-#endif
-#if defined(F16_ABL_NOB)
-#define F16_NB_LOAD 0
-#else
-#define F16_NB_LOAD NR
-#endif
 #define LOAD_CHUNK(kc)                                                                                   \
   {                                                                                                      \
-    _Pragma("unroll") for (int e = 0; e < F16_NA_LOAD; ++e)                                              \
+    _Pragma("unroll") for (int e = 0; e < NA; ++e)                                                       \
       areg[e] = *reinterpret_cast<const i32x4*>(wblk + (long)(kc) * (HOCT * BM) + e * 256);              \
     int2 t;                                                                                              \
     if (uniform_tap) {                                                                                   \
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
       __builtin_amdgcn_sched_barrier(0);                                                                 \
     }                                                                                                    \
     const unsigned toff = (unsigned)t.x + lane_off;                                                      \
-    _Pragma("unroll") for (int r = 0; r < F16_NB_LOAD; ++r) {                                            \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                                     \
       const unsigned inv = (unsigned)(ninv64[r] >> t.y);                                                 \
       /* the tap offset is per lane, so it goes into the VGPR offset (a divergent soffset would be waterfalled) */ \
       breg[r] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((inv << 31) | voff[r]) + toff), 0, 0)); \
@@ -178,11 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const int buf = (kc - kc_begin) & 1;
     const bool more = kc + 1 < kc_end;
-#if defined(F16_ABL_NOLOAD)
-    (void)0;
-#else
     if (more) LOAD_CHUNK(kc + 1);
-#endif
     const h8* as = &As[buf * HOCT * BM + lrow * BM + wm0 + lcol];
     const h8* bs = &Bs[buf * HOCT * BN + (wn0 + lcol) * 8];
     const int sw = (lcol >> 1) & 7;   // == ((pixel >> 1) & 7): wn0 and j*32 are multiples of 16
@@ -201,22 +197,14 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
         for (int j = 0; j < TN; ++j) bf[(t + 1) & 1][j] = bs[j * 256 + (((t + 1) * 2 + lrow) ^ sw)];
       }
       // the next chunk goes to the other LDS buffer before the last k-step, so its ds_writes overlap these MFMAs
-#if !defined(F16_ABL_NOSTORE)
       if (t == HOCT / 2 - 1 && more) STORE_CHUNK(buf ^ 1);
-#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-#if defined(F16_ABL_NOMFMA)
-          acc[i][j][0] += (float)af[t & 1][i][0] + (float)bf[t & 1][j][0];
-#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][i], bf[t & 1][j], acc[i][j], 0, 0, 0);
-#endif
     }
-#if !defined(F16_ABL_NOSYNC)
     __syncthreads();
-#endif
   }
 #undef LOAD_CHUNK
 #undef STORE_CHUNK
@@ -263,14 +251,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
 //   activations stage image [pixel 0..255][slot 0..3][8 halves], slot = octet ^ ((pixel >> 2) & 3): the DMA writes lanes
 //               linearly, so the swizzle is applied to WHICH 16 bytes of the pixel's 64-byte run a lane fetches; a
 //               ds_read_b128 lane group (16 pixels, one octet) then covers all 64 banks once.
-template <int DUMMY>
+// WGM x WGN waves of 128x128 (4x4 MFMA tiles) each: <2,2> = 256x256 block, 4 ring stages of 32 KB; <1,4> = 128x512 block for
+// Cout == 128 (conv2), 3 stages of 40 KB.
+template <int WGM, int WGN, int NSTAGE>
 __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
-  constexpr int BM = 256, BN = 256, TM = 4, TN = 4;
-  constexpr int STAGE = 2048;              // h8 per stage: 1024 weights + 1024 activations
+  constexpr int BM = WGM * 128, BN = WGN * 128, TM = 4, TN = 4;
+  constexpr int NPA = BM / 64, NPB = BN / 64, NP = NPA + NPB;   // 1 KB DMA pieces per wave per chunk: weights, activations
+  constexpr int STAGE = (BM + BN) * 4;     // h8 per stage: BM*4 weights + BN*4 activations
+  static_assert(WGM * WGN == 4 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
+  const int wm0 = (wave / WGN) * 128, wn0 = (wave % WGN) * 128;
   int vid;
   {
     const int total = p.gx * p.gy * p.ksplit, bid = blockIdx.x;
@@ -282,13 +274,13 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
   // chunk32 range of this K slice (chunks_per_split counts 64-wide chunks)
   const int c_begin = split * p.chunks_per_split * 2, c_end = min(p.nchunk, (split + 1) * p.chunks_per_split) * 2;
 
-  // activation gather: instruction i of wave w fills pixels (w*4+i)*16 .. +15 of the stage, lane = (pixel l>>2, slot l&3)
-  unsigned voff[4];
-  unsigned long long ninv64[4];
-  unsigned lane_off[4];
+  // activation gather: piece i of wave w fills pixels (w*NPB+i)*16 .. +15 of the stage, lane = (pixel l>>2, slot l&3)
+  unsigned voff[NPB];
+  unsigned long long ninv64[NPB];
+  unsigned lane_off[NPB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int P = (wave * 4 + i) * 16 + (lane >> 2);
+  for (int i = 0; i < NPB; ++i) {
+    const int P = (wave * NPB + i) * 16 + (lane >> 2);
     const long pix = n0 + P;
     voff[i] = 0x80000000u;
     unsigned long long m64 = 0;
@@ -299,26 +291,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
       const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
       voff[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
-      unsigned mky = 0, mkx = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        if (hi0 + k >= 0 && hi0 + k < p.H) mky |= 1u << k;
-        if (wi0 + k >= 0 && wi0 + k < p.W) mkx |= 1u << k;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if ((mky >> k) & 1u) m64 |= (unsigned long long)mkx << (8 * k);
+      m64 = tap_mask64(hi0, wi0, p.H, p.W);
     }
     ninv64[i] = ~m64;
     lane_off[i] = (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 16);   // the octet this lane fetches into its slot
   }
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
-  // weights of this M tile: nchunk 64-wide chunks x 8 octets x 256 rows x 16 B, chunk32 c at c*16 KB
+  // weights of this M tile: nchunk 64-wide chunks x 8 octets x BM rows x 16 B, chunk32 c at c*BM*64 bytes
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.wp + (long)mb * p.nchunk * (HOCT * BM)), 0, (int)((long)p.nchunk * HOCT * BM * 16), 0x00020000);
   const unsigned lds0 = (unsigned)(size_t)smem;
-  const unsigned w_voff = (unsigned)((wave * 4) * 1024 + lane * 16);          // + i*1024 + c*16384
+  const unsigned w_voff = (unsigned)((wave * NPA) * 1024 + lane * 16);          // + i*1024 + c*BM*64
 
 #define DMA(ldsaddr, voffset, rsrc)                                                                      \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                 \
@@ -334,24 +318,24 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
     const int tap = kc % ntaps;
     i_half = c_begin & 1; i_cg = kc / ntaps; i_ky = tap / kw_; i_kx = tap - i_ky * kw_;
   }
-  // one chunk's 8 DMA pieces are issued one at a time (piece q: 0-3 weights, 4-7 activations) so that the main loop can
-  // place one piece after every fourth MFMA: a DMA piece costs ~100 issue cycles next to ds_reads and almost nothing in the
-  // shadow of an MFMA, and eight of them back to back after the barrier left the matrix pipe idle for most of a chunk
+  // one chunk's NP DMA pieces are issued one at a time (pieces 0..NPA-1 weights, then activations) so that the main loop
+  // can spread them over the chunk's MFMAs: a DMA piece costs ~100 issue cycles next to ds_reads and almost nothing in the
+  // shadow of an MFMA, and all of them back to back after the barrier left the matrix pipe idle for most of a chunk
   unsigned i_sbase = 0, i_toff = 0, i_wbase = 0;
   int i_tbit = 0;
   auto issue_begin = [&]() {
-    i_sbase = lds0 + (unsigned)((ic - c_begin) & 3) * (STAGE * 16);
+    i_sbase = lds0 + (unsigned)((ic - c_begin) % NSTAGE) * (STAGE * 16);
     i_toff = (unsigned)(((i_ky * p.W + i_kx) * p.Cin + i_cg * 64 + i_half * 32) * 2);
     i_tbit = i_ky * 8 + i_kx;
-    i_wbase = (unsigned)min(ic, c_end - 1) * 16384u;
+    i_wbase = (unsigned)min(ic, c_end - 1) * (unsigned)(BM * 64);
   };
   auto issue_piece = [&](int q) {
-    if (q < 4) {
-      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * 4 + q) * 1024));
+    if (q < NPA) {
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * NPA + q) * 1024));
       DMA(la, w_voff + (unsigned)q * 1024u + i_wbase, rsrc_w);
     } else {
-      const int i = q - 4;
-      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + 16384u + (unsigned)((wave * 4 + i) * 1024));
+      const int i = q - NPA;
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)(BM * 64) + (unsigned)((wave * NPB + i) * 1024));
       const unsigned inv = (unsigned)(ninv64[i] >> i_tbit);
       DMA(la, ((inv << 31) | voff[i]) + i_toff + lane_off[i], rsrc_in);
     }
@@ -377,26 +361,27 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int pre = 0; pre < 3; ++pre) {
+  for (int pre = 0; pre < NSTAGE - 1; ++pre) {
     issue_begin();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(q);
+    for (int q = 0; q < NP; ++q) issue_piece(q);
     issue_end();
   }
   const int lrow = lane >> 5, lcol = lane & 31;
   const int sw = (lcol >> 2) & 3;
   for (int c = c_begin; c < c_end; ++c) {
-    // chunk c has landed once at most the 16 loads of chunks c+1, c+2 are outstanding; then every wave's part is visible
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    // chunk c has landed once at most the loads of the NSTAGE-2 later chunks are outstanding; then every wave's part is visible
+    if (NSTAGE == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
     __builtin_amdgcn_s_barrier();
-    issue_begin();                                  // chunk c+3 goes into the slot chunk c-1 was read from (all waves are past it)
-    const h8* as = smem + ((c - c_begin) & 3) * STAGE + lrow * 256 + wm0 + lcol;
-    const h8* bs = smem + ((c - c_begin) & 3) * STAGE + 1024 + (wn0 + lcol) * 4;
+    issue_begin();                                  // chunk c+NSTAGE-1 goes into the slot chunk c-1 was read from (all waves are past it)
+    const h8* as = smem + ((c - c_begin) % NSTAGE) * STAGE + lrow * BM + wm0 + lcol;
+    const h8* bs = smem + ((c - c_begin) % NSTAGE) * STAGE + BM * 4 + (wn0 + lcol) * 4;
     h8 af[2][TM], bf[2][TN];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[t][i] = as[t * 512 + i * 32];
+      for (int i = 0; i < TM; ++i) af[t][i] = as[t * 2 * BM + i * 32];
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[t][j] = bs[j * 128 + ((t * 2 + lrow) ^ sw)];
     }
@@ -408,7 +393,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i], bf[t][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        issue_piece(t * 4 + i);
+        constexpr int S8 = 8;                       // 8 issue slots per chunk (one after every 4 MFMAs)
+        const int slot = t * 4 + i;
+#pragma unroll
+        for (int q = slot * NP / S8; q < (slot + 1) * NP / S8; ++q) issue_piece(q);
         __builtin_amdgcn_sched_barrier(0);
       }
     issue_end();
@@ -611,7 +599,8 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     ctx->conv_tabs.push_back({2, Cin_pad, kh, kw, H, W, (void*)tab});
   }
   p.tab = tab;
-  const int BM = f16_bm(Cout), BN = f16_bn(Cout);
+  const bool ut = ((Cin_pad >> 3) & 7) == 0;
+  const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !getenv("DEEPIM_F16_NO_DMA"));
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   const int blocks = p.gx * p.gy;
   // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when
@@ -637,7 +626,6 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     p.partial = (float*)scratch;
   }
   const size_t lds = (size_t)2 * HOCT * (BM + BN) * 16;
-  const bool ut = ((Cin_pad >> 3) & 7) == 0;
   static bool attr_set = false;
   if (!attr_set) {
 #define DI_F16_ATTR(A, B2, C, D, BMv, BNv)                                                                                  \
@@ -645,7 +633,7 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
                                2 * HOCT * (BMv + BNv) * 16));                                                              \
   DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_kernel<A, B2, C, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                2 * HOCT * (BMv + BNv) * 16));
-    DI_F16_ATTR(1, 4, 2, 4, 64, 512)
+    DI_F16_ATTR(1, 4, 2, 2, 64, 256)
     DI_F16_ATTR(2, 2, 2, 4, 128, 256)
     DI_F16_ATTR(2, 2, 4, 4, 256, 256)
 #undef DI_F16_ATTR
@@ -659,13 +647,15 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   }
   static bool dma_attr = false;
   if (!dma_attr) {
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     dma_attr = true;
   }
-  if (BM == 64) DI_F16_LAUNCH(1, 4, 2, 4)
+  const bool dma = ut && !getenv("DEEPIM_F16_NO_DMA");
+  if (BM == 64) DI_F16_LAUNCH(1, 4, 2, 2)
+  else if (BM == 128 && dma) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3>), grid, dim3(256), 122880, ctx->stream, p);
   else if (BM == 128) DI_F16_LAUNCH(2, 2, 2, 4)
-  else if (ut && !getenv("DEEPIM_F16_NO_DMA"))
-    hipLaunchKernelGGL(conv_f16_dma_kernel<0>, grid, dim3(256), 131072, ctx->stream, p);
+  else if (dma) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4>), grid, dim3(256), 131072, ctx->stream, p);
   else DI_F16_LAUNCH(2, 2, 4, 4)
 #undef DI_F16_LAUNCH
   if (p.ksplit > 1) {
