@@ -192,6 +192,13 @@ int deepim_zoom_concat_forward(deepim_ctx* ctx,
                                const float* pixel_means_host,
                                float* net_input, float* zoom_factor,
                                int B, int H, int W);
+/* the same front end in the TRAINING graph (deepIM_flownet.py:392-412): the zoom region comes from mask_gt_observed
+ * (B,1,H,W; NULL = mask_observed, i.e. the test graph) */
+int deepim_zoom_concat_train_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                     const float* mask_observed, const float* mask_gt_observed, const float* mask_rendered,
+                                     const float* depth_observed, const float* depth_rendered, const float* src_pose,
+                                     const float* K_host, const float* pixel_means_host, float* net_input,
+                                     float* zoom_factor, int B, int H, int W);
 /* parity hook: runs all 2^32 float bit patterns through the kernel's 5-op replacement of `v / 255.0f`
  * (deepIM_flownet.py:35-36 divides the zoomed images by 255) against the IEEE division on the device and returns the
  * number of patterns whose results differ in any bit (NaN results compare equal). Must be 0. */
@@ -357,6 +364,30 @@ int deepim_group_picker_forward(deepim_ctx* ctx, float* out /*B,C/G*/, const flo
                                 const float* group_idx /*B*/, int group_num, int B, int C);
 int deepim_group_picker_backward(deepim_ctx* ctx, float* in_grad /*B,C*/, const float* out_grad,
                                  const float* group_idx, int group_num, int B, int C);
+
+/* ------------------------------------ T-group: backward of the network + SGD -- */
+/* what module.backward and the "sgd" optimizer do for the conv stack and the FC head in the reference's
+ * training loop (deepim/core/module.py:1131-1137, deepim/train.py:295-338; layers at deepIM_flownet.py:63-116,211-215).
+ * All tensors NCHW fp32 device. Reductions are deterministic (fixed order, no float atomics). */
+/* LeakyReLU gradient from the saved OUTPUT y: dz = y > 0 ? dy : slope*dy */
+int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy, const float* y, float slope, size_t n);
+/* db[c] = sum over n, pixels of dz (B,C,hw) */
+int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, size_t hw);
+/* wt (Cin,Cout,kh,kw) = w (Cout,Cin,kh,kw) transposed and flipped: the weights with which the data gradient of a
+ * convolution is itself a stride-1 convolution (pad kh-1-p) — run on deepim_conv2d_forward after deepim_conv_pack_weights */
+int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw);
+/* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
+int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
+/* dw (Cout,Cin,kh,kw) = sum over n, output pixels of dz (B,Cout,Ho,Wo) x the matching taps of x (B,Cin,H,W): MFMA GEMM
+ * with the pixels as the reduction dimension; Ho*Wo must be a multiple of 4 */
+int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W, int Cout,
+                        int kh, int kw, int stride, int pad);
+/* FullyConnected backward: dx (B,I) = dy·w, dw (O,I) = dyT·x, db (O) = sum_b dy; any of dx/dw/db may be NULL */
+int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* db, const float* dy, const float* x, const float* w,
+                       int B, int I, int O);
+/* MXNet sgd_mom_update (train.py:296-303): mom = momentum*mom - lr*(rescale*g [clipped to +-clip if clip > 0] + wd*w); w += mom */
+int deepim_sgd_mom_update(deepim_ctx* ctx, float* w, float* mom, const float* g, float lr, float wd, float momentum,
+                          float rescale, float clip, size_t n);
 
 /* ------------------------------------- R-group: re-render between iterations -- */
 /* Replaces Render_Py.render (lib/render_glumpy/render_py_multi.py:101-129: OpenGL draw + glReadPixels +

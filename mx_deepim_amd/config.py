@@ -44,10 +44,11 @@ def default_config():
         FP16_CONV=False,   # BASELINE config 5: fp16 conv path (not a reference key; the reference is fp32 only)
     )
     cfg.train_iter = AttrDict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L1", LW_PM=0.1, LW_FLOW=0.25, LW_MASK=0.03,
-                              NUM_3D_SAMPLE=3000, SE3_PM_SL1_SCALAR=1.0)
+                              NUM_3D_SAMPLE=3000, SE3_PM_SL1_SCALAR=1.0, SE3_DIST_LOSS=False)
     # experiments/deepim/cfgs/deepim_flownet_LM_SIXD_v1_ape_RFMx4_8epoch.yaml:76-92 (keys the label generation reads)
     # (the yaml also sets MASK_DILATE: True — a random cv2 dilation, i.e. loader-side augmentation, not built here)
-    cfg.TRAIN = AttrDict(INIT_MASK="box_gt", FLOW_WEIGHT_TYPE="viz", MASK_DILATE=False)
+    cfg.TRAIN = AttrDict(INIT_MASK="box_gt", FLOW_WEIGHT_TYPE="viz", MASK_DILATE=False,
+                         optimizer="sgd", lr=0.0001, momentum=0.975, wd=0.0005)   # config.py:68-77
     cfg.TEST = AttrDict(test_iter=4, FAST_TEST=True, UPDATE_MASK="box_rendered", INIT_MASK="box_rendered")
     cfg.SCALES = [(480, 640)]
     return cfg

@@ -1,0 +1,325 @@
+// Backward of the matching network's conv stack and FC head + the SGD step: what
+// module.backward / the "sgd" optimizer do for these layers in the reference's training loop
+// (deepim/core/module.py:1131-1137, deepim/train.py:295-338; layers wired at deepim/symbols/deepIM_flownet.py:63-116,211-215).
+//
+//   dgrad  dX = Σ dY·W          runs on the FORWARD MFMA conv kernel: weights transposed + flipped by
+//                               conv_flip_weights_kernel (W'[ci][co][ky'][kx'] = W[co][ci][kh-1-ky'][kw-1-kx']), stride-2 layers
+//                               on a zero-dilated dY (dilate2d_kernel), pad' = k-1-p — composed in
+//                               mx_deepim_amd/symbols/deepIM_flownet.py:_conv_backward
+//   wgrad  dW = Σ_pix dY·Xcol   wgrad_mfma_kernel: D[co][k] over v_mfma_f32_32x32x2_f32 with the PIXELS as the reduction
+//                               dimension, split into slices across the grid, partial sums added in slice order
+//                               (deterministic, no float atomics)
+//   bias   db = Σ dY            one block per channel, fixed-shape tree
+//   LeakyReLU'                  from the saved output: dZ = dY·(y > 0 ? 1 : slope)
+//   FC     dX = dY·W, dW = dYᵀ·X, db = Σ dY
+//   SGD    mom = m·mom − lr·(rescale·g [clipped] + wd·w); w += mom     (MXNet sgd_mom_update)
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void lrelu_backward_kernel(float* __restrict__ dz, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, float slope, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// db[c] = Σ_n Σ_p dz[n][c][p]: one block per channel, thread t sums elements t, t+256, … in order, then a fixed LDS tree
+__global__ __launch_bounds__(256) void bias_grad_kernel(float* __restrict__ db, const float* __restrict__ dz, int B, int C,
+                                                        long HW) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double acc = 0.0;
+  for (int n = 0; n < B; ++n) {
+    const float* p = dz + ((long)n * C + c) * HW;
+    for (long i = tid; i < HW; i += 256) acc += (double)p[i];
+  }
+  __shared__ double red[256];
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) db[c] = (float)red[0];
+}
+
+__global__ __launch_bounds__(256) void conv_flip_weights_kernel(float* __restrict__ wt, const float* __restrict__ w, int Cout,
+                                                                int Cin, int kh, int kw, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int kx = (int)(i % kw);
+  const int ky = (int)((i / kw) % kh);
+  const int co = (int)((i / ((long)kw * kh)) % Cout);
+  const int ci = (int)(i / ((long)kw * kh * Cout));
+  wt[i] = w[(((long)co * Cin + ci) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)];
+}
+
+// out (BC,Hd,Wd) = zeros except out[bc][stride*y][stride*x] = in[bc][y][x]
+__global__ __launch_bounds__(256) void dilate2d_kernel(float* __restrict__ out, const float* __restrict__ in, int Ho, int Wo,
+                                                       int Hd, int Wd, int stride, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xd = (int)(i % Wd);
+  const int yd = (int)((i / Wd) % Hd);
+  const long bc = i / ((long)Wd * Hd);
+  float v = 0.f;
+  if (yd % stride == 0 && xd % stride == 0) {
+    const int y = yd / stride, x = xd / stride;
+    if (y < Ho && x < Wo) v = in[(bc * Ho + y) * Wo + x];
+  }
+  out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------- wgrad ----
+// partial[slice][co][k] = Σ_{pixels of the slice} dZ[co][pix]·X[ci(k)][pix shifted by the tap of k],  k = (ci,ky,kx).
+// 128 (co) x 128 (k) block tile, four waves of 64x64 (2x2 MFMA 32x32x2 tiles). The reduction runs over the pixels of one
+// sample at a time in groups of 8: a lane loads 4 consecutive pixels of its dZ row as one dwordx4 (lanes 0-31 pixels 0-3,
+// lanes 32-63 pixels 4-7 → MFMA k-pairs (j, 4+j)) and gathers the matching 4 input pixels of its k (tap offset folded into
+// a per-lane base, zero padding by predication). No LDS: the four waves share lines through L1.
+struct WgradParams {
+  const float* x;    // (B,Cin,H,W)
+  const float* dz;   // (B,Cout,Ho,Wo)
+  float* partial;    // [S][Cout][K]
+  int B, Cin, H, W, Cout, Ho, Wo, kh, kw, stride, pad, K;
+  int ktiles, mtiles, S, groups_per_slice;   // groups of 8 pixels per sample: ceil(HW/8); slices cover (n, group) pairs
+};
+
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kt = blockIdx.x % p.ktiles, mt = (blockIdx.x / p.ktiles) % p.mtiles, sl = blockIdx.x / (p.ktiles * p.mtiles);
+  const int lcol = lane & 31, lrow = lane >> 5;
+  const int co_base = mt * 128 + (wave >> 1) * 64, k_base = kt * 128 + (wave & 1) * 64;
+  const int HW = p.Ho * p.Wo, gps = (HW + 7) >> 3;
+  // this lane's two dZ rows and two k columns
+  int co[2], kk[2], kci[2], kdy[2], kdx[2];
+  bool co_ok[2], k_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    co[i] = co_base + i * 32 + lcol;
+    co_ok[i] = co[i] < p.Cout;
+    kk[i] = k_base + i * 32 + lcol;
+    k_ok[i] = kk[i] < p.K;
+    const int k = k_ok[i] ? kk[i] : 0;
+    kci[i] = k / (p.kh * p.kw);
+    const int t = k - kci[i] * (p.kh * p.kw);
+    kdy[i] = t / p.kw - p.pad;
+    kdx[i] = t % p.kw - p.pad;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const long g_begin = (long)sl * p.groups_per_slice, g_end = min((long)p.B * gps, g_begin + p.groups_per_slice);
+  for (long g = g_begin; g < g_end; ++g) {
+    const int n = (int)(g / gps);
+    const int p0 = (int)(g - (long)n * gps) * 8 + lrow * 4;   // this lane's 4 pixels: p0 .. p0+3
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* row = p.dz + ((long)n * p.Cout + (co_ok[i] ? co[i] : 0)) * HW;
+      if (co_ok[i] && p0 + 3 < HW) {
+        const float4 v = *reinterpret_cast<const float4*>(row + p0);   // HW % 4 == 0 is required (checked on the host)
+        a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i][j] = (co_ok[i] && p0 + j < HW) ? row[p0 + j] : 0.f;
+      }
+    }
+    int ho = p0 / p.Wo, wo = p0 - ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool pin = p0 + j < HW;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hi = ho * p.stride + kdy[i], wi = wo * p.stride + kdx[i];
+        const bool ok = pin && k_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        b[i][j] = ok ? p.x[(((long)n * p.Cin + kci[i]) * p.H + hi) * p.W + wi] : 0.f;
+      }
+      if (++wo == p.Wo) { wo = 0; ++ho; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
+  }
+  float* out = p.partial + (long)sl * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = k_base + q * 32 + lcol;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (c < p.Cout) out[(long)c * p.K + k] = acc[i][q][r];
+      }
+    }
+}
+
+// dw[i] = Σ_s partial[s][i], slices in order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ partial, long n,
+                                                           int S) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = partial[i];
+  for (int s = 1; s < S; ++s) v += partial[(long)s * n + i];
+  dw[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------- FC ----
+// dW[o][i] = Σ_b dy[b][o]·x[b][i]: thread = (o, 4 consecutive i)
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(float* __restrict__ dw, const float* __restrict__ dy,
+                                                       const float* __restrict__ x, int B, int I, int O) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const int i4 = (int)(q % (I / 4));
+  const int o = (int)(q / (I / 4));
+  if (o >= O) return;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int b = 0; b < B; ++b) {
+    const float g = dy[(long)b * O + o];
+    const float4 v = *reinterpret_cast<const float4*>(x + (long)b * I + i4 * 4);
+    acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(dw + (long)o * I + i4 * 4) = acc;
+}
+// dX[b][i] = Σ_o dy[b][o]·w[o][i]: thread = 4 consecutive i for a tile of 8 batch rows (w is read once per 8 rows)
+__global__ __launch_bounds__(256) void fc_dgrad_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+                                                       const float* __restrict__ w, int B, int I, int O) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * 8;
+  if (i4 >= I / 4) return;
+  float4 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = make_float4(0, 0, 0, 0);
+  for (int o = 0; o < O; ++o) {
+    const float4 v = *reinterpret_cast<const float4*>(w + (long)o * I + i4 * 4);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const float g = b0 + b < B ? dy[(long)(b0 + b) * O + o] : 0.f;
+      acc[b].x = fmaf(g, v.x, acc[b].x); acc[b].y = fmaf(g, v.y, acc[b].y);
+      acc[b].z = fmaf(g, v.z, acc[b].z); acc[b].w = fmaf(g, v.w, acc[b].w);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    if (b0 + b < B) *reinterpret_cast<float4*>(dx + (long)(b0 + b) * I + i4 * 4) = acc[b];
+}
+__global__ void fc_bgrad_kernel(float* __restrict__ db, const float* __restrict__ dy, int B, int O) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= O) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dy[(long)b * O + o];
+  db[o] = s;
+}
+
+__global__ __launch_bounds__(256) void sgd_mom_kernel(float* __restrict__ w, float* __restrict__ mom, const float* __restrict__ g,
+                                                      float lr, float wd, float momentum, float rescale, float clip, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gg = g[i] * rescale;
+  if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+  const float m = momentum * mom[i] - lr * (gg + wd * w[i]);
+  mom[i] = m;
+  w[i] = w[i] + m;
+}
+
+}  // namespace
+
+extern "C" int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy, const float* y, float slope, size_t n) {
+  DI_DEVICE(ctx);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(lrelu_backward_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, dz, dy, y, slope, n);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, size_t hw) {
+  DI_DEVICE(ctx);
+  if (C == 0) return 0;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, ctx->stream, db, dz, B, C, (long)hw);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw) {
+  DI_DEVICE(ctx);
+  const long total = (long)Cout * Cin * kh * kw;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(conv_flip_weights_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, wt, w, Cout, Cin, kh,
+                     kw, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd,
+                               int stride) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(stride >= 1 && Hd >= (Ho - 1) * stride + 1 && Wd >= (Wo - 1) * stride + 1, "dilate2d: output too small");
+  const long total = (long)BC * Hd * Wd;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(dilate2d_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out, in, Ho, Wo, Hd, Wd, stride,
+                     total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W,
+                                   int Cout, int kh, int kw, int stride, int pad) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  WgradParams p;
+  p.x = x; p.dz = dz;
+  p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - kh) / stride + 1;
+  p.Wo = (W + 2 * pad - kw) / stride + 1;
+  p.K = Cin * kh * kw;
+  const int HW = p.Ho * p.Wo;
+  DI_REQUIRE((HW & 3) == 0, "conv2d_wgrad: Ho*Wo must be a multiple of 4");
+  p.ktiles = di_div_up(p.K, 128);
+  p.mtiles = di_div_up(Cout, 128);
+  const long groups = (long)B * ((HW + 7) >> 3);
+  // enough pixel slices to fill the chip (~1024 blocks), each at least 64 groups (512 pixels) long; fixed by the geometry
+  long S = di_div_up(1024, p.ktiles * p.mtiles);
+  S = min(S, max(1L, groups / 64));
+  p.groups_per_slice = (int)di_div_up(groups, S);
+  p.S = (int)di_div_up(groups, p.groups_per_slice);
+  const long n = (long)Cout * p.K;
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)p.S * n * sizeof(float), &scratch);
+  if (rc) return rc;
+  p.partial = (float*)scratch;
+  hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n, p.S);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* db, const float* dy, const float* x,
+                                  const float* w, int B, int I, int O) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE((I & 3) == 0, "fc_backward: input width must be a multiple of 4");
+  if (dw) hipLaunchKernelGGL(fc_wgrad_kernel, dim3(di_div_up((long)O * (I / 4), 256)), dim3(256), 0, ctx->stream, dw, dy, x, B, I, O);
+  if (dx) hipLaunchKernelGGL(fc_dgrad_kernel, dim3(di_div_up(I / 4, 256), di_div_up(B, 8)), dim3(256), 0, ctx->stream, dx, dy, w, B, I, O);
+  if (db) hipLaunchKernelGGL(fc_bgrad_kernel, dim3(di_div_up(O, 64)), dim3(64), 0, ctx->stream, db, dy, B, O);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_sgd_mom_update(deepim_ctx* ctx, float* w, float* mom, const float* g, float lr, float wd,
+                                     float momentum, float rescale, float clip, size_t n) {
+  DI_DEVICE(ctx);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sgd_mom_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, w, mom, g, lr, wd, momentum,
+                     rescale, clip, n);
+  DI_LAUNCH_CHECK();
+  return 0;
+}

@@ -607,6 +607,19 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
                                           const float* depth_observed, const float* depth_rendered,
                                           const float* src_pose, const float* K_host, const float* pixel_means_host,
                                           float* net_input, float* zoom_factor, int B, int H, int W) {
+  return deepim_zoom_concat_train_forward(ctx, image_observed, image_rendered, mask_observed, nullptr, mask_rendered,
+                                          depth_observed, depth_rendered, src_pose, K_host, pixel_means_host, net_input,
+                                          zoom_factor, B, H, W);
+}
+
+// training graph (deepIM_flownet.py:392-412): ZoomMask takes the zoom region from mask_GT_observed (NULL = the test graph,
+// where mask_gt_observed is mask_observed, :564)
+extern "C" int deepim_zoom_concat_train_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                                const float* mask_observed, const float* mask_gt_observed,
+                                                const float* mask_rendered, const float* depth_observed,
+                                                const float* depth_rendered, const float* src_pose, const float* K_host,
+                                                const float* pixel_means_host, float* net_input, float* zoom_factor, int B,
+                                                int H, int W) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((mask_observed == nullptr) == (mask_rendered == nullptr), "zoom_concat: pass both masks or neither");
@@ -615,8 +628,8 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
   const int C = 6 + (with_mask ? 2 : 0) + (depth_observed ? 2 : 0);
   int rc;
   if (with_mask)  // ZoomMask; test graph: mask_gt_observed ≡ mask_observed (deepIM_flownet.py:564)
-    rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr,
-                             src_pose, K_host, B, H, W);
+    rc = compute_zoom_factor(ctx, zoom_factor, mask_gt_observed ? mask_gt_observed : mask_observed, mask_rendered, BB_MASK_GT,
+                             BB_MASK_RENDERED, nullptr, src_pose, K_host, B, H, W);
   else            // ZoomImage: boxes of the non-black pixels (deepIM_flownet.py:594-605, zoom_image.py:31-37)
     rc = compute_zoom_factor(ctx, zoom_factor, image_observed, image_rendered, BB_IMAGE, BB_IMAGE, pixel_means_host,
                              src_pose, K_host, B, H, W);

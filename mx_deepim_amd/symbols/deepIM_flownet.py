@@ -58,10 +58,28 @@ class deepIM_flownet(object):
             cfg = default_config()
         if cfg.network.REGRESSOR_NUM != 1:
             raise Exception("NOT IMPLEMENTED")  # deepIM_flownet.py:748
-        if is_train:
-            raise NotImplementedError("training graph (backward through the conv stack) is out of scope (SURVEY §8f)")
         self.cfg = cfg
+        if is_train:
+            return self.get_train_symbol(cfg)
         return self.get_test_symbol_share(cfg)
+
+    def get_train_symbol(self, cfg):
+        """Training graph of the POSE branch (deepIM_flownet.py:367-546 with get_convs :32-116 and the se3 part of
+        get_loss :209-312): zoom (region from mask_gt_observed) → encoder → fc6/fc7 → rot → L2Normalization, trans →
+        inverse ZoomTrans → Transform3D → point-matching loss [+ rot / trans distance losses], then backward through all of
+        it and an SGD step, resident on the device. The FlowNetS decoder with the flow / mask losses (:120-207, :317-361) has
+        a forward here but no backward yet, so a config that trains those heads is refused."""
+        n = cfg.network
+        if bool(n.PRED_FLOW) or bool(n.PRED_MASK):
+            raise NotImplementedError("training graph: the backward of the decoder / flow / mask heads is not built — "
+                                      "set network.PRED_FLOW = PRED_MASK = False for the pose branch (SURVEY §8f-4)")
+        if not cfg.train_iter.SE3_PM_LOSS:
+            raise NotImplementedError("training graph needs train_iter.SE3_PM_LOSS")
+        self.get_test_symbol_share(cfg)
+        self.is_train = True
+        self.nc8 = False          # NCHW activations: what the backward kernels read
+        self.with_mask_head = self.with_flow_head = self.with_decoder = False
+        return self
 
     def get_test_symbol_share(self, cfg):
         n = cfg.network
@@ -386,3 +404,146 @@ class deepIM_flownet(object):
         RT_transform.  `data["src_pose"]` is the current estimate; returns the refined (B,3,4) poses."""
         self.forward(data)
         return self.pose_update(data["src_pose"], pose_out)
+
+
+# ------------------------------------------------------------------------------------------------- training ----
+def _train_methods():
+    """Training-side methods of deepIM_flownet (kept below the inference code; attached to the class at import)."""
+
+    def bind_train(self, ctx, batch_size, arg_params, num_points=3000):
+        """bind() + gradient, momentum and workspace buffers for one training-style iteration."""
+        assert getattr(self, "is_train", False), "call get_symbol(cfg, is_train=True) first"
+        self.bind(ctx, batch_size, arg_params)
+        B = self.B
+        self.grad = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
+        self.mom = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
+        A = self.act
+        A["rot"], A["rot_norm"] = ctx.empty((B, 4)), ctx.empty((B, 4))
+        A["zoom_trans"], A["trans_est"] = ctx.empty((B, 3)), ctx.empty((B, 3))
+        A["points_est"] = ctx.empty((B, 3, num_points))
+        A["pm_loss"], A["pm_loss_sum"] = ctx.empty((B, 3, num_points)), ctx.empty((1,))
+        self.num_points = num_points
+        # backward workspaces: two ping-pong activation-gradient buffers, the dilated gradient of the stride-2 layers, the
+        # transposed+flipped weights and their packed form (sized for the largest layer)
+        big = max(int(np.prod(A[g[0]].shape)) for g in self.enc_geom)
+        self.ws = {"ga": ctx.empty((big,)), "gb": ctx.empty((big,))}
+        dil, wmax, pmax = 4, 4, 4
+        for name, cin, h, w, cout, k, s_, p_ in self.enc_geom[1:]:
+            if s_ > 1:
+                dil = max(dil, B * cout * (h - k + 1 + 2 * p_) * (w - k + 1 + 2 * p_))
+            wmax = max(wmax, cout * cin * k * k)
+            pmax = max(pmax, lib.load().deepim_conv_packed_size(cin, cout, k, k) // 4)
+        self.ws["dil"], self.ws["wt"], self.ws["wt_packed"] = ctx.empty((dil,)), ctx.empty((wmax,)), ctx.empty((pmax,))
+        self.ws["g256a"], self.ws["g256b"] = ctx.empty((B, 256)), ctx.empty((B, 256))
+        self.ws["dy7"], self.ws["w7"], self.ws["dw7"], self.ws["db7"] = ctx.empty((B, 7)), ctx.empty((7, 256)), ctx.empty((7, 256)), ctx.empty((7,))
+        self.ws["d_points"] = ctx.empty((B, 3, num_points))
+        self.ws["d_rot_norm"], self.ws["d_trans_est"] = ctx.empty((B, 4)), ctx.empty((B, 3))
+        self.ws["d_rot"], self.ws["d_trans"] = ctx.empty((B, 4)), ctx.empty((B, 3))
+        ctx.sync()
+        return self
+
+    def forward_train(self, data, label):
+        """data: image_observed, image_rendered, mask_observed, mask_rendered [, depth_*], src_pose; label:
+        mask_gt_observed, point_cloud_model, point_cloud_weights, point_cloud_observed (device arrays). Returns the
+        point-matching loss sum (device scalar) after filling every activation the backward needs."""
+        A, P, h, B = self.act, self.params, self.ctx.handle, self.B
+        c = ctypes.c_float
+        lib.deepim_zoom_concat_train_forward(
+            h, data["image_observed"], data["image_rendered"], data["mask_observed"] if self.input_mask else None,
+            label["mask_gt_observed"] if self.input_mask else None, data["mask_rendered"] if self.input_mask else None,
+            data.get("depth_observed") if self.input_depth else None, data.get("depth_rendered") if self.input_depth else None,
+            data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], B, self.H, self.W)
+        self.encoder()
+        flat = A["conv6_1"].reshape((B, -1))
+        lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256, c(SLOPE))
+        lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256, c(SLOPE))
+        lib.deepim_fc_forward(h, A["rot"], A["fc7"], P["rot_weight"], P["rot_bias"], B, 256, 4, c(1.0))
+        lib.deepim_fc_forward(h, A["zoom_trans"], A["fc7"], P["trans_weight"], P["trans_bias"], B, 256, 3, c(1.0))
+        lib.deepim_l2_normalize_forward(h, A["rot_norm"], A["rot"], B, 4, c(1e-10))                       # :217
+        lib.deepim_zoom_trans_forward(h, A["zoom_factor"], A["zoom_trans"], A["trans_est"], 1, B)           # :218-225
+        lib.deepim_transform3d_forward(h, A["points_est"], label["point_cloud_model"], A["rot_norm"], A["trans_est"],
+                                       data["src_pose"], self.T_means, self.T_stds, self.rot_coord, B, self.num_points)
+        t = self.cfg.train_iter
+        ltype = {"L1": 0, "L2": 1, "smooth_L1": 2}[t.SE3_PM_LOSS_TYPE]
+        lib.deepim_point_matching_loss(h, A["pm_loss"], A["pm_loss_sum"], self.ws["d_points"], A["points_est"],
+                                       label["point_cloud_observed"], label["point_cloud_weights"],
+                                       c(self.cfg.dataset.NORMALIZE_3D_POINT), ltype, c(t.SE3_PM_SL1_SCALAR),
+                                       c(t.LW_PM / t.NUM_3D_SAMPLE), B, self.num_points)                    # :265-312
+        self._train_io = (data, label)
+        return A["pm_loss_sum"]
+
+    def _conv_backward(self, li, dz, dx):
+        """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into
+        self.grad, data gradient into dx (None for the first layer)."""
+        name, cin, hh, ww, cout, k, s_, p_ = self.enc_geom[li]
+        h, B, A = self.ctx.handle, self.B, self.act
+        ho, wo = _out_hw(hh, ww, k, s_, p_)
+        src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
+        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
+        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, k, k, s_, p_)
+        if dx is None:
+            return
+        # data gradient = stride-1 convolution of the (zero-dilated) dz with the transposed, flipped weights, pad k-1-p
+        lib.deepim_conv_flip_weights(h, self.ws["wt"], self.params[name + "_weight"], cout, cin, k, k)
+        lib.deepim_conv_pack_weights(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k)
+        g, gh, gw = dz, ho, wo
+        if s_ > 1:
+            gh, gw = hh - k + 1 + 2 * p_, ww - k + 1 + 2 * p_
+            lib.deepim_dilate2d(h, self.ws["dil"], dz, B * cout, ho, wo, gh, gw, s_)
+            g = self.ws["dil"]
+        lib.deepim_conv2d_forward(h, dx, g, self.ws["wt_packed"], None, B, cout, gh, gw, cin, k, k, 1, k - 1 - p_,
+                                  ctypes.c_float(1.0), 0, 0)
+
+    def backward(self):
+        """module.backward (deepim/core/module.py:1131-1137) for the pose branch: fills self.grad for every parameter."""
+        A, P, G, W_, h, B = self.act, self.params, self.grad, self.ws, self.ctx.handle, self.B
+        c = ctypes.c_float
+        data, label = self._train_io
+        lib.deepim_transform3d_backward(h, W_["d_rot_norm"], W_["d_trans_est"], W_["d_points"], label["point_cloud_model"],
+                                        A["rot_norm"], A["trans_est"], data["src_pose"], self.T_means, self.T_stds,
+                                        self.rot_coord, B, self.num_points)
+        lib.deepim_l2_normalize_backward(h, W_["d_rot"], W_["d_rot_norm"], A["rot"], B, 4, c(1e-10))
+        lib.deepim_zoom_trans_backward(h, A["zoom_factor"], W_["d_trans_est"], W_["d_trans"], 1, 0, B)     # b_zoom_grad=False
+        # rot / trans FullyConnected as one 7-row layer: dy7 = [d_rot | d_trans], w7 = [rot_weight; trans_weight]
+        lib.deepim_copy_channels(h, W_["dy7"], 7, 0, W_["d_rot"], 4, B, 1)
+        lib.deepim_copy_channels(h, W_["dy7"], 7, 4, W_["d_trans"], 3, B, 1)
+        W_["w7"][0:4].copyfrom(P["rot_weight"])
+        W_["w7"][4:7].copyfrom(P["trans_weight"])
+        lib.deepim_fc_backward(h, W_["g256a"], W_["dw7"], W_["db7"], W_["dy7"], A["fc7"], W_["w7"], B, 256, 7)
+        G["rot_weight"].copyfrom(W_["dw7"][0:4]); G["trans_weight"].copyfrom(W_["dw7"][4:7])
+        G["rot_bias"].copyfrom(W_["db7"][0:4]); G["trans_bias"].copyfrom(W_["db7"][4:7])
+        # fc7, fc6 (LeakyReLU gradient from the saved outputs)
+        lib.deepim_lrelu_backward(h, W_["g256a"], W_["g256a"], A["fc7"], c(SLOPE), B * 256)
+        lib.deepim_fc_backward(h, W_["g256b"], G["fc7_weight"], G["fc7_bias"], W_["g256a"], A["fc6"], P["fc7_weight"], B, 256, 256)
+        lib.deepim_lrelu_backward(h, W_["g256b"], W_["g256b"], A["fc6"], c(SLOPE), B * 256)
+        n6 = 1024 * 8 * 10
+        ga, gb = W_["ga"], W_["gb"]
+        lib.deepim_fc_backward(h, ga, G["fc6_weight"], G["fc6_bias"], W_["g256b"], A["conv6_1"].reshape((B, n6)),
+                               P["fc6_weight"], B, n6, 256)
+        # encoder, last layer first: dz in place over dy, dx into the other buffer
+        for li in range(len(self.enc_geom) - 1, -1, -1):
+            name = self.enc_geom[li][0]
+            n_el = A[name].size
+            lib.deepim_lrelu_backward(h, ga, ga, A[name], c(SLOPE), n_el)
+            self._conv_backward(li, ga, gb if li > 0 else None)
+            ga, gb = gb, ga
+        return G
+
+    def update(self, lr, wd=0.0005, momentum=0.975, rescale_grad=1.0, clip_gradient=None):
+        """The "sgd" optimizer step of train.py:296-303 (MXNet sgd_mom_update) on every parameter, then the re-pack of the
+        conv / fc6 weights the forward kernels read."""
+        h = self.ctx.handle
+        c = ctypes.c_float
+        for name, w in self.params.items():
+            lib.deepim_sgd_mom_update(h, w, self.mom[name], self.grad[name], c(lr), c(wd), c(momentum), c(rescale_grad),
+                                      c(clip_gradient or 0.0), w.size)
+        for name, cin, hh, ww, cout, k, s_, p_ in self.enc_geom:
+            lib.deepim_conv_pack_weights(h, self.packed[name], self.params[name + "_weight"], cout, cin, k, k)
+        lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
+
+    return dict(bind_train=bind_train, forward_train=forward_train, _conv_backward=_conv_backward, backward=backward,
+                update=update)
+
+
+for _name, _fn in _train_methods().items():
+    setattr(deepIM_flownet, _name, _fn)

@@ -128,3 +128,103 @@ void oracle_fc(float* out, const float* in, const float* w, const float* bias, i
       out[(size_t)b * O + o] = lrelu((float)acc + (bias ? bias[o] : 0.f), slope);
     }
 }
+
+/* ---------------------------------------------------------------------------------------------- backward ----
+ * Gradients of MXNet Convolution / FullyConnected (the training graph, deepim/symbols/deepIM_flownet.py:367-546 →
+ * module.backward, deepim/core/module.py:1131-1137).  Plain definitions, float64 accumulation (order-free reference;
+ * cross-checked against torch autograd in tests/test_oracle_thirdparty.py). */
+
+/* dX[n,ci,h,w] = Σ_{co,ky,kx} dY[n,co,ho,wo]·W[co,ci,ky,kx] with h = ho·s − p + ky, w = wo·s − p + kx */
+void oracle_conv2d_dgrad(float* dx, const float* dy, const float* w, int B, int Cin, int H, int W, int Cout, int kh,
+                         int kw, int stride, int pad) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int n = 0; n < B; ++n)
+    for (int ci = 0; ci < Cin; ++ci) {
+      double* acc = (double*)calloc((size_t)H * W, sizeof(double));
+      for (int co = 0; co < Cout; ++co) {
+        const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+        const float* wp = w + (((size_t)co * Cin + ci) * kh) * kw;
+        for (int ky = 0; ky < kh; ++ky)
+          for (int kx = 0; kx < kw; ++kx) {
+            const double wv = wp[ky * kw + kx];
+            for (int ho = 0; ho < Ho; ++ho) {
+              const int h = ho * stride - pad + ky;
+              if (h < 0 || h >= H) continue;
+              for (int wo = 0; wo < Wo; ++wo) {
+                const int x = wo * stride - pad + kx;
+                if (x < 0 || x >= W) continue;
+                acc[(size_t)h * W + x] += wv * (double)g[(size_t)ho * Wo + wo];
+              }
+            }
+          }
+      }
+      float* o = dx + ((size_t)n * Cin + ci) * H * W;
+      for (size_t i = 0; i < (size_t)H * W; ++i) o[i] = (float)acc[i];
+      free(acc);
+    }
+}
+
+/* dW[co,ci,ky,kx] = Σ_{n,ho,wo} dY[n,co,ho,wo]·X[n,ci,ho·s−p+ky,wo·s−p+kx];  db[co] = Σ dY[n,co,:,:] */
+void oracle_conv2d_wgrad(float* dw, float* db, const float* x, const float* dy, int B, int Cin, int H, int W, int Cout,
+                         int kh, int kw, int stride, int pad) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx) {
+          double acc = 0.0;
+          for (int n = 0; n < B; ++n) {
+            const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+            const float* ip = x + ((size_t)n * Cin + ci) * H * W;
+            for (int ho = 0; ho < Ho; ++ho) {
+              const int h = ho * stride - pad + ky;
+              if (h < 0 || h >= H) continue;
+              for (int wo = 0; wo < Wo; ++wo) {
+                const int xx = wo * stride - pad + kx;
+                if (xx < 0 || xx >= W) continue;
+                acc += (double)g[(size_t)ho * Wo + wo] * (double)ip[(size_t)h * W + xx];
+              }
+            }
+          }
+          dw[(((size_t)co * Cin + ci) * kh + ky) * kw + kx] = (float)acc;
+        }
+  if (db) {
+#pragma omp parallel for
+    for (int co = 0; co < Cout; ++co) {
+      double acc = 0.0;
+      for (int n = 0; n < B; ++n) {
+        const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+        for (int i = 0; i < Ho * Wo; ++i) acc += g[i];
+      }
+      db[co] = (float)acc;
+    }
+  }
+}
+
+/* FullyConnected backward: dX = dY·W, dW = dYᵀ·X, db = Σ_b dY */
+void oracle_fc_backward(float* dx, float* dw, float* db, const float* dy, const float* x, const float* w, int B, int I, int O) {
+#pragma omp parallel for
+  for (int b = 0; b < B; ++b) {
+    double* acc = (double*)calloc((size_t)I, sizeof(double));
+    for (int o = 0; o < O; ++o) {
+      const double g = dy[(size_t)b * O + o];
+      const float* wr = w + (size_t)o * I;
+      for (int k = 0; k < I; ++k) acc[k] += g * (double)wr[k];
+    }
+    for (int k = 0; k < I; ++k) dx[(size_t)b * I + k] = (float)acc[k];
+    free(acc);
+  }
+#pragma omp parallel for
+  for (int o = 0; o < O; ++o) {
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += dy[(size_t)b * O + o];
+    db[o] = (float)s;
+    for (int k = 0; k < I; ++k) {
+      double a = 0.0;
+      for (int b = 0; b < B; ++b) a += (double)dy[(size_t)b * O + o] * (double)x[(size_t)b * I + k];
+      dw[(size_t)o * I + k] = (float)a;
+    }
+  }
+}

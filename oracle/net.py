@@ -84,3 +84,43 @@ def bilinear_upsample_weights(C, k=32):
         y = (i // k) % k
         w[i] = (1 - abs(x / f - c)) * (1 - abs(y / f - c))
     return w.reshape(C, 1, k, k)
+
+
+# ------------------------------------------------------------------------------------------------ backward ----
+def lrelu_backward(dy, y, slope):
+    """MXNet LeakyReLU(leaky) gradient from the saved OUTPUT: dy where y > 0, slope*dy elsewhere."""
+    dy, y = np.asarray(dy, f32), np.asarray(y, f32)
+    return np.where(y > 0, dy, dy * f32(slope)).astype(f32)
+
+
+def conv2d_backward(x, w, dy, stride, pad, need_dx=True):
+    """Gradients of Convolution (bias + no activation): -> (dx or None, dw, db)."""
+    x, w, dy = _c(x), _c(w), _c(dy)
+    B, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    dw, db = np.empty_like(w), np.empty((Cout,), f32)
+    _lib().oracle_conv2d_wgrad(_p(dw), _p(db), _p(x), _p(dy), B, Cin, H, W, Cout, kh, kw, stride, pad)
+    dx = None
+    if need_dx:
+        dx = np.empty_like(x)
+        _lib().oracle_conv2d_dgrad(_p(dx), _p(dy), _p(w), B, Cin, H, W, Cout, kh, kw, stride, pad)
+    return dx, dw, db
+
+
+def fc_backward(x, w, dy):
+    x, w, dy = _c(x), _c(w), _c(dy)
+    B, I = x.shape
+    O = w.shape[0]
+    dx, dw, db = np.empty_like(x), np.empty_like(w), np.empty((O,), f32)
+    _lib().oracle_fc_backward(_p(dx), _p(dw), _p(db), _p(dy), _p(x), _p(w), B, I, O)
+    return dx, dw, db
+
+
+def sgd_mom_update(w, mom, g, lr, wd, momentum, rescale=1.0, clip=None):
+    """MXNet sgd_mom_update: mom = momentum*mom - lr*(rescale*g [clipped] + wd*w); w += mom (float32)."""
+    w, mom, g = np.asarray(w, f32), np.asarray(mom, f32), np.asarray(g, f32)
+    gg = (g * f32(rescale)).astype(f32)
+    if clip is not None and clip > 0:
+        gg = np.clip(gg, -f32(clip), f32(clip))
+    mom2 = (f32(momentum) * mom - f32(lr) * (gg + f32(wd) * w).astype(f32)).astype(f32)
+    return (w + mom2).astype(f32), mom2

@@ -104,3 +104,46 @@ def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coor
                                    T_stds, rot_coord)
     out["pose_est"] = pose
     return out
+
+
+def train_pose_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", lw_pm=0.1,
+                         num_3d_sample=3000, normalize_3d=0.1, loss_type="L1", sigma=1.0):
+    """Forward + backward of the pose branch of the training graph (deepIM_flownet.py:367-546, losses :209-312; backward =
+    module.backward, deepim/core/module.py:1131-1137): returns (loss_sum, grads dict keyed like params, forward dict)."""
+    from . import heads
+    x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
+                           data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"),
+                           mask_gt_observed=label["mask_gt_observed"])
+    acts = encoder(params, x)
+    B = x.shape[0]
+    feat = acts["conv6_1"].reshape(B, -1)
+    fc6 = net.fc(feat, params["fc6_weight"], params["fc6_bias"], SLOPE)
+    fc7 = net.fc(fc6, params["fc7_weight"], params["fc7_bias"], SLOPE)
+    rot = net.fc(fc7, params["rot_weight"], params["rot_bias"], 1.0)
+    ztr = net.fc(fc7, params["trans_weight"], params["trans_bias"], 1.0)
+    rot_norm = heads.l2_normalize(rot)
+    trans_est = zoom.zoom_trans(zf, ztr, b_inv_zoom=True)
+    pts = se3.transform3d_forward(label["point_cloud_model"], rot_norm, trans_est, data["src_pose"], T_means, T_stds, rot_coord)
+    loss, loss_sum, d_pts = heads.point_matching_loss(pts, label["point_cloud_observed"], label["point_cloud_weights"],
+                                                      normalize_3d, loss_type, sigma, lw_pm / num_3d_sample)
+    fwd = dict(acts, net_input=x, zoom_factor=zf, fc6=fc6, fc7=fc7, rot=rot, zoom_trans=ztr, rot_norm=rot_norm,
+               trans_est=trans_est, points_est=pts, pm_loss=loss)
+    # ---- backward
+    d_rot_norm, d_trans_est = se3.transform3d_backward(d_pts, label["point_cloud_model"], rot_norm, trans_est, data["src_pose"],
+                                                        T_means, T_stds, rot_coord)
+    d_rot = heads.l2_normalize_backward(d_rot_norm, rot)
+    d_ztr = zoom.zoom_trans_backward(zf, d_trans_est, b_inv_zoom=True, b_zoom_grad=False)
+    g = {}
+    dx_r, g["rot_weight"], g["rot_bias"] = net.fc_backward(fc7, params["rot_weight"], d_rot)
+    dx_t, g["trans_weight"], g["trans_bias"] = net.fc_backward(fc7, params["trans_weight"], d_ztr)
+    d = net.lrelu_backward((dx_r + dx_t).astype(f32), fc7, SLOPE)
+    d, g["fc7_weight"], g["fc7_bias"] = net.fc_backward(fc6, params["fc7_weight"], d)
+    d = net.lrelu_backward(d, fc6, SLOPE)
+    d, g["fc6_weight"], g["fc6_bias"] = net.fc_backward(feat, params["fc6_weight"], d)
+    d = d.reshape(acts["conv6_1"].shape)
+    for li in range(len(ENCODER) - 1, -1, -1):
+        name, s, p = ENCODER[li]
+        src = x if li == 0 else acts[ENCODER[li - 1][0]]
+        dz = net.lrelu_backward(d, acts[name], SLOPE)
+        d, g[name + "_weight"], g[name + "_bias"] = net.conv2d_backward(src, params[name + "_weight"], dz, s, p, need_dx=li > 0)
+    return loss_sum, g, fwd

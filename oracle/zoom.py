@@ -294,13 +294,15 @@ def zoom_trans_backward(zoom_factor, out_grad, b_inv_zoom=False, b_zoom_grad=Fal
 
 
 def net_input(image_observed, image_rendered, mask_observed, mask_rendered, src_pose, K, pixel_means,
-              depth_observed=None, depth_rendered=None):
+              depth_observed=None, depth_rendered=None, mask_gt_observed=None):
     """Front end of the test graph (deepIM_flownet.py:563-622 + :33-62): ZoomMask (gt ≡ observed)
     → ZoomImageWithFactor [→ ZoomDepth] → /255 → Concat."""
     if mask_observed is None:   # INPUT_MASK=False: ZoomImage computes the factor (deepIM_flownet.py:594-605)
         zio, zir, zf = zoom_image(image_observed, image_rendered, src_pose, K, pixel_means)
     else:
-        zmo, _, zmr, zf = zoom_mask(mask_observed, mask_observed, mask_rendered, src_pose, K)
+        # test graph: mask_gt_observed is mask_observed (deepIM_flownet.py:564); training graph: the real gt mask (:392-412)
+        zmo, _, zmr, zf = zoom_mask(mask_observed, mask_observed if mask_gt_observed is None else mask_gt_observed,
+                                    mask_rendered, src_pose, K)
         zio, zir = zoom_image_with_factor(zf, image_observed, image_rendered, pixel_means)
     parts = [(zio / f32(255.0)).astype(f32), (zir / f32(255.0)).astype(f32)]
     if depth_observed is not None:

@@ -83,3 +83,38 @@ def test_conv_order_switch_matches_torch_and_itself():
     xi = rng.integers(-3, 4, x.shape).astype(np.float32)     # small integers: every partial sum is exact in fp32
     wi = rng.integers(-3, 4, w.shape).astype(np.float32)
     np.testing.assert_array_equal(onet.conv2d(xi, wi, None, 1, 1, 1.0), onet.conv2d(xi, wi, None, 1, 1, 1.0, pair_order=True))
+
+
+def test_oracle_backward_matches_torch_autograd():
+    """oracle/net.c conv / FC backward and the LeakyReLU / SGD helpers against torch autograd / torch.optim.SGD-style math."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    from oracle import net as onet
+    rng = np.random.default_rng(0)
+    for (B, cin, H, W, cout, k, s, p) in [(2, 3, 9, 11, 4, 3, 1, 1), (1, 4, 12, 10, 5, 5, 2, 2), (2, 2, 13, 9, 3, 7, 2, 3), (1, 6, 8, 10, 4, 3, 2, 1)]:
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        xt, wt, bt = (torch.tensor(a, requires_grad=True) for a in (x, w, b))
+        y = F.leaky_relu(F.conv2d(xt, wt, bt, stride=s, padding=p), 0.1)
+        dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(torch.tensor(dy))
+        dz = onet.lrelu_backward(dy, y.detach().numpy(), 0.1)
+        dx, dw, db = onet.conv2d_backward(x, w, dz, s, p)
+        for got, ref in ((dx, xt.grad), (dw, wt.grad), (db, bt.grad)):
+            np.testing.assert_allclose(got, ref.numpy(), rtol=1e-4, atol=2e-5)
+    x, w, dy = (rng.standard_normal(sh).astype(np.float32) for sh in ((3, 20), (5, 20), (3, 5)))
+    xt, wt, bt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True), torch.zeros(5, requires_grad=True)
+    F.linear(xt, wt, bt).backward(torch.tensor(dy))
+    for got, ref in zip(onet.fc_backward(x, w, dy), (xt.grad, wt.grad, bt.grad)):
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-5, atol=1e-6)
+    # MXNet sgd_mom_update == torch SGD with the learning rate folded into the momentum buffer
+    wv, g = rng.standard_normal(50).astype(np.float32), rng.standard_normal(50).astype(np.float32)
+    w1, m1 = onet.sgd_mom_update(wv, np.zeros(50, np.float32), g, 0.1, 0.01, 0.9)
+    w2, _ = onet.sgd_mom_update(w1, m1, g, 0.1, 0.01, 0.9)
+    pt = torch.tensor(wv, requires_grad=True)
+    opt = torch.optim.SGD([pt], lr=0.1, momentum=0.9, weight_decay=0.01)
+    for _ in range(2):
+        pt.grad = torch.tensor(g)
+        opt.step()
+    np.testing.assert_allclose(w2, pt.detach().numpy(), rtol=1e-5, atol=1e-6)
