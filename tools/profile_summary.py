@@ -47,7 +47,7 @@ def cmd_stats(a):
     out = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps %d --warmup 2 --batch %d" % (a.iters // 4, a.batch),
            "# (B=%d/GPU, 4 iters, 480x640, 1x MI355X). Two views:" % a.batch,
            "# (1) timed region only = the last %d pose-refinement iterations of the kernel trace (the full-run --stats table below also" % a.iters,
-           "#     contains the priming pass, where each conv geometry is launched ~30x by the split-K autotuner);",
+           "#     contains the priming and warm-up passes and the one-time weight packing);",
            "kernel,calls,total_us,avg_us,pct"]
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.append("%s,%d,%.1f,%.2f,%.2f" % (n.replace(",", ";"), c, t / 1e3, t / 1e3 / c, 100.0 * t / total))
@@ -71,7 +71,7 @@ def cmd_traffic(a):
         for r in rows[marks[-a.iters - 1] + 1:]:       # the last `iters` iterations: priming/autotuning launches excluded
             n = short(r["Kernel_Name"])
             key = "conv kernels + split-K reduces" if is_conv(n) else (
-                "zoom front end (bbox, zoom_factor, resample)" if re.match(r"bbox|zoom_factor|resample", n) else (
+                "zoom front end (bbox, zoom_factor, resample)" if re.match(r"bbox|zoom_factor|resample|zoom_concat", n) else (
                     "re-render + mask update" if re.match(r"project|raster|resolve|depth_to_mask|mask_b", n) else (
                         "fc / pose head / rt_transform" if re.match(r"fc_|pose_head|rt_transform", n) else n)))
             g[key][0] += 1
@@ -81,7 +81,7 @@ def cmd_traffic(a):
     lines = ["# HBM traffic of the hot path from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
              "cmd: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1 --batch %d` " % a.batch +
              "(and the same with WRITE_SIZE); the last %d pose-refinement iterations of %d pairs each (warm-up + timed step; the "
-             "priming pass with its autotuning launches is cut off at the pose-update kernel). Counter unit = KB (x1024 B)." % (a.iters, a.batch), "",
+             "priming pass is cut off at the pose-update kernel). Counter unit = KB (x1024 B)." % (a.iters, a.batch), "",
              "FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-B requests at "
              "64 B for wide coalesced reads; the dword loads of the conv kernels are uncalibrated, so 'corrected' is an upper bound).", "",
              "| kernel group | dispatches | FETCH raw MB/iter | FETCH corrected MB/iter | WRITE MB/iter |", "|---|---|---|---|---|"]
