@@ -432,17 +432,30 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
   }
 }
 
-// split-K second pass: out[pix][c] = f16(lrelu(Σ_s partial[s][pix][c] + bias[c])), fixed order
+// split-K second pass: out[pix][c] = f16(lrelu(Σ_s partial[s][pix][c] + bias[c])), slices added in order; 4 channels per thread
+// (dwordx4 loads of every slice, one 8-byte store); Cout % 4 == 0
 __global__ __launch_bounds__(256) void splitk_f16_reduce_kernel(_Float16* __restrict__ out, const float* __restrict__ partial,
-                                                                const float* __restrict__ bias, long total, int S,
+                                                                const float* __restrict__ bias, long total4, int S,
                                                                 int Cout, float slope) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  float v = partial[i];
-  for (int s = 1; s < S; ++s) v += partial[(long)s * total + i];
-  v = v + (bias ? bias[i % Cout] : 0.f);
-  v = v > 0.f ? v : v * slope;
-  out[i] = (_Float16)v;
+  if (i >= total4) return;
+  const float4* p4 = reinterpret_cast<const float4*>(partial);
+  float4 v = p4[i];
+#pragma unroll 4
+  for (int s = 1; s < S; ++s) {
+    const float4 u = p4[(long)s * total4 + i];
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  const int c0 = (int)((i * 4) % Cout);
+  float r[4] = {v.x, v.y, v.z, v.w};
+  h4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = r[k] + (bias ? bias[c0 + k] : 0.f);
+    x = x > 0.f ? x : x * slope;
+    o[k] = (_Float16)x;
+  }
+  *reinterpret_cast<h4*>(out + i * 4) = o;
 }
 
 // K order. A k-octet q is 8 consecutive input channels of one tap. With Cin_pad a multiple of 64 the octets run
@@ -611,7 +624,7 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
       if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
       const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
-                         (s_ > 1 ? 1.5f + 0.004f * (float)((long)blocks * s_) * (float)(BM * BN) / 16384.f : 0.f);
+                         (s_ > 1 ? 1.5f + 0.009f * (float)((long)blocks * s_) * (float)(BM * BN) / 16384.f : 0.f);   // reduce: 8 B of fp32 partials written + read per output per slice
       if (cost < best * 0.985f) { best = cost; ks = s_; }
     }
   }
@@ -659,9 +672,9 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   else DI_F16_LAUNCH(2, 2, 4, 4)
 #undef DI_F16_LAUNCH
   if (p.ksplit > 1) {
-    const long total = p.npix * Cout;
-    hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out,
-                       p.partial, bias, total, p.ksplit, Cout, slope);
+    const long total4 = p.npix * Cout / 4;
+    hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out,
+                       p.partial, bias, total4, p.ksplit, Cout, slope);
   }
   DI_LAUNCH_CHECK();
   return 0;
