@@ -119,6 +119,8 @@ def main():
                     "FlowNetS decoder and the mask / flow heads in every iteration (NOT the headline)")
     ap.add_argument("--no-cpu-onednn", action="store_true", help="skip the labelled secondary CPU figure (network forward "
                     "through torch-CPU = oneDNN, as MXNet-MKL would run it; imports torch after the timed region, N=1 only)")
+    ap.add_argument("--autotune", action="store_true", help="dev: let the library time split-K factors per conv geometry on "
+                    "the first call instead of using the deterministic cost-model plan")
     ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     args = ap.parse_args()
@@ -137,6 +139,8 @@ def main():
 
     ctx = Context.get(device_id)
     h = ctx.handle
+    if args.autotune:
+        lib.deepim_set_option(h, b"conv_autotune", 1)
     comm = parallel.PoseComm(ctx, rdzv) if (world > 1 and backend == "rccl") else None
     NIT = args.iters
     if args.global_batch:

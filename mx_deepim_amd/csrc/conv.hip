@@ -1095,9 +1095,9 @@ struct TileChoice { int bm, bn, ksplit, tail_s; };
 //   cost(s) = ceil(tiles·s / 256) · ceil(nchunk / s)        MFMA time: blocks sharing a CU share its matrix pipes, so what
 //                                                            counts is the most loaded CU, in units of one K chunk (≈1 µs)
 //           + [s > 1] · (3 + 0.016 · tiles · s)             split-K reduce: launch + 64 KB of partial sums per block
-// over s ∈ {1,2,3,4,6,8,10,12,16,20,24}, s ≤ nchunk/4, tiles·s ≤ 4096; ties go to the smaller s.
+// over s ∈ {1,…,10,12,14,16,20,24}, s ≤ nchunk/4, tiles·s ≤ 4096; ties go to the smaller s.
 int plan_ksplit(long tiles, int nchunk) {
-  const int cands[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24};
+  const int cands[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24};
   float best = 1e30f;
   int best_s = 1;
   for (int s : cands) {
@@ -1204,8 +1204,8 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
       }
     if (!found && !ctx->capturing) {
       const int tiles = di_div_up(p.Cout, t.bm) * di_div_up(p.npix, t.bn) * classes;
-      int cands[16], nc = 0;
-      const int base[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24};
+      int cands[24], nc = 0;
+      const int base[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24};
       for (int c : base)
         if ((c == 1 || (long)tiles * c <= 4096) && c <= max(1, p.nchunk / 4)) cands[nc++] = c;
       // tail split (LDS-free kernel only, opt-in): cut just the tiles of the under-filled last round, so that their
@@ -1217,7 +1217,7 @@ int launch_conv(deepim_ctx* ctx, const ConvParams& p, int classes) {
         if (tiles >= slots && R > 0) {
           const int s0 = min(slots / R, max(1, p.nchunk / 4));
           for (int sN : {s0, s0 - 1, s0 * 2})
-            if (sN >= 2 && sN <= max(1, p.nchunk / 4) && nc < 16) cands[nc++] = -sN;
+            if (sN >= 2 && sN <= max(1, p.nchunk / 4) && nc < 24) cands[nc++] = -sN;
         }
       }
       struct EventPair {   // destroyed on every exit path, including the DI_CHECK early returns below

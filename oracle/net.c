@@ -9,6 +9,9 @@
  * conv/deconv parity is checked bit-for-bit.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -24,37 +27,50 @@ void oracle_conv2d_order(float* out, const float* in, const float* w, const floa
                          int Cout, int kh, int kw, int stride, int pad, float slope, int pair_order) {
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   const int khw = kh * kw, K = Cin * khw;
-#pragma omp parallel for collapse(2) schedule(dynamic)
+  /* tasks = (sample, output channel, block of output rows): enough of them for every host core even at B = 1 with 64
+   * channels; splitting rows does not change any output's own fmaf chain */
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  int RB = (4 * nthreads + B * Cout - 1) / (B * Cout);
+  if (RB < 1) RB = 1;
+  if (RB > Ho) RB = Ho;
+  const int rows_per = (Ho + RB - 1) / RB;
+#pragma omp parallel for collapse(3) schedule(dynamic)
   for (int n = 0; n < B; ++n)
-    for (int co = 0; co < Cout; ++co) {
-      float* acc = out + ((size_t)n * Cout + co) * Ho * Wo;
-      memset(acc, 0, sizeof(float) * Ho * Wo);
-      for (int s = 0; s < K; ++s) {
-        int ci, t;
-        if (pair_order == 2) { const int g = s >> 3, e = s & 7; ci = 8 * (g / khw) + (e >> 1) + 4 * (e & 1); t = g % khw; }
-        else if (pair_order) { const int g = s >> 1; ci = 2 * (g / khw) + (s & 1); t = g % khw; }
-        else { ci = s / khw; t = s % khw; }
-        const int ky = t / kw, kx = t % kw;
-        const float* ip = in + ((size_t)n * Cin + ci) * H * W;
-        const float wv = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
-        int wo_lo = 0, wo_hi = Wo;
-        while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
-        while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
-        for (int ho = 0; ho < Ho; ++ho) {
-          const int hi = ho * stride - pad + ky;
-          if (hi < 0 || hi >= H) continue;
-          const float* row = ip + (size_t)hi * W - pad + kx;
-          float* arow = acc + (size_t)ho * Wo;
-          if (stride == 1) {
-            for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo], arow[wo]);
-          } else {
-            for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo * stride], arow[wo]);
+    for (int co = 0; co < Cout; ++co)
+      for (int rb = 0; rb < RB; ++rb) {
+        const int r0 = rb * rows_per, r1 = r0 + rows_per < Ho ? r0 + rows_per : Ho;
+        if (r0 >= r1) continue;
+        float* acc = out + ((size_t)n * Cout + co) * Ho * Wo;
+        memset(acc + (size_t)r0 * Wo, 0, sizeof(float) * (size_t)(r1 - r0) * Wo);
+        for (int s = 0; s < K; ++s) {
+          int ci, t;
+          if (pair_order == 2) { const int g = s >> 3, e = s & 7; ci = 8 * (g / khw) + (e >> 1) + 4 * (e & 1); t = g % khw; }
+          else if (pair_order) { const int g = s >> 1; ci = 2 * (g / khw) + (s & 1); t = g % khw; }
+          else { ci = s / khw; t = s % khw; }
+          const int ky = t / kw, kx = t % kw;
+          const float* ip = in + ((size_t)n * Cin + ci) * H * W;
+          const float wv = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
+          int wo_lo = 0, wo_hi = Wo;
+          while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
+          while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
+          for (int ho = r0; ho < r1; ++ho) {
+            const int hi = ho * stride - pad + ky;
+            if (hi < 0 || hi >= H) continue;
+            const float* row = ip + (size_t)hi * W - pad + kx;
+            float* arow = acc + (size_t)ho * Wo;
+            if (stride == 1) {
+              for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo], arow[wo]);
+            } else {
+              for (int wo = wo_lo; wo < wo_hi; ++wo) arow[wo] = fmaf(wv, row[wo * stride], arow[wo]);
+            }
           }
         }
+        const float bv = bias ? bias[co] : 0.f;
+        for (size_t i = (size_t)r0 * Wo; i < (size_t)r1 * Wo; ++i) acc[i] = lrelu(acc[i] + bv, slope);
       }
-      const float bv = bias ? bias[co] : 0.f;
-      for (int i = 0; i < Ho * Wo; ++i) acc[i] = lrelu(acc[i] + bv, slope);
-    }
 }
 
 void oracle_conv2d(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
