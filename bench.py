@@ -119,6 +119,9 @@ def main():
                     "FlowNetS decoder and the mask / flow heads in every iteration (NOT the headline)")
     ap.add_argument("--no-cpu-onednn", action="store_true", help="skip the labelled secondary CPU figure (network forward "
                     "through torch-CPU = oneDNN, as MXNet-MKL would run it; imports torch after the timed region, N=1 only)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short secondary runs of the other BASELINE "
+                    "configurations (B=16, B=4 share of config 3, config 4 heads, config 5 fp16) that the default N=1 run "
+                    "appends to its JSON line as `other_configs`")
     ap.add_argument("--autotune", action="store_true", help="dev: let the library time split-K factors per conv geometry on "
                     "the first call instead of using the deterministic cost-model plan")
     ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
@@ -309,10 +312,37 @@ def main():
                     out["cpu_baseline"]["secondary_onednn"] = cpu_onednn_secondary(cfg)
                 except ImportError as e:       # torch is test/bench tooling only; the figure is optional
                     out["cpu_baseline"]["secondary_onednn"] = {"skipped": str(e)}
+        default_run = (world == 1 and not (args.fp16 or args.heads or args.prestaged or args.global_batch or args.layers)
+                       and args.batch == 32 and not args.no_other_configs and not args.no_cpu_baseline)
+        if default_run:
+            out["other_configs"] = other_configs()
         print(json.dumps(out))
     if comm is not None:
         comm.close()
     rdzv.close()
+
+
+def other_configs():
+    """Short secondary runs (separate processes, after the timed region of the headline) of the other BASELINE.json
+    configurations on this GPU, so that they are measured by the same driver command: configs[1] (batch 16), the per-GPU share
+    of configs[2] (batch 4), configs[3] (decoder + mask / flow heads in every iteration) and configs[4] (fp16 conv path at
+    its per-GPU share, batch 8). Each entry: value (it/s), ms_per_step, conv-stack TFLOP/s and its fraction of the peak."""
+    import subprocess
+    runs = {"configs[1]_ape_batch16": ["--batch", "16"], "configs[2]_per_gpu_share_batch4": ["--batch", "4"],
+            "configs[3]_decoder_mask_flow_heads_batch32": ["--heads"], "configs[4]_fp16_conv_per_gpu_share_batch8": ["--fp16", "--batch", "8"],
+            "fp16_conv_batch32": ["--fp16"]}
+    res = {}
+    for name, extra in runs.items():
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                                "--no-other-configs"] + extra, capture_output=True, text=True, timeout=240)
+            j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
+                         "workload": j["config"]["workload"], "conv_tflops": j["roofline"]["achieved"],
+                         "conv_peak_tflops": j["roofline"]["peak"], "conv_frac": j["roofline"]["frac"]}
+        except Exception as e:      # a secondary figure must never break the headline line
+            res[name] = {"error": repr(e)[:200]}
+    return res
 
 
 def layer_timings(ctx, net, reps=5):
