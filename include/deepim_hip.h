@@ -378,6 +378,17 @@ int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, 
 int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw);
 /* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
 int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
+/* the same with an offset: out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x], zeros elsewhere — also the backward of
+ * Crop (stride 1): the gradient of a cropped Deconvolution output put back into the full frame */
+int deepim_scatter2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride,
+                     int off_y, int off_x);
+/* data gradient of deepim_upsample16_crop_forward (depthwise k32 s16 transposed conv with fixed bilinear weights, lr_mult 0:
+ * deepIM_flownet.py:185-200,326-340): d_in (B,C,H,W) from dy (B,C,Ho,Wo) */
+int deepim_upsample16_crop_backward(deepim_ctx* ctx, float* d_in, const float* dy, const float* w, int B, int C, int H, int W,
+                                    int Ho, int Wo, int crop_y, int crop_x, float scale);
+/* backward of Concat: dst (B,C,hw) = channels [src_coff, src_coff+C) of src (B,src_ctotal,hw) */
+int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float* src, int src_ctotal, int src_coff, int C, int B,
+                            size_t hw);
 /* dw (Cout,Cin,kh,kw) = sum over n, output pixels of dz (B,Cout,Ho,Wo) x the matching taps of x (B,Cin,H,W): MFMA GEMM
  * with the pixels as the reduction dimension; Ho*Wo must be a multiple of 4 */
 int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W, int Cout,

@@ -55,20 +55,44 @@ __global__ __launch_bounds__(256) void conv_flip_weights_kernel(float* __restric
   wt[i] = w[(((long)co * Cin + ci) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)];
 }
 
-// out (BC,Hd,Wd) = zeros except out[bc][stride*y][stride*x] = in[bc][y][x]
+// out (BC,Hd,Wd) = zeros except out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x]  (dilation and/or un-crop)
 __global__ __launch_bounds__(256) void dilate2d_kernel(float* __restrict__ out, const float* __restrict__ in, int Ho, int Wo,
-                                                       int Hd, int Wd, int stride, long total) {
+                                                       int Hd, int Wd, int stride, int off_y, int off_x, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int xd = (int)(i % Wd);
-  const int yd = (int)((i / Wd) % Hd);
+  const int xd = (int)(i % Wd) - off_x;
+  const int yd = (int)((i / Wd) % Hd) - off_y;
   const long bc = i / ((long)Wd * Hd);
   float v = 0.f;
-  if (yd % stride == 0 && xd % stride == 0) {
+  if (yd >= 0 && xd >= 0 && yd % stride == 0 && xd % stride == 0) {
     const int y = yd / stride, x = xd / stride;
     if (y < Ho && x < Wo) v = in[(bc * Ho + y) * Wo + x];
   }
   out[i] = v;
+}
+
+// data gradient of the depthwise k32 s16 transposed convolution + crop (fixed bilinear weights, deepIM_flownet.py:185-200,
+// 326-340): d_in[bc][iy][ix] = scale * sum_{ky,kx} dy[bc][16iy+ky-cy][16ix+kx-cx] * w[c][ky][kx]; one 64-lane group per output
+// element, lane = (ky parity rows...) sums 16 taps, fixed-shape butterfly
+__global__ __launch_bounds__(256) void upsample16_backward_kernel(float* __restrict__ d_in, const float* __restrict__ dy,
+                                                                  const float* __restrict__ w, int C, int H, int W, int Ho,
+                                                                  int Wo, int crop_y, int crop_x, float scale, long total) {
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per low-resolution element
+  const int lane = threadIdx.x & 63;
+  if (e >= total) return;
+  const int ix = (int)(e % W), iy = (int)((e / W) % H);
+  const long bc = e / ((long)W * H);
+  const float* g = dy + bc * (long)Ho * Wo;
+  const float* wp = w + (bc % C) * 1024;
+  float acc = 0.f;
+  for (int t = lane; t < 1024; t += 64) {                      // lane takes taps t, t+64, ... in order
+    const int ky = t >> 5, kx = t & 31;
+    const int y = 16 * iy + ky - crop_y, x = 16 * ix + kx - crop_x;
+    if (y >= 0 && y < Ho && x >= 0 && x < Wo) acc = fmaf(g[(long)y * Wo + x], wp[t], acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) d_in[e] = acc * scale;
 }
 
 // ------------------------------------------------------------------------------------------------------- wgrad ----
@@ -259,15 +283,41 @@ extern "C" int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float*
   return 0;
 }
 
-extern "C" int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd,
-                               int stride) {
+extern "C" int deepim_scatter2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd,
+                                int stride, int off_y, int off_x) {
   DI_DEVICE(ctx);
-  DI_REQUIRE(stride >= 1 && Hd >= (Ho - 1) * stride + 1 && Wd >= (Wo - 1) * stride + 1, "dilate2d: output too small");
+  DI_REQUIRE(stride >= 1 && off_y >= 0 && off_x >= 0 && Hd >= off_y + (Ho - 1) * stride + 1 && Wd >= off_x + (Wo - 1) * stride + 1,
+             "scatter2d: output too small");
   const long total = (long)BC * Hd * Wd;
   if (total == 0) return 0;
   hipLaunchKernelGGL(dilate2d_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out, in, Ho, Wo, Hd, Wd, stride,
-                     total);
+                     off_y, off_x, total);
   DI_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd,
+                               int stride) {
+  return deepim_scatter2d(ctx, out, in, BC, Ho, Wo, Hd, Wd, stride, 0, 0);
+}
+
+extern "C" int deepim_upsample16_crop_backward(deepim_ctx* ctx, float* d_in, const float* dy, const float* w, int B, int C,
+                                               int H, int W, int Ho, int Wo, int crop_y, int crop_x, float scale) {
+  DI_DEVICE(ctx);
+  const long total = (long)B * C * H * W;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(upsample16_backward_kernel, dim3(di_div_up(total, 4)), dim3(256), 0, ctx->stream, d_in, dy, w, C, H, W, Ho,
+                     Wo, crop_y, crop_x, scale, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// dst (B,C,hw) = channels [coff, coff+C) of src (B,Ctotal,hw): the backward of Concat (and the inverse of deepim_copy_channels)
+extern "C" int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float* src, int src_ctotal, int src_coff, int C, int B,
+                                       size_t hw) {
+  DI_DEVICE(ctx);
+  if (B == 0 || C == 0) return 0;
+  DI_CHECK(hipMemcpy2DAsync(dst, (size_t)C * hw * sizeof(float), src + (size_t)src_coff * hw, (size_t)src_ctotal * hw * sizeof(float),
+                            (size_t)C * hw * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
 

@@ -64,21 +64,20 @@ class deepIM_flownet(object):
         return self.get_test_symbol_share(cfg)
 
     def get_train_symbol(self, cfg):
-        """Training graph of the POSE branch (deepIM_flownet.py:367-546 with get_convs :32-116 and the se3 part of
-        get_loss :209-312): zoom (region from mask_gt_observed) → encoder → fc6/fc7 → rot → L2Normalization, trans →
-        inverse ZoomTrans → Transform3D → point-matching loss [+ rot / trans distance losses], then backward through all of
-        it and an SGD step, resident on the device. The FlowNetS decoder with the flow / mask losses (:120-207, :317-361) has
-        a forward here but no backward yet, so a config that trains those heads is refused."""
+        """Training graph (deepIM_flownet.py:367-546 with get_convs :32-169 and get_loss :170-365): zoom (region from
+        mask_gt_observed) → encoder → fc6/fc7 → rot → L2Normalization, trans → inverse ZoomTrans → Transform3D →
+        point-matching loss; with network.PRED_FLOW / PRED_MASK also the FlowNetS refinement decoder, Convolution3 →
+        upsampling → flow loss against the ZoomFlow-ed labels, and mask_conv3 → mask_upsampling →
+        LogisticRegressionOutput against the zoomed mask_gt_observed. forward_train / backward / update run all of it
+        resident on the device."""
         n = cfg.network
-        if bool(n.PRED_FLOW) or bool(n.PRED_MASK):
-            raise NotImplementedError("training graph: the backward of the decoder / flow / mask heads is not built — "
-                                      "set network.PRED_FLOW = PRED_MASK = False for the pose branch (SURVEY §8f-4)")
         if not cfg.train_iter.SE3_PM_LOSS:
             raise NotImplementedError("training graph needs train_iter.SE3_PM_LOSS")
         self.get_test_symbol_share(cfg)
         self.is_train = True
         self.nc8 = False          # NCHW activations: what the backward kernels read
-        self.with_mask_head = self.with_flow_head = self.with_decoder = False
+        self.with_mask_head, self.with_flow_head = bool(n.PRED_MASK), bool(n.PRED_FLOW)    # :183, :314
+        self.with_decoder = self.with_mask_head or self.with_flow_head
         return self
 
     def get_test_symbol_share(self, cfg):
@@ -414,7 +413,7 @@ def _train_methods():
         """bind() + gradient, momentum and workspace buffers for one training-style iteration."""
         assert getattr(self, "is_train", False), "call get_symbol(cfg, is_train=True) first"
         self.bind(ctx, batch_size, arg_params)
-        B = self.B
+        B, H, W = self.B, self.H, self.W
         self.grad = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
         self.mom = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
         A = self.act
@@ -428,11 +427,34 @@ def _train_methods():
         big = max(int(np.prod(A[g[0]].shape)) for g in self.enc_geom)
         self.ws = {"ga": ctx.empty((big,)), "gb": ctx.empty((big,))}
         dil, wmax, pmax = 4, 4, 4
+        psize = lib.load().deepim_conv_packed_size
         for name, cin, h, w, cout, k, s_, p_ in self.enc_geom[1:]:
             if s_ > 1:
                 dil = max(dil, B * cout * (h - k + 1 + 2 * p_) * (w - k + 1 + 2 * p_))
             wmax = max(wmax, cout * cin * k * k)
-            pmax = max(pmax, lib.load().deepim_conv_packed_size(cin, cout, k, k) // 4)
+            pmax = max(pmax, psize(cin, cout, k, k) // 4)
+        if self.with_decoder:
+            # the un-cropped gradients of the two big transposed convolutions, and the role-swapped weights of the decoder layers
+            dil = max(dil, B * 256 * 32 * 42, B * 512 * 18 * 22)
+            wmax = max(wmax, 1026 * 256 * 16, 1024 * 512 * 16)
+            pmax = max(pmax, psize(1026, 256, 4, 4) // 4, psize(1024, 512, 4, 4) // 4, psize(1026, 2, 3, 3) // 4,
+                       psize(770, 2, 3, 3) // 4)
+            W_ = self.ws
+            W_["d_Concat3"], W_["d_Concat2"] = ctx.empty((B, 770, 30, 40)), ctx.empty((B, 1026, 15, 20))
+            W_["d_skip4"], W_["d_skip5"] = ctx.empty((B, 512, 30, 40)), ctx.empty((B, 512, 15, 20))
+            W_["d_dec61"] = ctx.empty((B, 1024, 8, 10))
+            sl = max(B * 256 * 30 * 40, B * 512 * 15 * 20)
+            W_["sl_dy"], W_["sl_y"] = ctx.empty((sl,)), ctx.empty((sl,))
+            W_["d_flow5"], W_["d_flow6"] = ctx.empty((B, 2, 15, 20)), ctx.empty((B, 2, 8, 10))
+            W_["d_low"] = ctx.empty((B, 2, 30, 40))
+        if self.with_flow_head:
+            A["flow_loss"], A["flow_loss_sum"] = ctx.empty((B, 2, H, W)), ctx.empty((1,))
+            A["zoom_flow_gt"], A["zoom_flow_weights"] = ctx.empty((B, 2, H, W)), ctx.empty((B, 2, H, W))
+            self.ws["d_flow_hi"] = ctx.empty((B, 2, H, W))
+        if self.with_mask_head:
+            A["mask_prob"], A["zoom_mask_gt_observed"] = ctx.empty((B, 1, H, W)), ctx.empty((B, 1, H, W))
+            self.ws["zm_a"], self.ws["zm_b"], self.ws["zm_f"] = ctx.empty((B, 1, H, W)), ctx.empty((B, 1, H, W)), ctx.empty((B, 4))
+            self.ws["d_mask_hi"] = ctx.empty((B, 1, H, W))
         self.ws["dil"], self.ws["wt"], self.ws["wt_packed"] = ctx.empty((dil,)), ctx.empty((wmax,)), ctx.empty((pmax,))
         self.ws["g256a"], self.ws["g256b"] = ctx.empty((B, 256)), ctx.empty((B, 256))
         self.ws["dy7"], self.ws["w7"], self.ws["dw7"], self.ws["db7"] = ctx.empty((B, 7)), ctx.empty((7, 256)), ctx.empty((7, 256)), ctx.empty((7,))
@@ -444,16 +466,39 @@ def _train_methods():
 
     def forward_train(self, data, label):
         """data: image_observed, image_rendered, mask_observed, mask_rendered [, depth_*], src_pose; label:
-        mask_gt_observed, point_cloud_model, point_cloud_weights, point_cloud_observed (device arrays). Returns the
-        point-matching loss sum (device scalar) after filling every activation the backward needs."""
-        A, P, h, B = self.act, self.params, self.ctx.handle, self.B
+        mask_gt_observed, point_cloud_model, point_cloud_weights, point_cloud_observed [, flow, flow_weights] (device arrays).
+        Returns the point-matching loss sum (device scalar) after filling every activation the backward needs; the flow loss
+        and the mask probability land in self.act["flow_loss"] / ["mask_prob"]."""
+        A, P, h, B, H, W = self.act, self.params, self.ctx.handle, self.B, self.H, self.W
         c = ctypes.c_float
+        t = self.cfg.train_iter
         lib.deepim_zoom_concat_train_forward(
             h, data["image_observed"], data["image_rendered"], data["mask_observed"] if self.input_mask else None,
             label["mask_gt_observed"] if self.input_mask else None, data["mask_rendered"] if self.input_mask else None,
             data.get("depth_observed") if self.input_depth else None, data.get("depth_rendered") if self.input_depth else None,
-            data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], B, self.H, self.W)
+            data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], B, H, W)
         self.encoder()
+        if self.with_decoder:
+            self.decoder()
+        if self.with_flow_head:   # deepIM_flownet.py:183-207 (+ the ZoomFlow of the labels, :478-492)
+            self._conv("Convolution3", A["Concat3"], A["flow_lowres"], B, 770, 30, 40, 2, 3, 1, 1, 1.0)
+            lib.deepim_upsample16_crop_forward(h, A["zoom_flow_est"], A["flow_lowres"], P["upsampling_weight"], B, 2, 30, 40,
+                                               H, W, 8, 8, c(1.0))                      # flow_est_crop, in units of NORMALIZE_FLOW
+            lib.deepim_zoom_flow_forward(h, A["zoom_factor"], label["flow"], label["flow_weights"], A["zoom_flow_gt"],
+                                         A["zoom_flow_weights"], 0, B, H, W)
+            lib.deepim_flow_loss(h, A["flow_loss"], A["flow_loss_sum"], self.ws["d_flow_hi"], A["zoom_flow_est"],
+                                 A["zoom_flow_gt"], A["zoom_flow_weights"], c(self.normalize_flow), c(t.LW_FLOW / (480 * 640)),
+                                 B * 2 * H * W)
+        if self.with_mask_head:   # :314-361 (+ ZoomMask of mask_gt_observed, :395-412)
+            self._conv("mask_conv3", A["Concat3"], A["mask_lowres"], B, 770, 30, 40, 1, 3, 1, 1, 1.0)
+            lib.deepim_upsample16_crop_forward(h, A["mask_logits"], A["mask_lowres"], P["mask_upsampling_weight"], B, 1, 30, 40,
+                                               H, W, 8, 8, c(1.0))
+            lib.deepim_zoom_mask_forward(h, data["mask_observed"], label["mask_gt_observed"], data["mask_rendered"],
+                                         data["src_pose"], self.K, self.ws["zm_a"], A["zoom_mask_gt_observed"], self.ws["zm_b"],
+                                         self.ws["zm_f"], B, H, W)
+            # LogisticRegressionOutput: grad = grad_scale / num_output · (p − y), num_output = H·W per sample
+            lib.deepim_mask_logistic(h, A["mask_prob"], self.ws["d_mask_hi"], A["mask_logits"], A["zoom_mask_gt_observed"],
+                                     c(t.LW_MASK / (H * W)), B * H * W)
         flat = A["conv6_1"].reshape((B, -1))
         lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256, c(SLOPE))
         lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256, c(SLOPE))
@@ -463,7 +508,6 @@ def _train_methods():
         lib.deepim_zoom_trans_forward(h, A["zoom_factor"], A["zoom_trans"], A["trans_est"], 1, B)           # :218-225
         lib.deepim_transform3d_forward(h, A["points_est"], label["point_cloud_model"], A["rot_norm"], A["trans_est"],
                                        data["src_pose"], self.T_means, self.T_stds, self.rot_coord, B, self.num_points)
-        t = self.cfg.train_iter
         ltype = {"L1": 0, "L2": 1, "smooth_L1": 2}[t.SE3_PM_LOSS_TYPE]
         lib.deepim_point_matching_loss(h, A["pm_loss"], A["pm_loss_sum"], self.ws["d_points"], A["points_est"],
                                        label["point_cloud_observed"], label["point_cloud_weights"],
@@ -471,6 +515,20 @@ def _train_methods():
                                        c(t.LW_PM / t.NUM_3D_SAMPLE), B, self.num_points)                    # :265-312
         self._train_io = (data, label)
         return A["pm_loss_sum"]
+
+    def _dgrad(self, dx, dz, w_raw, B, cin, hh, ww, cout, k, s_, p_, ho, wo):
+        """dx (B,cin,hh,ww) of a Convolution (cout,cin,k,k; stride s_, pad p_) given dz (B,cout,ho,wo): the forward MFMA conv
+        kernel on the (zero-dilated) dz with the transposed, flipped weights, stride 1, pad k-1-p."""
+        h = self.ctx.handle
+        lib.deepim_conv_flip_weights(h, self.ws["wt"], w_raw, cout, cin, k, k)
+        lib.deepim_conv_pack_weights(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k)
+        g, gh, gw = dz, ho, wo
+        if s_ > 1:
+            gh, gw = hh - k + 1 + 2 * p_, ww - k + 1 + 2 * p_
+            lib.deepim_dilate2d(h, self.ws["dil"], dz, B * cout, ho, wo, gh, gw, s_)
+            g = self.ws["dil"]
+        lib.deepim_conv2d_forward(h, dx, g, self.ws["wt_packed"], None, B, cout, gh, gw, cin, k, k, 1, k - 1 - p_,
+                                  ctypes.c_float(1.0), 0, 0)
 
     def _conv_backward(self, li, dz, dx):
         """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into
@@ -481,24 +539,82 @@ def _train_methods():
         src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
         lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
         lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, k, k, s_, p_)
-        if dx is None:
-            return
-        # data gradient = stride-1 convolution of the (zero-dilated) dz with the transposed, flipped weights, pad k-1-p
-        lib.deepim_conv_flip_weights(h, self.ws["wt"], self.params[name + "_weight"], cout, cin, k, k)
-        lib.deepim_conv_pack_weights(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k)
-        g, gh, gw = dz, ho, wo
-        if s_ > 1:
-            gh, gw = hh - k + 1 + 2 * p_, ww - k + 1 + 2 * p_
-            lib.deepim_dilate2d(h, self.ws["dil"], dz, B * cout, ho, wo, gh, gw, s_)
-            g = self.ws["dil"]
-        lib.deepim_conv2d_forward(h, dx, g, self.ws["wt_packed"], None, B, cout, gh, gw, cin, k, k, 1, k - 1 - p_,
+        if dx is not None:
+            self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, k, s_, p_, ho, wo)
+
+    def _small_conv_backward(self, name, src, dz, dx, cin, hh, ww, cout):
+        """A 3x3 s1 p1 prediction layer (Convolution1/2/3, mask_conv3): gradients into self.grad, data gradient into dx."""
+        h, B = self.ctx.handle, self.B
+        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, hh * ww)
+        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, 3, 3, 1, 1)
+        self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, 3, 1, 1, hh, ww)
+
+    def _head_conv_backward(self, name, d_low, cout, first):
+        """Convolution3 / mask_conv3 on Concat3: the first head writes d_Concat3, the second adds to it."""
+        W_ = self.ws
+        if first:
+            self._small_conv_backward(name, self.act["Concat3"], d_low, W_["d_Concat3"], 770, 30, 40, cout)
+        else:
+            tmp = W_["ga"]
+            self._small_conv_backward(name, self.act["Concat3"], d_low, tmp, 770, 30, 40, cout)
+            lib.deepim_axpy(self.ctx.handle, W_["d_Concat3"], tmp, ctypes.c_float(1.0), W_["d_Concat3"].size)
+
+    def _deconv_backward(self, name, x, dy, dx, cin, hh, ww, cout, ho, wo):
+        """Deconvolution k4 s2 + Crop(1,1) given dy = gradient of the cropped, pre-activation output (B,cout,ho,wo),
+        contiguous: bias / weight gradients into self.grad, data gradient (B,cin,hh,ww) into dx. The MXNet weight
+        (cin,cout,4,4) already is the Convolution layout of the adjoint (filters = cin, channels = cout), so the data gradient
+        is a stride-2 convolution of the un-cropped dy and the weight gradient a conv wgrad with input and output swapped."""
+        h, B = self.ctx.handle, self.B
+        hf, wf = 2 * hh + 2, 2 * ww + 2
+        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dy, B, cout, ho * wo)
+        lib.deepim_scatter2d(h, self.ws["dil"], dy, B * cout, ho, wo, hf, wf, 1, 1, 1)
+        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
+        lib.deepim_conv_pack_weights(h, self.ws["wt_packed"], self.params[name + "_weight"], cin, cout, 4, 4)
+        lib.deepim_conv2d_forward(h, dx, self.ws["dil"], self.ws["wt_packed"], None, B, cout, hf, wf, cin, 4, 4, 2, 0,
                                   ctypes.c_float(1.0), 0, 0)
 
+    def _decoder_backward(self):
+        """Backward of the flow / mask heads and the refinement decoder (deepIM_flownet.py:120-167): leaves the skip
+        gradients in d_skip4 / d_skip5 and the conv6_1 gradient in d_dec61."""
+        A, P, W_, h, B, H, W = self.act, self.params, self.ws, self.ctx.handle, self.B, self.H, self.W
+        c = ctypes.c_float
+        ext = lib.deepim_extract_channels
+        if self.with_flow_head:   # upsampling (fixed bilinear, lr_mult 0) → Convolution3
+            lib.deepim_upsample16_crop_backward(h, W_["d_low"], W_["d_flow_hi"], P["upsampling_weight"], B, 2, 30, 40, H, W, 8, 8,
+                                                c(1.0))
+            self._head_conv_backward("Convolution3", W_["d_low"], 2, first=True)
+        if self.with_mask_head:   # mask_upsampling → mask_conv3
+            lib.deepim_upsample16_crop_backward(h, W_["d_low"], W_["d_mask_hi"], P["mask_upsampling_weight"], B, 1, 30, 40, H, W,
+                                                8, 8, c(1.0))
+            self._head_conv_backward("mask_conv3", W_["d_low"], 1, first=not self.with_flow_head)
+        # Concat3 = [conv4_1 | lrelu(deconv4) | upsample_flow5to4]
+        ext(h, W_["d_skip4"], W_["d_Concat3"], 770, 0, 512, B, 1200)
+        ext(h, W_["sl_dy"], W_["d_Concat3"], 770, 512, 256, B, 1200)
+        ext(h, W_["sl_y"], A["Concat3"], 770, 512, 256, B, 1200)
+        lib.deepim_lrelu_backward(h, W_["sl_dy"], W_["sl_dy"], W_["sl_y"], c(SLOPE), B * 256 * 1200)
+        self._deconv_backward("deconv4", A["Concat2"], W_["sl_dy"], W_["d_Concat2"], 1026, 15, 20, 256, 30, 40)
+        ext(h, W_["sl_dy"], W_["d_Concat3"], 770, 768, 2, B, 1200)
+        self._deconv_backward("upsample_flow5to4", A["flow5"], W_["sl_dy"], W_["d_flow5"], 2, 15, 20, 2, 30, 40)
+        self._small_conv_backward("Convolution2", A["Concat2"], W_["d_flow5"], W_["ga"], 1026, 15, 20, 2)
+        lib.deepim_axpy(h, W_["d_Concat2"], W_["ga"], c(1.0), W_["d_Concat2"].size)
+        # Concat2 = [conv5_1 | lrelu(deconv5) | upsample_flow6to5]
+        ext(h, W_["d_skip5"], W_["d_Concat2"], 1026, 0, 512, B, 300)
+        ext(h, W_["sl_dy"], W_["d_Concat2"], 1026, 512, 512, B, 300)
+        ext(h, W_["sl_y"], A["Concat2"], 1026, 512, 512, B, 300)
+        lib.deepim_lrelu_backward(h, W_["sl_dy"], W_["sl_dy"], W_["sl_y"], c(SLOPE), B * 512 * 300)
+        self._deconv_backward("deconv5", A["conv6_1"], W_["sl_dy"], W_["d_dec61"], 1024, 8, 10, 512, 15, 20)
+        ext(h, W_["sl_dy"], W_["d_Concat2"], 1026, 1024, 2, B, 300)
+        self._deconv_backward("upsample_flow6to5", A["flow6"], W_["sl_dy"], W_["d_flow6"], 2, 8, 10, 2, 15, 20)
+        self._small_conv_backward("Convolution1", A["conv6_1"], W_["d_flow6"], W_["ga"], 1024, 8, 10, 2)
+        lib.deepim_axpy(h, W_["d_dec61"], W_["ga"], c(1.0), W_["d_dec61"].size)
+
     def backward(self):
-        """module.backward (deepim/core/module.py:1131-1137) for the pose branch: fills self.grad for every parameter."""
+        """module.backward (deepim/core/module.py:1131-1137): fills self.grad for every parameter."""
         A, P, G, W_, h, B = self.act, self.params, self.grad, self.ws, self.ctx.handle, self.B
         c = ctypes.c_float
         data, label = self._train_io
+        if self.with_decoder:
+            self._decoder_backward()
         lib.deepim_transform3d_backward(h, W_["d_rot_norm"], W_["d_trans_est"], W_["d_points"], label["point_cloud_model"],
                                         A["rot_norm"], A["trans_est"], data["src_pose"], self.T_means, self.T_stds,
                                         self.rot_coord, B, self.num_points)
@@ -520,10 +636,15 @@ def _train_methods():
         ga, gb = W_["ga"], W_["gb"]
         lib.deepim_fc_backward(h, ga, G["fc6_weight"], G["fc6_bias"], W_["g256b"], A["conv6_1"].reshape((B, n6)),
                                P["fc6_weight"], B, n6, 256)
+        if self.with_decoder:
+            lib.deepim_axpy(h, ga, W_["d_dec61"], c(1.0), B * n6)
+        skips = {"conv5_1": "d_skip5", "conv4_1": "d_skip4"} if self.with_decoder else {}
         # encoder, last layer first: dz in place over dy, dx into the other buffer
         for li in range(len(self.enc_geom) - 1, -1, -1):
             name = self.enc_geom[li][0]
             n_el = A[name].size
+            if name in skips:
+                lib.deepim_axpy(h, ga, W_[skips[name]], c(1.0), n_el)
             lib.deepim_lrelu_backward(h, ga, ga, A[name], c(SLOPE), n_el)
             self._conv_backward(li, ga, gb if li > 0 else None)
             ga, gb = gb, ga
@@ -531,18 +652,30 @@ def _train_methods():
 
     def update(self, lr, wd=0.0005, momentum=0.975, rescale_grad=1.0, clip_gradient=None):
         """The "sgd" optimizer step of train.py:296-303 (MXNet sgd_mom_update) on every parameter, then the re-pack of the
-        conv / fc6 weights the forward kernels read."""
+        conv / deconv / fc6 weights the forward kernels read. As mx.optimizer does when Module hands it the parameter
+        names: weight decay only on `*_weight` (wd_mult 0 elsewhere), and the bilinear upsampling kernels stay fixed
+        (attr lr_mult 0, deepIM_flownet.py:193,333,643,695)."""
         h = self.ctx.handle
         c = ctypes.c_float
         for name, w in self.params.items():
-            lib.deepim_sgd_mom_update(h, w, self.mom[name], self.grad[name], c(lr), c(wd), c(momentum), c(rescale_grad),
+            if name.endswith("upsampling_weight"):
+                continue
+            wd_n = wd if name.endswith("_weight") else 0.0
+            lib.deepim_sgd_mom_update(h, w, self.mom[name], self.grad[name], c(lr), c(wd_n), c(momentum), c(rescale_grad),
                                       c(clip_gradient or 0.0), w.size)
-        for name, cin, hh, ww, cout, k, s_, p_ in self.enc_geom:
-            lib.deepim_conv_pack_weights(h, self.packed[name], self.params[name + "_weight"], cout, cin, k, k)
+        for name, shape in self.arg_shape_dict().items():
+            if not name.endswith("_weight") or len(shape) != 4 or name.endswith("upsampling_weight"):
+                continue
+            base = name[: -len("_weight")]
+            if base.startswith("deconv") or base.startswith("upsample_flow"):
+                lib.deepim_deconv_pack_weights(h, self.packed[base], self.params[name], shape[0], shape[1])
+            else:
+                lib.deepim_conv_pack_weights(h, self.packed[base], self.params[name], shape[0], shape[1], shape[2], shape[3])
         lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
 
-    return dict(bind_train=bind_train, forward_train=forward_train, _conv_backward=_conv_backward, backward=backward,
-                update=update)
+    return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad, _conv_backward=_conv_backward,
+                _small_conv_backward=_small_conv_backward, _head_conv_backward=_head_conv_backward,
+                _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update)
 
 
 for _name, _fn in _train_methods().items():

@@ -244,3 +244,89 @@ void oracle_fc_backward(float* dx, float* dw, float* db, const float* dy, const 
     }
   }
 }
+
+/* Deconvolution k4 s2 p0 + Crop(crop_y,crop_x → Ho,Wo) backward: dy is the gradient of the CROPPED output (B,Cout,Ho,Wo);
+ * w (Cin,Cout,4,4).  d_in[n,ci,iy,ix] = Σ_{co,ky,kx} dy[n,co,2iy+ky−crop_y,2ix+kx−crop_x]·w[ci,co,ky,kx];
+ * dw[ci,co,ky,kx] = Σ_{n,iy,ix} in[n,ci,iy,ix]·dy[n,co,2iy+ky−crop_y,2ix+kx−crop_x];  db[co] = Σ dy */
+void oracle_deconv4x4s2_crop_backward(float* d_in, float* dw, float* db, const float* in, const float* w, const float* dy, int B,
+                                      int Cin, int H, int W, int Cout, int Ho, int Wo, int crop_y, int crop_x) {
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int n = 0; n < B; ++n)
+    for (int ci = 0; ci < Cin; ++ci) {
+      float* o = d_in + ((size_t)n * Cin + ci) * H * W;
+      for (int iy = 0; iy < H; ++iy)
+        for (int ix = 0; ix < W; ++ix) {
+          double acc = 0.0;
+          for (int co = 0; co < Cout; ++co) {
+            const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+            const float* wp = w + ((size_t)ci * Cout + co) * 16;
+            for (int ky = 0; ky < 4; ++ky) {
+              const int y = 2 * iy + ky - crop_y;
+              if (y < 0 || y >= Ho) continue;
+              for (int kx = 0; kx < 4; ++kx) {
+                const int x = 2 * ix + kx - crop_x;
+                if (x < 0 || x >= Wo) continue;
+                acc += (double)g[(size_t)y * Wo + x] * (double)wp[ky * 4 + kx];
+              }
+            }
+          }
+          o[(size_t)iy * W + ix] = (float)acc;
+        }
+    }
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int co = 0; co < Cout; ++co)
+      for (int ky = 0; ky < 4; ++ky)
+        for (int kx = 0; kx < 4; ++kx) {
+          double acc = 0.0;
+          for (int n = 0; n < B; ++n) {
+            const float* ip = in + ((size_t)n * Cin + ci) * H * W;
+            const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+            for (int iy = 0; iy < H; ++iy) {
+              const int y = 2 * iy + ky - crop_y;
+              if (y < 0 || y >= Ho) continue;
+              for (int ix = 0; ix < W; ++ix) {
+                const int x = 2 * ix + kx - crop_x;
+                if (x < 0 || x >= Wo) continue;
+                acc += (double)ip[(size_t)iy * W + ix] * (double)g[(size_t)y * Wo + x];
+              }
+            }
+          }
+          dw[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] = (float)acc;
+        }
+  if (db) {
+#pragma omp parallel for
+    for (int co = 0; co < Cout; ++co) {
+      double acc = 0.0;
+      for (int n = 0; n < B; ++n) {
+        const float* g = dy + ((size_t)n * Cout + co) * Ho * Wo;
+        for (int i = 0; i < Ho * Wo; ++i) acc += g[i];
+      }
+      db[co] = (float)acc;
+    }
+  }
+}
+
+/* data gradient of the depthwise k32 s16 upsampling (fixed weights, lr_mult 0): d_in[bc,iy,ix] = scale·Σ dy[bc,16iy+ky−cy,16ix+kx−cx]·w[c,ky,kx] */
+void oracle_upsample16_crop_backward(float* d_in, const float* dy, const float* w, int B, int C, int H, int W, int Ho, int Wo,
+                                     int crop_y, int crop_x, float scale) {
+#pragma omp parallel for schedule(dynamic)
+  for (int bc = 0; bc < B * C; ++bc) {
+    const float* g = dy + (size_t)bc * Ho * Wo;
+    const float* wp = w + (size_t)(bc % C) * 1024;
+    for (int iy = 0; iy < H; ++iy)
+      for (int ix = 0; ix < W; ++ix) {
+        double acc = 0.0;
+        for (int ky = 0; ky < 32; ++ky) {
+          const int y = 16 * iy + ky - crop_y;
+          if (y < 0 || y >= Ho) continue;
+          for (int kx = 0; kx < 32; ++kx) {
+            const int x = 16 * ix + kx - crop_x;
+            if (x < 0 || x >= Wo) continue;
+            acc += (double)g[(size_t)y * Wo + x] * (double)wp[ky * 32 + kx];
+          }
+        }
+        d_in[((size_t)bc * H + iy) * W + ix] = (float)(acc * (double)scale);
+      }
+  }
+}

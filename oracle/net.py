@@ -124,3 +124,22 @@ def sgd_mom_update(w, mom, g, lr, wd, momentum, rescale=1.0, clip=None):
         gg = np.clip(gg, -f32(clip), f32(clip))
     mom2 = (f32(momentum) * mom - f32(lr) * (gg + f32(wd) * w).astype(f32)).astype(f32)
     return (w + mom2).astype(f32), mom2
+
+
+def deconv4x4s2_crop_backward(x, w, dy, crop=(1, 1)):
+    """Gradients of Deconvolution k4 s2 + Crop given the gradient of the CROPPED output: -> (dx, dw, db)."""
+    x, w, dy = _c(x), _c(w), _c(dy)
+    B, Cin, H, W = x.shape
+    Cout, Ho, Wo = w.shape[1], dy.shape[2], dy.shape[3]
+    dx, dw, db = np.empty_like(x), np.empty_like(w), np.empty((Cout,), f32)
+    _lib().oracle_deconv4x4s2_crop_backward(_p(dx), _p(dw), _p(db), _p(x), _p(w), _p(dy), B, Cin, H, W, Cout, Ho, Wo, crop[0],
+                                            crop[1])
+    return dx, dw, db
+
+
+def upsample16_crop_backward(dy, w, H, W, crop=(8, 8), scale=1.0):
+    dy, w = _c(dy), _c(w)
+    B, C, Ho, Wo = dy.shape
+    dx = np.empty((B, C, H, W), f32)
+    _lib().oracle_upsample16_crop_backward(_p(dx), _p(dy), _p(w), B, C, H, W, Ho, Wo, crop[0], crop[1], ctypes.c_float(scale))
+    return dx

@@ -106,16 +106,19 @@ def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coor
     return out
 
 
-def train_pose_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", lw_pm=0.1,
-                         num_3d_sample=3000, normalize_3d=0.1, loss_type="L1", sigma=1.0):
-    """Forward + backward of the pose branch of the training graph (deepIM_flownet.py:367-546, losses :209-312; backward =
-    module.backward, deepim/core/module.py:1131-1137): returns (loss_sum, grads dict keyed like params, forward dict)."""
+def train_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", lw_pm=0.1,
+                    num_3d_sample=3000, normalize_3d=0.1, loss_type="L1", sigma=1.0, pred_flow=False, pred_mask=False,
+                    lw_flow=0.25, lw_mask=0.03, normalize_flow=20.0):
+    """Forward + backward of the training graph (deepIM_flownet.py:367-546, losses :170-365; backward = module.backward,
+    deepim/core/module.py:1131-1137): the point-matching pose branch, plus — pred_flow / pred_mask — the FlowNetS refinement
+    decoder with the flow loss (:183-207) and the mask loss (:314-361). Returns (loss_sum, grads keyed like params, forward
+    dict); loss_sum is the point-matching sum (the metric train.py logs)."""
     from . import heads
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"),
                            mask_gt_observed=label["mask_gt_observed"])
     acts = encoder(params, x)
-    B = x.shape[0]
+    B, _, H, W = x.shape
     feat = acts["conv6_1"].reshape(B, -1)
     fc6 = net.fc(feat, params["fc6_weight"], params["fc6_bias"], SLOPE)
     fc7 = net.fc(fc6, params["fc7_weight"], params["fc7_bias"], SLOPE)
@@ -128,12 +131,59 @@ def train_pose_iteration(params, data, label, K, pixel_means_rev, T_means, T_std
                                                       normalize_3d, loss_type, sigma, lw_pm / num_3d_sample)
     fwd = dict(acts, net_input=x, zoom_factor=zf, fc6=fc6, fc7=fc7, rot=rot, zoom_trans=ztr, rot_norm=rot_norm,
                trans_est=trans_est, points_est=pts, pm_loss=loss)
-    # ---- backward
+    g = {}
+    d_skip = {}
+    d_dec61 = None
+    if pred_flow or pred_mask:
+        P = params
+        dec = decoder(P, acts)
+        fwd.update(dec)
+        C3, C2 = dec["Concat3"], dec["Concat2"]
+        dC3 = np.zeros_like(C3)
+        if pred_flow:
+            low = net.conv2d(C3, P["Convolution3_weight"], P["Convolution3_bias"], 1, 1, 1.0)
+            est = net.upsample16_crop(low, P["upsampling_weight"], H, W, (8, 8), 1.0)                      # flow_est_crop
+            zflow, zfw = zoom.zoom_flow(zf, label["flow"], label["flow_weights"], b_inv_zoom=False)
+            fl, fl_sum, d_est = heads.flow_loss(est, zflow, zfw, normalize_flow, lw_flow / (480 * 640))
+            d_low = net.upsample16_crop_backward(d_est, P["upsampling_weight"], 30, 40, (8, 8), 1.0)
+            dx, g["Convolution3_weight"], g["Convolution3_bias"] = net.conv2d_backward(C3, P["Convolution3_weight"], d_low, 1, 1)
+            dC3 += dx
+            g["upsampling_weight"] = np.zeros_like(P["upsampling_weight"])                                  # lr_mult 0
+            fwd.update(flow_lowres=low, flow_est_crop=est, zoom_flow_gt=zflow, zoom_flow_weights=zfw, flow_loss=fl,
+                       flow_loss_sum=fl_sum)
+        if pred_mask:
+            low = net.conv2d(C3, P["mask_conv3_weight"], P["mask_conv3_bias"], 1, 1, 1.0)
+            logits = net.upsample16_crop(low, P["mask_upsampling_weight"], H, W, (8, 8), 1.0)
+            zgt = zoom.zoom_mask(data["mask_observed"], label["mask_gt_observed"], data["mask_rendered"], data["src_pose"], K)[1]
+            # LogisticRegressionOutput backward: grad_scale / num_output * (p - y), num_output = H*W per sample
+            prob, d_logits = heads.mask_logistic(logits, zgt, lw_mask / (H * W))
+            d_low = net.upsample16_crop_backward(d_logits, P["mask_upsampling_weight"], 30, 40, (8, 8), 1.0)
+            dx, g["mask_conv3_weight"], g["mask_conv3_bias"] = net.conv2d_backward(C3, P["mask_conv3_weight"], d_low, 1, 1)
+            dC3 += dx
+            g["mask_upsampling_weight"] = np.zeros_like(P["mask_upsampling_weight"])
+            fwd.update(mask_lowres=low, mask_logits=logits, mask_prob=prob, zoom_mask_gt_observed=zgt)
+        # Concat3 = [conv4_1 | lrelu(deconv4) | upsample_flow5to4]
+        d_skip["conv4_1"] = np.ascontiguousarray(dC3[:, :512])
+        d_d4 = net.lrelu_backward(dC3[:, 512:768], C3[:, 512:768], SLOPE)
+        dC2, g["deconv4_weight"], g["deconv4_bias"] = net.deconv4x4s2_crop_backward(C2, P["deconv4_weight"], d_d4)
+        d_f5, g["upsample_flow5to4_weight"], g["upsample_flow5to4_bias"] = net.deconv4x4s2_crop_backward(
+            dec["flow5"], P["upsample_flow5to4_weight"], dC3[:, 768:770])
+        dx, g["Convolution2_weight"], g["Convolution2_bias"] = net.conv2d_backward(C2, P["Convolution2_weight"], d_f5, 1, 1)
+        dC2 = (dC2 + dx).astype(f32)
+        # Concat2 = [conv5_1 | lrelu(deconv5) | upsample_flow6to5]
+        d_skip["conv5_1"] = np.ascontiguousarray(dC2[:, :512])
+        d_d5 = net.lrelu_backward(dC2[:, 512:1024], C2[:, 512:1024], SLOPE)
+        d_dec61, g["deconv5_weight"], g["deconv5_bias"] = net.deconv4x4s2_crop_backward(acts["conv6_1"], P["deconv5_weight"], d_d5)
+        d_f6, g["upsample_flow6to5_weight"], g["upsample_flow6to5_bias"] = net.deconv4x4s2_crop_backward(
+            dec["flow6"], P["upsample_flow6to5_weight"], dC2[:, 1024:1026])
+        dx, g["Convolution1_weight"], g["Convolution1_bias"] = net.conv2d_backward(acts["conv6_1"], P["Convolution1_weight"], d_f6, 1, 1)
+        d_dec61 = (d_dec61 + dx).astype(f32)
+        fwd.update(d_Concat3=dC3, d_Concat2=dC2)
+    # ---- pose branch
     d_rot_norm, d_trans_est = se3.transform3d_backward(d_pts, label["point_cloud_model"], rot_norm, trans_est, data["src_pose"],
                                                         T_means, T_stds, rot_coord)
     d_rot = heads.l2_normalize_backward(d_rot_norm, rot)
     d_ztr = zoom.zoom_trans_backward(zf, d_trans_est, b_inv_zoom=True, b_zoom_grad=False)
-    g = {}
     dx_r, g["rot_weight"], g["rot_bias"] = net.fc_backward(fc7, params["rot_weight"], d_rot)
     dx_t, g["trans_weight"], g["trans_bias"] = net.fc_backward(fc7, params["trans_weight"], d_ztr)
     d = net.lrelu_backward((dx_r + dx_t).astype(f32), fc7, SLOPE)
@@ -141,9 +191,18 @@ def train_pose_iteration(params, data, label, K, pixel_means_rev, T_means, T_std
     d = net.lrelu_backward(d, fc6, SLOPE)
     d, g["fc6_weight"], g["fc6_bias"] = net.fc_backward(feat, params["fc6_weight"], d)
     d = d.reshape(acts["conv6_1"].shape)
+    if d_dec61 is not None:
+        d = (d + d_dec61).astype(f32)
     for li in range(len(ENCODER) - 1, -1, -1):
         name, s, p = ENCODER[li]
+        if name in d_skip:
+            d = (d + d_skip[name]).astype(f32)
         src = x if li == 0 else acts[ENCODER[li - 1][0]]
         dz = net.lrelu_backward(d, acts[name], SLOPE)
         d, g[name + "_weight"], g[name + "_bias"] = net.conv2d_backward(src, params[name + "_weight"], dz, s, p, need_dx=li > 0)
     return loss_sum, g, fwd
+
+
+def train_pose_iteration(*args, **kw):
+    """The pose branch alone (PRED_FLOW = PRED_MASK = False)."""
+    return train_iteration(*args, **kw)

@@ -91,13 +91,10 @@ def test_fc_backward_and_sgd(ctx, shape):
         np.testing.assert_allclose(md_.asnumpy(), m_ref, rtol=1e-5, atol=1e-10)
 
 
-def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
-    """One training-style iteration (B = 1, 480x640): zoom from the gt mask → encoder → fc → rot/trans → Transform3D →
-    point-matching loss, backward through everything, SGD step (module.py:1131-1137 order)."""
-    B = 1
-    d = synthetic.make_batch(B, seed=910, n_frames=1)
+def _train_setup(ctx, B, seed, pred_heads):
+    d = synthetic.make_batch(B, seed=seed, n_frames=1)
     cfg = default_config()
-    cfg.network.PRED_FLOW = cfg.network.PRED_MASK = False
+    cfg.network.PRED_FLOW = cfg.network.PRED_MASK = pred_heads
     net = deepIM_flownet().get_symbol(cfg, is_train=True)
     params = net.init_weights(cfg, seed=91)
     net.bind_train(ctx, B, params, num_points=3000)
@@ -109,6 +106,21 @@ def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
                "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0]}
     label_np = {"mask_gt_observed": gt, "point_cloud_model": d["point_cloud_model"], "point_cloud_weights": wts,
                 "point_cloud_observed": pco}
+    if pred_heads:   # flow labels the way the data layer makes them (lib/pair_matching/data_pair.py:get_pair_flow, on the device)
+        from mx_deepim_amd.lib.pair_matching import data_pair
+        flow, fw = data_pair.get_pair_flow({"depth_rendered": ctx.array(d["depth_rendered"][0]),
+                                            "depth_gt_observed": ctx.array(d["depth_gt_observed"]),
+                                            "pose_rendered": ctx.array(d["src_pose"][0]), "pose_observed": ctx.array(d["pose_tgt"])}, cfg)
+        label_np["flow"], label_np["flow_weights"] = flow.asnumpy(), fw.asnumpy()
+        assert np.count_nonzero(label_np["flow_weights"]) > 1000
+    return d, cfg, net, params, data_np, label_np
+
+
+def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
+    """One training-style iteration (B = 1, 480x640): zoom from the gt mask → encoder → fc → rot/trans → Transform3D →
+    point-matching loss, backward through everything, SGD step (module.py:1131-1137 order)."""
+    B = 1
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 910, False)
     data = {k: ctx.array(v) for k, v in data_np.items()}
     label = {k: ctx.array(v) for k, v in label_np.items()}
     # LeakyReLU makes the gradient discontinuous where an activation crosses zero: run the forward convs as single canonical
@@ -141,7 +153,132 @@ def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
     assert np.isfinite(loss2) and loss2 != loss
 
 
-def test_train_symbol_refuses_the_heads_it_cannot_backpropagate():
-    cfg = default_config()
-    with pytest.raises(NotImplementedError):
-        deepIM_flownet().get_symbol(cfg, is_train=True)
+DEC_CASES = [(2, 70, 6, 8, 24, 13, 17), (1, 2, 8, 10, 2, 15, 20), (1, 1026, 15, 20, 256, 30, 40)]
+
+
+@pytest.mark.parametrize("case", DEC_CASES)
+def test_deconv_crop_backward_matches_oracle(ctx, case):
+    """Deconvolution k4 s2 + Crop(1,1) backward as composed in deepIM_flownet._deconv_backward: un-crop (scatter2d), conv wgrad
+    with input and output swapped, stride-2 forward conv for the data gradient."""
+    B, cin, H, W, cout, ho, wo = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    dy = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    dx_ref, dw_ref, db_ref = onet.deconv4x4s2_crop_backward(x, w, dy, (1, 1))
+    h = ctx.handle
+    hf, wf = 2 * H + 2, 2 * W + 2
+    full = ctx.empty((B, cout, hf, wf))
+    lib.deepim_scatter2d(h, full, ctx.array(dy), B * cout, ho, wo, hf, wf, 1, 1, 1)
+    f = full.asnumpy()
+    np.testing.assert_array_equal(f[:, :, 1:1 + ho, 1:1 + wo], dy)
+    assert np.count_nonzero(f) == np.count_nonzero(dy)
+    db, dw, dx = ctx.empty((cout,)), ctx.empty(w.shape), ctx.empty(x.shape)
+    lib.deepim_bias_grad(h, db, ctx.array(dy), B, cout, ho * wo)
+    lib.deepim_conv2d_wgrad(h, dw, full, ctx.array(x), B, cout, hf, wf, cin, 4, 4, 2, 0)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cin, cout, 4, 4) // 4,))
+    lib.deepim_conv_pack_weights(h, pk, ctx.array(w), cin, cout, 4, 4)
+    lib.deepim_conv2d_forward(h, dx, full, pk, None, B, cout, hf, wf, cin, 4, 4, 2, 0, cf(1.0), 0, 0)
+    close(db.asnumpy(), db_ref); close(dw.asnumpy(), dw_ref); close(dx.asnumpy(), dx_ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 30, 40, 480, 640), (1, 1, 30, 40, 480, 640), (3, 2, 5, 7, 70, 100)])
+def test_upsample16_backward_and_extract_channels(ctx, shape):
+    B, C, H, W, Ho, Wo = shape
+    rng = np.random.default_rng(Ho + C)
+    w = np.stack([deepIM_flownet._init_bilinear((1, 1, 32, 32))[0] for _ in range(C)]).astype(np.float32)
+    w = (w * rng.uniform(0.5, 1.5, w.shape)).astype(np.float32)           # not separable: every tap distinct
+    dy = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    ref = onet.upsample16_crop_backward(dy, w, H, W, (8, 8), 1.5)
+    out = ctx.empty((B, C, H, W))
+    lib.deepim_upsample16_crop_backward(ctx.handle, out, ctx.array(dy), ctx.array(w), B, C, H, W, Ho, Wo, 8, 8, cf(1.5))
+    close(out.asnumpy(), ref, 1e-5)
+    src = rng.standard_normal((B, 11, H * W)).astype(np.float32)
+    dst = ctx.empty((B, 4, H * W))
+    lib.deepim_extract_channels(ctx.handle, dst, ctx.array(src), 11, 5, 4, B, H * W)
+    np.testing.assert_array_equal(dst.asnumpy(), src[:, 5:9])
+
+
+def test_training_iteration_with_flow_and_mask_heads_matches_oracle(ctx):
+    """The full training graph (network.PRED_FLOW = PRED_MASK = True, the reference's default flow-net configuration): pose
+    branch + refinement decoder + flow loss + mask loss, backward through all of it (skip connections into conv4_1 / conv5_1 /
+    conv6_1 included), SGD step with the bilinear upsampling kernels held fixed."""
+    B = 1
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 915, True)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    try:
+        loss = net.forward_train(data, label).asnumpy()[0]
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    grads = net.backward()
+    t = cfg.train_iter
+    ref_loss, g_ref, fwd = opipe.train_iteration(params, data_np, label_np, d["K"], MEANS_REV, cfg.dataset.trans_means,
+                                                 cfg.dataset.trans_stds, cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE,
+                                                 cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR,
+                                                 pred_flow=True, pred_mask=True, lw_flow=t.LW_FLOW, lw_mask=t.LW_MASK,
+                                                 normalize_flow=cfg.dataset.NORMALIZE_FLOW)
+    A = net.act
+    np.testing.assert_array_equal(A["conv6_1"].asnumpy(), fwd["conv6_1"])
+    np.testing.assert_array_equal(A["Concat3"].asnumpy(), fwd["Concat3"])
+    np.testing.assert_array_equal(A["zoom_flow_gt"].asnumpy(), fwd["zoom_flow_gt"])
+    np.testing.assert_array_equal(A["zoom_flow_weights"].asnumpy(), fwd["zoom_flow_weights"])
+    np.testing.assert_array_equal(A["zoom_mask_gt_observed"].asnumpy(), fwd["zoom_mask_gt_observed"])
+    close(A["zoom_flow_est"].asnumpy(), fwd["flow_est_crop"], 1e-5)
+    close(A["flow_loss"].asnumpy(), fwd["flow_loss"], 1e-5)
+    close(A["mask_prob"].asnumpy(), fwd["mask_prob"], 1e-5)
+    assert abs(A["flow_loss_sum"].asnumpy()[0] - fwd["flow_loss_sum"]) <= 1e-4 * abs(fwd["flow_loss_sum"])
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    close(net.ws["d_Concat3"].asnumpy(), fwd["d_Concat3"], 2e-4)
+    close(net.ws["d_Concat2"].asnumpy(), fwd["d_Concat2"], 2e-4)
+    assert set(grads) == set(g_ref)
+    for name in sorted(g_ref):
+        if name.endswith("upsampling_weight"):
+            assert not grads[name].asnumpy().any()
+            continue
+        assert np.abs(g_ref[name]).max() > 0, name
+        close(grads[name].asnumpy(), g_ref[name], 2e-4)
+    # the heads really reach the encoder: its gradients differ from the pose-branch-only ones
+    _, g_pose, _ = opipe.train_pose_iteration(params, data_np, label_np, d["K"], MEANS_REV, cfg.dataset.trans_means,
+                                              cfg.dataset.trans_stds, cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE,
+                                              cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR)
+    assert np.abs(g_pose["conv4_1_weight"] - g_ref["conv4_1_weight"]).max() > 1e-3 * np.abs(g_ref["conv4_1_weight"]).max()
+    # SGD: weights move by the oracle's step, biases carry no weight decay, the bilinear kernels stay put, the decoder's packed
+    # weights are refreshed (the forward changes)
+    names = ("deconv4_weight", "Convolution3_weight", "deconv5_bias", "upsampling_weight", "mask_upsampling_weight")
+    before = {k: net.params[k].asnumpy() for k in names}
+    c3 = A["Concat3"].asnumpy()
+    net.update(lr=1e-2, wd=cfg.TRAIN.wd, momentum=cfg.TRAIN.momentum)
+    for k, v in before.items():
+        if k.endswith("upsampling_weight"):
+            np.testing.assert_array_equal(net.params[k].asnumpy(), v)
+            continue
+        w_ref, _ = onet.sgd_mom_update(v, np.zeros_like(v), g_ref[k], 1e-2, cfg.TRAIN.wd if k.endswith("_weight") else 0.0,
+                                       cfg.TRAIN.momentum)
+        np.testing.assert_allclose(net.params[k].asnumpy(), w_ref, rtol=1e-4, atol=1e-7)
+    loss2 = net.forward_train(data, label).asnumpy()[0]
+    assert np.isfinite(loss2) and loss2 != loss
+    assert not np.array_equal(A["Concat3"].asnumpy(), c3)
+
+
+def test_training_with_heads_reduces_all_three_losses(ctx):
+    """A few SGD steps on one fixed batch (B = 2): the point-matching, flow and mask losses all go down."""
+    B = 2
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 77, True)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+
+    def losses():
+        pm = net.forward_train(data, label).asnumpy()[0]
+        p, y = net.act["mask_prob"].asnumpy().astype(np.float64), net.act["zoom_mask_gt_observed"].asnumpy()
+        bce = float(-(y * np.log(p + 1e-12) + (1 - y) * np.log(1 - p + 1e-12)).mean())
+        return float(pm), float(net.act["flow_loss_sum"].asnumpy()[0]), bce
+
+    first = losses()
+    for _ in range(6):
+        net.backward()
+        net.update(lr=2e-3, wd=cfg.TRAIN.wd, momentum=0.5)
+        last = losses()
+    assert all(np.isfinite(last))
+    assert last[0] < first[0] and last[1] < first[1] and last[2] < first[2], (first, last)

@@ -118,3 +118,26 @@ def test_oracle_backward_matches_torch_autograd():
         pt.grad = torch.tensor(g)
         opt.step()
     np.testing.assert_allclose(w2, pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_decoder_backward_matches_torch_autograd():
+    """oracle/net.c Deconvolution(k4 s2)+Crop and the depthwise k32 s16 upsampling + Crop backward against torch autograd."""
+    rng = np.random.default_rng(12)
+    for B, cin, H, W, cout, ho, wo in [(2, 5, 6, 7, 3, 13, 15), (1, 2, 8, 10, 2, 15, 20)]:
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = rng.standard_normal((cin, cout, 4, 4)).astype(np.float32)
+        dy = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+        xt, wt, bt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True), torch.zeros(cout, requires_grad=True)
+        y = F.conv_transpose2d(xt, wt, bt, stride=2)[:, :, 1:1 + ho, 1:1 + wo]
+        y.backward(torch.tensor(dy))
+        dx, dw, db = onet.deconv4x4s2_crop_backward(x, w, dy, (1, 1))
+        np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(dw, wt.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-4, atol=1e-4)
+    B, C, H, W, Ho, Wo = 2, 2, 5, 6, 70, 90
+    wu = rng.standard_normal((C, 1, 32, 32)).astype(np.float32)
+    dy = rng.standard_normal((B, C, Ho, Wo)).astype(np.float32)
+    xt = torch.zeros((B, C, H, W), requires_grad=True)
+    y = 1.5 * F.conv_transpose2d(xt, torch.tensor(wu), stride=16, groups=C)[:, :, 8:8 + Ho, 8:8 + Wo]
+    y.backward(torch.tensor(dy))
+    np.testing.assert_allclose(onet.upsample16_crop_backward(dy, wu, H, W, (8, 8), 1.5), xt.grad.numpy(), rtol=1e-4, atol=1e-4)
