@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5 mode: conv stack on the fp16 matrix cores "
                     "(NOT the headline: reduced precision; reported with dtype f16)")
+    ap.add_argument("--x3", action="store_true", help="split-fp16 conv mode: conv2 … conv6_1 as hi·hi + hi·lo + lo·hi on the "
+                    "fp16 matrix cores with fp32 accumulation — fp32-grade results (≈1e-6 of the fp32 path, inside north_star's "
+                    "1e-4), not bit-exact; reported with dtype f16x3 next to the bit-exact fp32 headline")
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
     ap.add_argument("--heads", action="store_true", help="BASELINE config 4 mode: full test graph (FAST_TEST off) with the "
                     "FlowNetS decoder and the mask / flow heads in every iteration (NOT the headline)")
@@ -154,6 +157,7 @@ def main():
         B = Bmax = args.batch
     cfg = default_config()
     cfg.network.FP16_CONV = bool(args.fp16)
+    cfg.network.X3_CONV = bool(args.x3)
     if args.heads:
         cfg.TEST.FAST_TEST = False
     net = deepIM_flownet().get_symbol(cfg)
@@ -268,10 +272,12 @@ def main():
         flops = encoder_flops_per_pair(net.cin) * B
         achieved = flops / (enc_ms * 1e-3) / 1e12
         peak = 2500.0 if args.fp16 else FP32_PEAK_TFLOPS   # dense fp16 MFMA peak, MI355X_MICROARCH.md
+        if args.x3:   # three fp16 MFMA products per algorithmic multiply-add on conv2 … conv6_1: peak in algorithmic FLOPs
+            peak = 2500.0 / 3.0
         zoom_bytes = 2 * (net.cin * 480 * 640 * 4) * B   # read + write every zoomed channel once
         traffic, traffic_src = None, None                # HBM bytes per conv launch group from a recorded PMC pass
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not args.fp16:
+        if os.path.exists(tpath) and not args.fp16 and not args.x3:
             tj = json.load(open(tpath)).get("B%d" % B)
             if tj:
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
@@ -282,14 +288,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
-            "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
+            "dtype": "f16" if args.fp16 else ("f16x3" if args.x3 else "f32"), "data": "synthetic",
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, %s, %d refinement iters, 480x640, "
                                    "%s (8-ch input), %s" % ("global batch %d sharded %d per GPU" % (args.global_batch, Bmax) if args.global_batch else "batch %d per GPU" % B, NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph", "pre-staged rendered frames (render excluded)"
                                    if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT,
                        "parallelism": "pairs sharded across %d GPU(s), one process per GPU, one ncclAllGather (RCCL) of the "
                                       "refined poses per iteration on the compute stream, no torch" % world},
-            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_nc8_kernel / conv_direct_kernel") +
+            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_f16_dma_kernel<X3> (conv2-conv6_1: 3 fp16 "
+                                                      "MFMAs per product; peak = 2.5 PF / 3) + conv_direct_kernel (conv1, fp32)"
+                                                      if args.x3 else "conv_nc8_kernel / conv_direct_kernel") +
                          " (10 encoder launches per iteration incl. split-K reduces)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
@@ -312,7 +320,7 @@ def main():
                     out["cpu_baseline"]["secondary_onednn"] = cpu_onednn_secondary(cfg)
                 except ImportError as e:       # torch is test/bench tooling only; the figure is optional
                     out["cpu_baseline"]["secondary_onednn"] = {"skipped": str(e)}
-        default_run = (world == 1 and not (args.fp16 or args.heads or args.prestaged or args.global_batch or args.layers)
+        default_run = (world == 1 and not (args.fp16 or args.x3 or args.heads or args.prestaged or args.global_batch or args.layers)
                        and args.batch == 32 and not args.no_other_configs and not args.no_cpu_baseline)
         if default_run:
             out["other_configs"] = other_configs()
@@ -330,7 +338,7 @@ def other_configs():
     import subprocess
     runs = {"configs[1]_ape_batch16": ["--batch", "16"], "configs[2]_per_gpu_share_batch4": ["--batch", "4"],
             "configs[3]_decoder_mask_flow_heads_batch32": ["--heads"], "configs[4]_fp16_conv_per_gpu_share_batch8": ["--fp16", "--batch", "8"],
-            "fp16_conv_batch32": ["--fp16"]}
+            "fp16_conv_batch32": ["--fp16"], "split_fp16_x3_conv_batch32": ["--x3"], "split_fp16_x3_conv_batch4": ["--x3", "--batch", "4"]}
     res = {}
     for name, extra in runs.items():
         try:

@@ -251,6 +251,20 @@ int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const float* w /
 int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* in_nhwc_f16, const void* packed_w,
                               const float* bias, int B, int Cin_pad, int H, int W, int Cout, int kh, int kw,
                               int stride, int pad, float slope);
+/* Split-fp16 ("x3") convolution: the same Convolution + bias + LeakyReLU (deepIM_flownet.py:63-107) at fp32-grade accuracy on
+ * the fp16 matrix cores. A value v travels as the fp16 pair hi = f16(v·s), lo = f16(v·s − hi) (22 significand bits, s a power
+ * of two), a product is hi·hi + hi·lo + lo·hi (v_mfma_f32_32x32x16_f16, fp32 accumulation; the dropped lo·lo term is 2^-22
+ * relative). Tensors are "split16" NHWC: per pixel, per 16 channels, 32 halves [hi 0..15 | lo 0..15].
+ * acc_scale = 1 / (s_in · s_w) returns the accumulator to real units before bias; out_scale = s of the stored output.
+ * Needs Cin % 32 == 0, Cout % 128 == 0 (conv2 … conv6_1 of the encoder; conv1 runs in fp32 and is converted). */
+int deepim_nchw_f32_to_split16(deepim_ctx* ctx, void* out_split16, const float* in, int B, int C, int H, int W, float scale);
+int deepim_split16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_split16, int B, int C, int H, int W, float inv_scale);
+size_t deepim_conv_x3_packed_size(int Cout, int Cin, int kh, int kw);
+int deepim_conv_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*Cout,Cin,kh,kw dev f32*/, int Cout, int Cin,
+                                int kh, int kw, float w_scale);
+int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
+                             int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
+                             float acc_scale, float out_scale);
 /* MXNet Deconvolution k4 s2 p0 (+bias) + Crop(offset 1,1 → Ho,Wo) [+LeakyReLU]
  * (deepIM_flownet.py:127-143,149-165). w layout (Cin,Cout,4,4). */
 size_t deepim_deconv_packed_size(int Cin, int Cout);

@@ -41,6 +41,7 @@ def default_config():
         ROT_COORD="CAMERA",
         REGRESSOR_NUM=1,
         STANDARD_FLOW_REP=False,
+        X3_CONV=False,     # split-fp16 conv path: fp32-grade accuracy (≈1e-6) on the fp16 matrix cores (not a reference key)
         FP16_CONV=False,   # BASELINE config 5: fp16 conv path (not a reference key; the reference is fp32 only)
     )
     cfg.train_iter = AttrDict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L1", LW_PM=0.1, LW_FLOW=0.25, LW_MASK=0.03,

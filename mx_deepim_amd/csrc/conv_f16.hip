@@ -54,7 +54,21 @@ struct ConvF16Params {
   int ksplit, chunks_per_split;  // split-K across grid slices for under-filled grids
   float* partial;                // [ksplit][npix][Cout] fp32 partial sums when ksplit > 1
   int stride_kw;                 // (kh << 16) | kw, for the DMA kernel's scalar tap counters
+  float acc_scale, out_scale;    // X3 mode: accumulator → real units (2^-(s_act+s_w)), real units → stored activations (2^s_act)
 };
+
+// X3 ("split fp16") operands: a real value v is carried as the fp16 pair hi = f16(v·2^s), lo = f16(v·2^s − hi), i.e. 22
+// significand bits, and a product as hi·hi + hi·lo + lo·hi on the fp16 matrix cores with fp32 accumulation (the dropped
+// lo·lo term is 2^-22 relative): fp32-grade results at 16/3 of the fp32 MFMA rate. Tensors keep the NHWC fp16 machinery:
+// 16 real channels are one 32-half record [hi 0..15 | lo 0..15], so a tensor with C real channels looks like an fp16
+// tensor with 2C channels and the loaders below run unchanged; one 32-wide K chunk is then 16 real channels of a tap.
+struct X3Pair { _Float16 hi, lo; };
+__device__ __forceinline__ X3Pair x3_split(float x, float scale) {
+  float v = x * scale;
+  v = fminf(fmaxf(v, -60000.f), 60000.f);     // saturate instead of inf (fp16 max 65504)
+  const _Float16 h = (_Float16)v;
+  return {h, (_Float16)(v - (float)h)};
+}
 
 // validity of the (ky,kx) taps of a pixel as a 64-bit word (bit ky*8+kx), kh,kw <= 7: rows/columns hi0+k, wi0+k inside the frame
 __device__ __forceinline__ unsigned long long tap_mask64(int hi0, int wi0, int H, int W) {
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
 //               ds_read_b128 lane group (16 pixels, one octet) then covers all 64 banks once.
 // WGM x WGN waves of 128x128 (4x4 MFMA tiles) each: <2,2> = 256x256 block, 4 ring stages of 32 KB; <1,4> = 128x512 block for
 // Cout == 128 (conv2), 3 stages of 40 KB.
-template <int WGM, int WGN, int NSTAGE>
+template <int WGM, int WGN, int NSTAGE, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
   constexpr int BM = WGM * 128, BN = WGN * 128, TM = 4, TN = 4;
   constexpr int NPA = BM / 64, NPB = BN / 64, NP = NPA + NPB;   // 1 KB DMA pieces per wave per chunk: weights, activations
@@ -386,19 +400,38 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
       for (int j = 0; j < TN; ++j) bf[t][j] = bs[j * 128 + ((t * 2 + lrow) ^ sw)];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (X3) {
+      // octets 0,1 of the chunk = hi, octets 2,3 = lo of the same 16 real channels: af/bf[0] = hi, [1] = lo fragments.
+      // Three passes over the 4x4 tile grid (hi·hi, hi·lo, lo·hi): an accumulator is touched once per 16 MFMAs.
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int term = 0; term < 3; ++term)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i], bf[t][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int S8 = 8;                       // 8 issue slots per chunk (one after every 4 MFMAs)
-        const int slot = t * 4 + i;
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[term == 2 ? 1 : 0][i], bf[term == 1 ? 1 : 0][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int S12 = 12;                   // 12 issue slots per chunk (one after every 4 MFMAs)
+          const int slot = term * 4 + i;
 #pragma unroll
-        for (int q = slot * NP / S8; q < (slot + 1) * NP / S8; ++q) issue_piece(q);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+          for (int q = slot * NP / S12; q < (slot + 1) * NP / S12; ++q) issue_piece(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i], bf[t][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          constexpr int S8 = 8;                       // 8 issue slots per chunk (one after every 4 MFMAs)
+          const int slot = t * 4 + i;
+#pragma unroll
+          for (int q = slot * NP / S8; q < (slot + 1) * NP / S8; ++q) issue_piece(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     issue_end();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -418,6 +451,17 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
         if (co0 < p.Cout && prow) {
           *reinterpret_cast<float4*>(prow + co0) =
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        } else if (co0 < p.Cout && X3) {   // split16 output: record of 16 channels = [hi 16 | lo 16]
+          h4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][4 * g + r] * p.acc_scale + (p.bias ? p.bias[co0 + r] : 0.f);
+            x = x > 0.f ? x : x * p.slope;
+            { const X3Pair s2 = x3_split(x, p.out_scale); vh[r] = s2.hi; vl[r] = s2.lo; }
+          }
+          _Float16* rec = p.out + op * (2 * p.Cout) + (co0 >> 4) * 32 + (co0 & 15);
+          *reinterpret_cast<h4*>(rec) = vh;
+          *reinterpret_cast<h4*>(rec + 16) = vl;
         } else if (co0 < p.Cout) {
           h4 v;
 #pragma unroll
@@ -430,6 +474,35 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
         }
       }
   }
+}
+
+// X3 split-K second pass: Σ_s partial (fixed order) → real units → bias → LeakyReLU → split16 record
+__global__ __launch_bounds__(256) void splitk_x3_reduce_kernel(_Float16* __restrict__ out, const float* __restrict__ partial,
+                                                               const float* __restrict__ bias, long total4, int S, int Cout,
+                                                               float slope, float acc_scale, float out_scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const float4* p4 = reinterpret_cast<const float4*>(partial);
+  float4 v = p4[i];
+#pragma unroll 4
+  for (int s = 1; s < S; ++s) {
+    const float4 u = p4[(long)s * total4 + i];
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  const long e = i * 4;
+  const long pix = e / Cout;
+  const int c0 = (int)(e - pix * Cout);
+  float r[4] = {v.x, v.y, v.z, v.w};
+  h4 vh, vl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = r[k] * acc_scale + (bias ? bias[c0 + k] : 0.f);
+    x = x > 0.f ? x : x * slope;
+    { const X3Pair s2 = x3_split(x, out_scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+  }
+  _Float16* rec = out + pix * (2 * Cout) + (c0 >> 4) * 32 + (c0 & 15);
+  *reinterpret_cast<h4*>(rec) = vh;
+  *reinterpret_cast<h4*>(rec + 16) = vl;
 }
 
 // split-K second pass: out[pix][c] = f16(lrelu(Σ_s partial[s][pix][c] + bias[c])), slices added in order; 4 channels per thread
@@ -533,6 +606,58 @@ __global__ __launch_bounds__(256) void nhwc_f16_to_nchw_kernel(float* __restrict
   const long c = (i / hw) % C;
   const long n = i / (hw * C);
   out[i] = (float)in[(n * hw + r) * C + c];
+}
+
+// X3 weights: the packed layout of pack_f16_kernel over the 2·Cin virtual channels [hi 16 | lo 16] of w·w_scale
+__global__ void pack_x3_kernel(_Float16* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, int kh, int kw,
+                               int nchunk, int BM, float w_scale, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int h = (int)(i & 7);
+  const long r1 = i >> 3;
+  const int m = (int)(r1 % BM);
+  const long r2 = r1 / BM;
+  const int o = (int)(r2 & 7);
+  const long r3 = r2 >> 3;
+  const int kc = (int)(r3 % nchunk);
+  const int mt = (int)(r3 / nchunk);
+  int tap, cv0;
+  f16_octet(kc * HOCT + o, 2 * Cin, kh * kw, &tap, &cv0);
+  const int cv = cv0 + h, co = mt * BM + m;
+  const int ci = (cv >> 5) * 16 + (cv & 15);
+  X3Pair s2 = {(_Float16)0.f, (_Float16)0.f};
+  if (co < Cout && ci < Cin && tap < kh * kw) s2 = x3_split(w[(((long)co * Cin + ci) * kh + tap / kw) * kw + tap % kw], w_scale);
+  packed[i] = (cv & 16) ? s2.lo : s2.hi;
+}
+
+// NCHW fp32 → split16 NHWC; one thread per (pixel, 4 channels): two 8-byte stores
+__global__ __launch_bounds__(256) void nchw_to_split16_kernel(_Float16* __restrict__ out, const float* __restrict__ in, int C,
+                                                              long hw, float scale, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int q4 = C >> 2;
+  const int cq = (int)(i % q4);
+  const long pix = i / q4;
+  const long n = pix / hw, r = pix - n * hw;
+  h4 vh, vl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const X3Pair s2 = x3_split(in[(n * C + cq * 4 + k) * hw + r], scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+  const int c0 = cq * 4;
+  _Float16* rec = out + pix * (2 * C) + (c0 >> 4) * 32 + (c0 & 15);
+  *reinterpret_cast<h4*>(rec) = vh;
+  *reinterpret_cast<h4*>(rec + 16) = vl;
+}
+
+// split16 NHWC → NCHW fp32 (hi + lo, back to real units); lanes run along pixels of one channel
+__global__ __launch_bounds__(256) void split16_to_nchw_kernel(float* __restrict__ out, const _Float16* __restrict__ in, int C,
+                                                              long hw, float inv_scale, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long r = i % hw;
+  const int c = (int)((i / hw) % C);
+  const long n = i / (hw * C);
+  const _Float16* rec = in + (n * hw + r) * (2 * C) + (c >> 4) * 32 + (c & 15);
+  out[i] = ((float)rec[0] + (float)rec[16]) * inv_scale;
 }
 
 inline int f16_chunks(int Cin_pad, int kh, int kw) { return di_div_up(kh * kw * (Cin_pad / 8), HOCT); }
@@ -675,6 +800,113 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     const long total4 = p.npix * Cout / 4;
     hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out,
                        p.partial, bias, total4, p.ksplit, Cout, slope);
+  }
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------- X3: split-fp16 convolution ----
+extern "C" int deepim_nchw_f32_to_split16(deepim_ctx* ctx, void* out_split16, const float* in, int B, int C, int H, int W,
+                                          float scale) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE((C & 15) == 0, "nchw_to_split16: C must be a multiple of 16");
+  const long total = (long)B * H * W * (C / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(nchw_to_split16_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)out_split16, in,
+                     C, (long)H * W, scale, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_split16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_split16, int B, int C, int H, int W,
+                                          float inv_scale) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE((C & 15) == 0, "split16_to_nchw: C must be a multiple of 16");
+  const long total = (long)B * C * H * W;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(split16_to_nchw_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out,
+                     (const _Float16*)in_split16, C, (long)H * W, inv_scale, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t deepim_conv_x3_packed_size(int Cout, int Cin, int kh, int kw) {
+  return deepim_conv_f16_packed_size(Cout, 2 * Cin, kh, kw);
+}
+
+extern "C" int deepim_conv_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w, int Cout, int Cin, int kh, int kw,
+                                           float w_scale) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE((Cin & 31) == 0 && (Cout & 127) == 0, "conv_x3_pack: needs Cin % 32 == 0 and Cout % 128 == 0");
+  const int nchunk = f16_chunks(2 * Cin, kh, kw);
+  const int BM = f16_bm(Cout);
+  const long total = (long)di_div_up(Cout, BM) * nchunk * HOCT * BM * 8;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)packed, w, Cout, Cin, kh,
+                     kw, nchunk, BM, w_scale, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w,
+                                        const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                                        int pad, float slope, float acc_scale, float out_scale) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE((Cin & 31) == 0 && (Cout & 127) == 0, "conv2d_x3: needs Cin % 32 == 0 and Cout % 128 == 0");
+  DI_REQUIRE(kh <= 7 && kw <= 7, "conv2d_x3: kernel larger than 7 not supported");
+  const int Cv = 2 * Cin;   // virtual fp16 channels
+  ConvF16Params p;
+  p.in = in_split16; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_split16; p.tab = nullptr;
+  p.B = B; p.Cin = Cv; p.H = H; p.W = W; p.Cout = Cout;
+  p.Ho = (H + 2 * pad - kh) / stride + 1;
+  p.Wo = (W + 2 * pad - kw) / stride + 1;
+  p.stride = stride; p.pad = pad; p.slope = slope;
+  p.stride_kw = (kh << 16) | kw;
+  p.acc_scale = acc_scale; p.out_scale = out_scale;
+  p.nchunk = f16_chunks(Cv, kh, kw);
+  p.npix = (long)B * p.Ho * p.Wo;
+  p.pad_bytes = (pad * W + pad) * Cv * 2;
+  const size_t in_bytes = (size_t)B * H * W * Cv * 2;
+  DI_REQUIRE(in_bytes + p.pad_bytes < 0x7fffffffUL, "conv2d_x3: input tensor must be < 2 GiB per launch");
+  p.in_bytes = (unsigned)in_bytes;
+  const int BM = f16_bm(Cout), BN = f16_bn(Cout, true);
+  p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
+  const int blocks = p.gx * p.gy;
+  // split-K plan: the model of deepim_conv2d_f16_forward with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
+  int ks = 1;
+  if (ctx->conv_max_split != 1) {
+    float best = 1e30f;
+    for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
+      if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
+      const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
+                         (s_ > 1 ? 1.0f + 0.006f * (float)((long)blocks * s_) * (float)(BM * BN) / 16384.f : 0.f);
+      if (cost < best * 0.985f) { best = cost; ks = s_; }
+    }
+  }
+  if (ctx->conv_max_split > 1) ks = min(ks, ctx->conv_max_split);
+  p.chunks_per_split = di_div_up(p.nchunk, ks);
+  p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
+  p.partial = nullptr;
+  if (p.ksplit > 1) {
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)p.ksplit * p.npix * Cout * sizeof(float), &scratch);
+    if (rc) return rc;
+    p.partial = (float*)scratch;
+  }
+  static bool attr = false;
+  if (!attr) {
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+    attr = true;
+  }
+  const dim3 grid(blocks * p.ksplit);
+  if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, true>), grid, dim3(256), 122880, ctx->stream, p);
+  else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, true>), grid, dim3(256), 131072, ctx->stream, p);
+  if (p.ksplit > 1) {
+    const long total4 = p.npix * Cout / 4;
+    hipLaunchKernelGGL(splitk_x3_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, bias,
+                       total4, p.ksplit, Cout, slope, acc_scale, out_scale);
   }
   DI_LAUNCH_CHECK();
   return 0;
