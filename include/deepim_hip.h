@@ -262,6 +262,10 @@ int deepim_split16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_split
 size_t deepim_conv_x3_packed_size(int Cout, int Cin, int kh, int kw);
 int deepim_conv_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*Cout,Cin,kh,kw dev f32*/, int Cout, int Cin,
                                 int kh, int kw, float w_scale);
+/* conv1 of that encoder: the fp32 MFMA convolution (NCHW fp32 in, bit-exact products) writing split16 from its epilogue */
+int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16, const float* in, const float* packed_w, const float* bias,
+                                  int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
+                                  float out_scale);
 int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
                              int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                              float acc_scale, float out_scale);

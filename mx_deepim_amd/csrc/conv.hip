@@ -90,7 +90,8 @@ struct ConvParams {
   int n_full, tail_s, tail_cps, n_tail_pad;
   float* tail_partial;      // [tail_s][R][128 co][128 px]
   // channel-blocked activations ("NC8": [n][C/8][h][w][8]) between the encoder layers
-  int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW)
+  int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW, 1 = NC8; output only: 2 = split16 fp16 pairs)
+  float out_scale;          // split16 output: stored value = result · out_scale
   const float* wd8;         // weights for NC8 inputs [Cout/32][group = (c8,ky,kx)][lane][4]
   const int2* tab8;         // per group: {byte offset (c8*H*W + ky*W + kx)*32, bit ky*8+kx}
 };
@@ -390,6 +391,42 @@ __device__ __forceinline__ void store_tile_nc8(f32x16 (&acc)[TM][TN], float* __r
   }
 }
 
+// Epilogue for "split16" output (the activation format of the split-fp16 conv path, csrc/conv_f16.hip): NHWC, per 16 channels
+// a 32-half record [hi 0..15 | lo 0..15] with hi = f16(v·scale), lo = f16(v·scale − hi). Same ownership as the NC8 epilogue:
+// a lane holds 4 runs of 4 consecutive channels of one pixel → one 8-byte hi and one 8-byte lo store per run.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile_split16(f32x16 (&acc)[TM][TN], const ConvParams& p, int co0, long pix0, int lrow,
+                                                   int lcol) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long op = pix0 + j * 32 + lcol;
+    if (op >= p.npix) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = co0 + i * 32 + g * 8 + 4 * lrow;
+        if (c >= p.Cout) continue;
+        h4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][4 * g + r] + (p.bias ? p.bias[c + r] : 0.f);
+          v = v > 0.f ? v : v * p.slope;
+          v = fminf(fmaxf(v * p.out_scale, -60000.f), 60000.f);
+          const _Float16 h = (_Float16)v;
+          vh[r] = h;
+          vl[r] = (_Float16)(v - (float)h);
+        }
+        _Float16* rec = outh + op * (2 * p.Cout) + (c >> 4) * 32 + (c & 15);
+        *reinterpret_cast<h4*>(rec) = vh;
+        *reinterpret_cast<h4*>(rec + 16) = vl;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-free variant for the encoder convolutions (MODE_CONV, even Cin): every wave feeds its MFMAs straight from
 // registers loaded with coalesced buffer loads — no LDS staging, no block barrier, four fully independent waves per
@@ -594,6 +631,10 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
   float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
   const int ctotal = partial ? p.Cout : p.out_ctotal;
   const int coff = partial ? 0 : p.out_coff;
+  if (p.out_nc8 == 2) {   // split16 (never with split-K: the launcher keeps ksplit = 1 for this layout)
+    store_tile_split16<TM, TN>(acc, p, mb * BM + wm0, n0 + wn0, lrow, lcol);
+    return;
+  }
   if (p.out_nc8) {
     store_tile_nc8<TM, TN>(acc, outp, p, partial, mb * BM + wm0, n0 + wn0, lrow, lcol);
     return;
@@ -1118,6 +1159,7 @@ TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, i
 
 template <int MODE>
 int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
+  if (p.out_nc8 == 2) t.ksplit = 1, t.tail_s = 0;   // the split16 epilogue has no split-K second pass
   p.ksplit = t.ksplit;
   p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
   if (p.in_nc8) p.chunks_per_split = (p.chunks_per_split + 1) & ~1;   // the NC8 kernel consumes whole pairs of chunks
@@ -1328,10 +1370,31 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
                                   out_coff, 0, 0);
 }
 
+static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
+                               int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
+                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale);
+
 extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                         const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                         int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8,
                                         int out_nc8) {
+  return conv2d_forward_impl(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal, out_coff,
+                             in_nc8, out_nc8 ? 1 : 0, 1.f);
+}
+
+// NCHW fp32 in → split16 out (conv1 of the split-fp16 encoder): the fp32 MFMA convolution with the split folded into its
+// epilogue. Cout % 16 == 0; LDS-free kernels only (even Cin).
+extern "C" int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16, const float* in, const float* packed_w,
+                                             const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                             int stride, int pad, float slope, float out_scale) {
+  DI_REQUIRE((Cout & 15) == 0 && (Cin & 1) == 0, "conv2d_split16: needs Cout % 16 == 0 and an even Cin");
+  return conv2d_forward_impl(ctx, (float*)out_split16, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, 0, 0,
+                             0, 2, out_scale);
+}
+
+static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
+                               int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
+                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
@@ -1343,11 +1406,11 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
       const int Bc = (int)((limit - 1) / per_sample);
       DI_REQUIRE(Bc >= 1, "conv2d: one sample exceeds 2 GiB");
       const int Ho_ = (H + 2 * pad - kh) / stride + 1, Wo_ = (W + 2 * pad - kw) / stride + 1;
-      const size_t out_sample = (size_t)(out_ctotal > 0 ? out_ctotal : Cout) * Ho_ * Wo_;
+      const size_t out_sample = (size_t)(out_ctotal > 0 ? out_ctotal : Cout) * Ho_ * Wo_;   // split16: 2·Cout halves = Cout floats
       for (int b0 = 0; b0 < B; b0 += Bc) {
-        const int rc = deepim_conv2d_forward_ex(ctx, out + (size_t)b0 * out_sample, in + (size_t)b0 * Cin * H * W, packed_w, bias,
-                                                min(Bc, B - b0), Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
-                                                out_coff, in_nc8, out_nc8);
+        const int rc = conv2d_forward_impl(ctx, out + (size_t)b0 * out_sample, in + (size_t)b0 * Cin * H * W, packed_w, bias,
+                                           min(Bc, B - b0), Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
+                                           out_coff, in_nc8, out_nc8, out_scale);
         if (rc) return rc;
       }
       return 0;
@@ -1374,7 +1437,8 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
-  p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8 ? 1 : 0; p.wd8 = nullptr; p.tab8 = nullptr;
+  p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8; p.out_scale = out_scale; p.wd8 = nullptr; p.tab8 = nullptr;
+  if (out_nc8 == 2) DI_REQUIRE(!in_nc8, "conv2d: split16 output is built for the NCHW-input LDS-free kernel (conv1)");
   if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
   if (in_nc8) {
     DI_REQUIRE((Cin & 7) == 0 && Cout > 64, "conv2d: NC8 input needs Cin % 8 == 0 and Cout > 64");

@@ -54,6 +54,10 @@ struct ConvF16Params {
   int ksplit, chunks_per_split;  // split-K across grid slices for under-filled grids
   float* partial;                // [ksplit][npix][Cout] fp32 partial sums when ksplit > 1
   int stride_kw;                 // (kh << 16) | kw, for the DMA kernel's scalar tap counters
+  // tail split (DMA kernel, ksplit == 1): tiles [0, n_full) run whole; the R = gx·gy − n_full tiles of the under-filled last
+  // round are cut into tail_s K slices of tail_cps chunks → tile-local fp32 partials [slice][R][BN pixels][BM channels]
+  int n_full, tail_s, tail_cps;
+  float* tail_partial;
   float acc_scale, out_scale;    // X3 mode: accumulator → real units (2^-(s_act+s_w)), real units → stored activations (2^s_act)
 };
 
@@ -279,14 +283,24 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
   const int wm0 = (wave / WGN) * 128, wn0 = (wave % WGN) * 128;
   int vid;
   {
-    const int total = p.gx * p.gy * p.ksplit, bid = blockIdx.x;
+    // XCD-aware order over the whole tiles; the tail slices keep the dispatch order (they must start last)
+    const int total = p.n_full > 0 ? p.n_full : p.gx * p.gy * p.ksplit, bid = blockIdx.x;
     const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
-    vid = xcd * qn + min(xcd, rn) + (bid >> 3);
+    vid = bid < total ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
   }
-  const int bx = vid % p.gx, mb = (vid / p.gx) % p.gy, split = vid / (p.gx * p.gy);
+  int bx, mb, split, c_begin, c_end, tail_slot = -1;
+  if (p.n_full > 0 && vid >= p.n_full) {
+    const int R = p.gx * p.gy - p.n_full, t = vid - p.n_full;
+    const int tile = p.n_full + t % R, ts = t / R;
+    bx = tile % p.gx; mb = tile / p.gx; split = 0;
+    tail_slot = ts * R + (tile - p.n_full);
+    c_begin = ts * p.tail_cps * 2; c_end = min(p.nchunk, (ts + 1) * p.tail_cps) * 2;
+  } else {
+    bx = vid % p.gx; mb = (vid / p.gx) % p.gy; split = vid / (p.gx * p.gy);
+    // chunk32 range of this K slice (chunks_per_split counts 64-wide chunks)
+    c_begin = split * p.chunks_per_split * 2; c_end = min(p.nchunk, (split + 1) * p.chunks_per_split) * 2;
+  }
   const long n0 = (long)bx * BN;
-  // chunk32 range of this K slice (chunks_per_split counts 64-wide chunks)
-  const int c_begin = split * p.chunks_per_split * 2, c_end = min(p.nchunk, (split + 1) * p.chunks_per_split) * 2;
 
   // activation gather: piece i of wave w fills pixels (w*NPB+i)*16 .. +15 of the stage, lane = (pixel l>>2, slot l&3)
   unsigned voff[NPB];
@@ -437,6 +451,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DMA
 
+  if (tail_slot >= 0) {   // raw fp32 partial sums of a tail slice, tile-local [pixel][channel]
+    float* tp = p.tail_partial + (long)tail_slot * (BM * BN);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(tp + (wn0 + j * 32 + lcol) * BM + wm0 + i * 32 + 8 * g + 4 * lrow) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long op = n0 + wn0 + j * 32 + lcol;
@@ -503,6 +529,44 @@ __global__ __launch_bounds__(256) void splitk_x3_reduce_kernel(_Float16* __restr
   _Float16* rec = out + pix * (2 * Cout) + (c0 >> 4) * 32 + (c0 & 15);
   *reinterpret_cast<h4*>(rec) = vh;
   *reinterpret_cast<h4*>(rec + 16) = vl;
+}
+
+// tail-split second pass: one thread per (remainder tile, pixel, 4 channels); slices added in order, then the layer epilogue
+template <bool X3>
+__global__ __launch_bounds__(256) void tail_f16_reduce_kernel(ConvF16Params p, int BM, int BN) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int R = p.gx * p.gy - p.n_full, q4 = BM >> 2;
+  const long per_tile = (long)BN * q4;
+  if (i >= R * per_tile) return;
+  const int rt = (int)(i / per_tile);
+  const long e = i - rt * per_tile;
+  const int pl = (int)(e / q4), c4 = (int)(e - (long)pl * q4);
+  const int tile = p.n_full + rt, bx = tile % p.gx, mb = tile / p.gx;
+  const long op = (long)bx * BN + pl;
+  const int co0 = mb * BM + c4 * 4;
+  if (op >= p.npix || co0 >= p.Cout) return;
+  const float* tp = p.tail_partial + ((long)rt * BN + pl) * BM + c4 * 4;
+  float4 v = *reinterpret_cast<const float4*>(tp);
+  for (int s = 1; s < p.tail_s; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(tp + (long)s * R * BM * BN);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  float r[4] = {v.x, v.y, v.z, v.w};
+  h4 vh, vl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = (X3 ? r[k] * p.acc_scale : r[k]) + (p.bias ? p.bias[co0 + k] : 0.f);
+    x = x > 0.f ? x : x * p.slope;
+    if (X3) { const X3Pair s2 = x3_split(x, p.out_scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+    else vh[k] = (_Float16)x;
+  }
+  if (X3) {
+    _Float16* rec = p.out + op * (2 * p.Cout) + (co0 >> 4) * 32 + (co0 & 15);
+    *reinterpret_cast<h4*>(rec) = vh;
+    *reinterpret_cast<h4*>(rec + 16) = vl;
+  } else {
+    *reinterpret_cast<h4*>(p.out + op * p.Cout + co0) = vh;
+  }
 }
 
 // split-K second pass: out[pix][c] = f16(lrelu(Σ_s partial[s][pix][c] + bias[c])), slices added in order; 4 channels per thread
@@ -704,6 +768,86 @@ extern "C" int deepim_conv_f16_pack_weights(deepim_ctx* ctx, void* packed, const
   return 0;
 }
 
+namespace {
+// Plan + launch of the LDS-DMA kernel (fp16 or X3). One 256-thread block per CU. Plans, in units of one 64-wide K chunk:
+//   uniform split-K s:   ceil(blocks·s / 256) · ceil(nchunk / s)                      + reduce(blocks·s)
+//   tail split ts:       floor(blocks / 256) · nchunk + ceil(R·ts / 256) · ceil(nchunk / ts) + reduce(R·ts),  R = blocks mod 256
+// reduce(n) = c0 + c1·n·(BM·BN/16384): fp32 partial tiles written and read once; deterministic, no timing involved.
+template <bool X3>
+int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1) {
+  const int blocks = p.gx * p.gy;
+  int ks = 1, ts = 0;
+  if (ctx->conv_max_split != 1) {
+    float best = 1e30f;
+    const float tile_w = (float)(BM * BN) / 16384.f;
+    for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
+      if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
+      const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
+                         (s_ > 1 ? c0 + c1 * (float)((long)blocks * s_) * tile_w : 0.f);
+      if (cost < best * 0.985f) { best = cost; ks = s_; }
+    }
+    const int R = blocks % 256;
+    if (blocks > 256 && R > 0 && ctx->conv_max_split == 0 && !getenv("DEEPIM_F16_NO_TAIL")) {
+      for (int t_ : {2, 3, 4, 5, 6, 8}) {
+        if (t_ > max(1, p.nchunk / 4)) continue;
+        const float cost = (float)(blocks / 256) * (float)p.nchunk + (float)di_div_up(R * t_, 256) * (float)di_div_up(p.nchunk, t_) +
+                           c0 + c1 * (float)(R * t_) * tile_w;
+        if (cost < best * 0.97f) { best = cost; ts = t_; ks = 1; }
+      }
+    }
+  }
+  if (ctx->conv_max_split > 1) ks = min(ks, ctx->conv_max_split);
+  p.chunks_per_split = di_div_up(p.nchunk, ks);
+  p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
+  p.partial = nullptr;
+  p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr;
+  int grid = blocks * p.ksplit;
+  if (p.ksplit > 1) {
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)p.ksplit * p.npix * p.Cout * sizeof(float), &scratch);
+    if (rc) return rc;
+    p.partial = (float*)scratch;
+  } else if (ts > 1) {
+    const int R = blocks % 256;
+    p.n_full = blocks - R;
+    p.tail_cps = di_div_up(p.nchunk, ts);
+    p.tail_s = di_div_up(p.nchunk, p.tail_cps);
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)p.tail_s * R * BM * BN * sizeof(float), &scratch);
+    if (rc) return rc;
+    p.tail_partial = (float*)scratch;
+    grid = p.n_full + R * p.tail_s;
+  }
+  static bool attr = false;
+  if (!attr) {
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+    attr = true;
+  }
+  if (getenv("DEEPIM_CONV_VERBOSE"))
+    fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
+            X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
+  if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3>), dim3(grid), dim3(256), 122880, ctx->stream, p);
+  else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, X3>), dim3(grid), dim3(256), 131072, ctx->stream, p);
+  if (p.ksplit > 1) {
+    const long total4 = p.npix * p.Cout / 4;
+    if (X3)
+      hipLaunchKernelGGL(splitk_x3_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, p.bias,
+                         total4, p.ksplit, p.Cout, p.slope, p.acc_scale, p.out_scale);
+    else
+      hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, p.bias,
+                         total4, p.ksplit, p.Cout, p.slope);
+  } else if (p.tail_s > 1) {
+    const long total = (long)(blocks - p.n_full) * BN * (BM / 4);
+    hipLaunchKernelGGL(tail_f16_reduce_kernel<X3>, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p, BM, BN);
+  }
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* in_nhwc_f16,
                                          const void* packed_w, const float* bias, int B, int Cin_pad, int H, int W,
                                          int Cout, int kh, int kw, int stride, int pad, float slope) {
@@ -740,6 +884,8 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   const bool ut = ((Cin_pad >> 3) & 7) == 0;
   const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !getenv("DEEPIM_F16_NO_DMA"));
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
+  p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr; p.acc_scale = p.out_scale = 1.f;
+  if (ut && BM >= 128 && !getenv("DEEPIM_F16_NO_DMA")) return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f);
   const int blocks = p.gx * p.gy;
   // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when
   // the grid cannot fill the 256 CUs; deterministic (cost model of csrc/conv.hip's plan_ksplit, one slot per CU)
@@ -872,42 +1018,6 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   p.in_bytes = (unsigned)in_bytes;
   const int BM = f16_bm(Cout), BN = f16_bn(Cout, true);
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
-  const int blocks = p.gx * p.gy;
-  // split-K plan: the model of deepim_conv2d_f16_forward with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
-  int ks = 1;
-  if (ctx->conv_max_split != 1) {
-    float best = 1e30f;
-    for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
-      if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
-      const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
-                         (s_ > 1 ? 1.0f + 0.006f * (float)((long)blocks * s_) * (float)(BM * BN) / 16384.f : 0.f);
-      if (cost < best * 0.985f) { best = cost; ks = s_; }
-    }
-  }
-  if (ctx->conv_max_split > 1) ks = min(ks, ctx->conv_max_split);
-  p.chunks_per_split = di_div_up(p.nchunk, ks);
-  p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
-  p.partial = nullptr;
-  if (p.ksplit > 1) {
-    void* scratch;
-    int rc = deepim_scratch(ctx, (size_t)p.ksplit * p.npix * Cout * sizeof(float), &scratch);
-    if (rc) return rc;
-    p.partial = (float*)scratch;
-  }
-  static bool attr = false;
-  if (!attr) {
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
-    attr = true;
-  }
-  const dim3 grid(blocks * p.ksplit);
-  if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, true>), grid, dim3(256), 122880, ctx->stream, p);
-  else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, true>), grid, dim3(256), 131072, ctx->stream, p);
-  if (p.ksplit > 1) {
-    const long total4 = p.npix * Cout / 4;
-    hipLaunchKernelGGL(splitk_x3_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, bias,
-                       total4, p.ksplit, Cout, slope, acc_scale, out_scale);
-  }
-  DI_LAUNCH_CHECK();
-  return 0;
+  // the plan model of the fp16 path with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
+  return launch_f16_dma<true>(ctx, p, BM, BN, 1.0f, 0.006f);
 }

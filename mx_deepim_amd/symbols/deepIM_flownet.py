@@ -314,9 +314,8 @@ class deepIM_flownet(object):
         A, h, B = self.act, self.ctx.handle, self.B
         c, sa = ctypes.c_float, self.X3_ACT_SCALE
         name, cin, hh, ww, cout, k, s, p = self.enc_geom[0]
-        self._conv(name, A["net_input"], A[name], B, cin, hh, ww, cout, k, s, p, SLOPE)
-        ho, wo = _out_hw(hh, ww, k, s, p)
-        lib.deepim_nchw_f32_to_split16(h, A[name + "_x"], A[name], B, cout, ho, wo, c(sa))
+        lib.deepim_conv2d_forward_split16(h, A[name + "_x"], A["net_input"], self.packed[name], self.params[name + "_bias"], B,
+                                          cin, hh, ww, cout, k, k, s, p, c(SLOPE), c(sa))
         src = A[name + "_x"]
         for name, cin, hh, ww, cout, k, s, p in self.enc_geom[1:]:
             lib.deepim_conv2d_x3_forward(h, A[name + "_x"], src, self.packed_x3[name], self.params[name + "_bias"], B, cin, hh,
@@ -355,7 +354,7 @@ class deepIM_flownet(object):
         """Encoder activation `name` as an NCHW device array (a converted copy when the encoder ran channel-blocked)."""
         a = self.act[name]
         names = [g[0] for g in self.enc_geom]
-        if getattr(self, "act_layout", "nchw") == "x3" and name in names[1:-1]:
+        if getattr(self, "act_layout", "nchw") == "x3" and name in names[:-1]:
             lib.deepim_split16_to_nchw_f32(self.ctx.handle, a, self.act[name + "_x"], a.shape[0], a.shape[1], a.shape[2],
                                            a.shape[3], ctypes.c_float(1.0 / self.X3_ACT_SCALE))
             return a

@@ -65,7 +65,8 @@ def test_split16_round_trip(ctx):
 
 
 X3_CASES = [(1, 64, 60, 80, 128, 5, 2, 2), (2, 128, 30, 40, 256, 5, 2, 2), (2, 256, 15, 20, 256, 3, 1, 1), (1, 256, 30, 40, 512, 3, 2, 1),
-            (3, 1024, 8, 10, 1024, 3, 1, 1), (2, 32, 9, 11, 128, 3, 1, 1), (1, 96, 7, 6, 384, 3, 2, 1)]
+            (3, 1024, 8, 10, 1024, 3, 1, 1), (2, 32, 9, 11, 128, 3, 1, 1), (1, 96, 7, 6, 384, 3, 2, 1),
+            (4, 32, 120, 160, 256, 3, 1, 1)]   # last: 300 tiles of 256x256 → 256 whole + 44 tail tiles cut into K slices
 
 
 @pytest.mark.parametrize("case", X3_CASES)
