@@ -266,6 +266,14 @@ int deepim_conv_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*
 int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16, const float* in, const float* packed_w, const float* bias,
                                   int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                                   float out_scale);
+/* conv1 (Cin 8, 7x7, stride 2, pad 3, Cout 64; deepIM_flownet.py:63-67) in split fp16 straight from the NCHW fp32 net input:
+ * persistent LDS-patch kernel, two taps per 16-wide MFMA k-step. in_scale: scale applied to the input before the split;
+ * acc_scale = 1 / (in_scale · w_scale). Output split16 (B,Ho,Wo,64 ch). */
+size_t deepim_conv1_x3_packed_size(void);
+int deepim_conv1_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*64,8,7,7*/, float w_scale);
+int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const float* in /*B,8,H,W*/, const void* packed_w,
+                            const float* bias, int B, int H, int W, float slope, float in_scale, float acc_scale,
+                            float out_scale);
 int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
                              int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                              float acc_scale, float out_scale);

@@ -724,6 +724,203 @@ __global__ __launch_bounds__(256) void split16_to_nchw_kernel(float* __restrict_
   out[i] = ((float)rec[0] + (float)rec[16]) * inv_scale;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1 of the split-fp16 encoder: Cin = 8, 7x7, stride 2, pad 3, Cout = 64 (deepIM_flownet.py:63-67) straight from the NCHW
+// fp32 net input. With 8 input channels a 16-wide MFMA k-step holds TWO taps (lanes 0-31 tap t, lanes 32-63 tap t+1), so the
+// 49 taps are 25 k-steps and the three split products 75 MFMAs per 32x32 output tile.
+//   * persistent blocks (one per CU), the packed weights of all taps stay in LDS (100 KB: w_hi / w_lo [tap][co][8 halves]);
+//   * a block tile is 8 output rows x 32 columns of one image; its 21 x 69 input patch is loaded as fp32 (coalesced along
+//     rows, zero outside the frame), split into (hi, lo) and stored in LDS de-interleaved by column parity
+//     [row][parity][35][8 halves] — stride 2 then makes the 32 pixels of a fragment 512 contiguous bytes (conflict-free
+//     ds_read_b128), for every tap; the next tile's patch is prefetched into registers while the current one is multiplied;
+//   * wave w owns output rows 2w, 2w+1 (two 32-pixel fragments) x all 64 channels: 8 ds_read_b128 per 12 MFMAs;
+//   * epilogue: accumulator → real units, bias, LeakyReLU, split16 records (NHWC) for conv2.
+constexpr int C1_TAPS = 49, C1_PAIRS = 25, C1_ROWS = 21, C1_RW = 35, C1_PIX = 21 * 69;
+constexpr int C1_WH = 50 * 64;                 // h8 entries of w_hi (and of w_lo)
+constexpr int C1_PH = C1_ROWS * 2 * C1_RW;     // h8 entries of a_hi (and of a_lo)
+constexpr int C1_LDS = (2 * C1_WH + 2 * C1_PH) * 16;
+
+struct Conv1Params {
+  const float* in;      // (B,8,H,W) fp32
+  const h8* wp;         // packed [hi|lo][50 taps][64 co] h8 (tap 49 = zeros)
+  const float* bias;
+  _Float16* out;        // split16 NHWC (B,Ho,Wo,128 halves)
+  int B, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
+  float slope, in_scale, acc_scale, out_scale;
+};
+
+__global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
+  extern __shared__ __attribute__((aligned(16))) h8 smem[];
+  h8* w_hi = smem;
+  h8* w_lo = smem + C1_WH;
+  h8* a_hi = smem + 2 * C1_WH;
+  h8* a_lo = a_hi + C1_PH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 5, lcol = lane & 31;
+  for (int i = tid; i < 2 * C1_WH; i += 256) smem[i] = p.wp[i];
+
+  // patch pixels of this thread: q = k*256 + tid → (row q / 69, column q % 69)
+  int pr[6], pc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int q = k * 256 + tid;
+    pr[k] = q / 69;
+    pc[k] = q - pr[k] * 69;
+  }
+  float v[6][8];
+  const long plane = (long)p.H * p.W;
+  auto load_patch = [&](int tile) {
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+    const int gy0 = 2 * (ty * 8) - 3, gx0 = 2 * (tx * 32) - 3;
+    const float* src = p.in + (long)n * 8 * plane;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int gy = gy0 + pr[k], gx = gx0 + pc[k];
+      const bool ok = (k * 256 + tid) < C1_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const long o = ok ? (long)gy * p.W + gx : 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float x = src[o + c * plane];
+        v[k][c] = ok ? x : 0.f;
+      }
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k * 256 + tid >= C1_PIX) continue;
+      h8 hi, lo;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const X3Pair s2 = x3_split(v[k][c], p.in_scale);
+        hi[c] = s2.hi;
+        lo[c] = s2.lo;
+      }
+      const int idx = (pr[k] * 2 + (pc[k] & 1)) * C1_RW + (pc[k] >> 1);
+      a_hi[idx] = hi;
+      a_lo[idx] = lo;
+    }
+  };
+
+  // bias of this lane's 8 channel runs (i, g), kept in registers: a load inside the epilogue would wait behind the prefetch
+  // loads and the previous tile's stores (vmcnt counts in order)
+  float bias_r[2][4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_r[i][g][r] = p.bias ? p.bias[i * 32 + 8 * g + 4 * lrow + r] : 0.f;
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_patch(tile);
+  // fragment bases: A rows = output channels (lane%32, + 32 for the second tile), the half-wave picks tap t or t+1;
+  // B columns = 32 output pixels of row 2*wave + j
+  const int a_base = lrow * 64 + lcol;
+  const int b_base0 = (2 * (2 * wave) * 2) * C1_RW + lcol, b_base1 = (2 * (2 * wave + 1) * 2) * C1_RW + lcol;
+  // epilogue staging (the patch region, once every wave is done with it): this wave's 32 pixels of one output row as
+  // records of 256 B at a 272-byte pitch, so the lane-per-pixel writes spread over the banks
+  constexpr int C1_PITCH = 272;
+  char* stage = reinterpret_cast<char*>(a_hi) + wave * (32 * C1_PITCH);
+  h8 fr[2][8];   // [set][ah0 ah1 al0 al1 bh0 bh1 bl0 bl1]
+  auto read_frags = [&](int set, int pp) {
+    const int t0 = 2 * pp, t1 = min(2 * pp + 1, C1_TAPS - 1);   // tap 49 has zero weights: any valid pixel address will do
+    const int ky0 = t0 / 7, kx0 = t0 % 7, ky1 = t1 / 7, kx1 = t1 % 7;
+    const int o0 = (ky0 * 2 + (kx0 & 1)) * C1_RW + (kx0 >> 1), o1 = (ky1 * 2 + (kx1 & 1)) * C1_RW + (kx1 >> 1);
+    const int bo = lrow ? o1 : o0;
+    fr[set][0] = w_hi[t0 * 64 + a_base];
+    fr[set][1] = w_hi[t0 * 64 + a_base + 32];
+    fr[set][4] = a_hi[b_base0 + bo];
+    fr[set][5] = a_hi[b_base1 + bo];
+    fr[set][6] = a_lo[b_base0 + bo];
+    fr[set][7] = a_lo[b_base1 + bo];
+    fr[set][2] = w_lo[t0 * 64 + a_base];
+    fr[set][3] = w_lo[t0 * 64 + a_base + 32];
+  };
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();                       // every wave is done with the staging area (and the weights are in place)
+    store_patch();
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) load_patch(tile + gridDim.x);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    {
+      read_frags(0, 0);
+#pragma unroll
+      for (int pp = 0; pp < C1_PAIRS; ++pp) {
+        const int cur = pp & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp + 1 < C1_PAIRS) read_frags(cur ^ 1, pp + 1);     // next pair's fragments fly while this pair multiplies
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][6 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][2 + i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                       // all waves are past their last patch read: the region becomes the staging area
+    // epilogue: real units, bias, LeakyReLU, split → LDS record → 16 B per lane, 1 KB (4 pixel records) per wave store
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + (long)n * p.Ho * p.Wo * 128), 0, (int)((long)p.Ho * p.Wo * 256), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oy = ty * 8 + 2 * wave + j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co0 = i * 32 + 8 * g + 4 * lrow;
+          h4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][4 * g + r] * p.acc_scale + bias_r[i][g][r];
+            x = x > 0.f ? x : x * p.slope;
+            const X3Pair s2 = x3_split(x, p.out_scale);
+            vh[r] = s2.hi;
+            vl[r] = s2.lo;
+          }
+          char* rec = stage + lcol * C1_PITCH + (co0 >> 4) * 64 + (co0 & 15) * 2;
+          *reinterpret_cast<h4*>(rec) = vh;
+          *reinterpret_cast<h4*>(rec + 32) = vl;
+        }
+      // the wave reads back its own writes (LDS operations of a wave complete in order)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int px = k * 4 + (lane >> 4), chunk = lane & 15;
+        const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * C1_PITCH + chunk * 16);
+        const int ox = tx * 32 + px;
+        const bool ok = oy < p.Ho && ox < p.Wo;
+        const unsigned off = ok ? (unsigned)((oy * p.Wo + ox) * 256 + chunk * 16) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)off, 0, 0);
+      }
+    }
+  }
+}
+
+// conv1 weights (64,8,7,7) fp32 → [hi|lo][50 taps][64 co][8 halves] of w·w_scale (tap 49 zero)
+__global__ void pack_conv1_x3_kernel(_Float16* __restrict__ packed, const float* __restrict__ w, float w_scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C1_WH * 8) return;
+  const int c = i & 7, co = (i >> 3) & 63, t = (i >> 9) % 50, part = i / (C1_WH * 8);
+  X3Pair s2 = {(_Float16)0.f, (_Float16)0.f};
+  if (t < C1_TAPS) s2 = x3_split(w[((co * 8 + c) * 7 + t / 7) * 7 + t % 7], w_scale);
+  packed[i] = part ? s2.lo : s2.hi;
+}
+
 inline int f16_chunks(int Cin_pad, int kh, int kw) { return di_div_up(kh * kw * (Cin_pad / 8), HOCT); }
 
 }  // namespace
@@ -1020,4 +1217,39 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   // the plan model of the fp16 path with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
   return launch_f16_dma<true>(ctx, p, BM, BN, 1.0f, 0.006f);
+}
+
+extern "C" size_t deepim_conv1_x3_packed_size(void) { return (size_t)2 * C1_WH * 16; }
+
+extern "C" int deepim_conv1_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w, float w_scale) {
+  DI_DEVICE(ctx);
+  hipLaunchKernelGGL(pack_conv1_x3_kernel, dim3(di_div_up(2 * C1_WH * 8, 256)), dim3(256), 0, ctx->stream, (_Float16*)packed, w,
+                     w_scale);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const float* in, const void* packed_w,
+                                       const float* bias, int B, int H, int W, float slope, float in_scale, float acc_scale,
+                                       float out_scale) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  Conv1Params p;
+  p.in = in; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_split16;
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
+  p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
+  const long nt = (long)p.tiles_x * p.tiles_y * B;
+  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W < (1L << 40), "conv1_x3: too many tiles");
+  p.ntiles = (int)nt;
+  p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale;
+  static bool attr = false;
+  if (!attr) {
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
+    attr = true;
+  }
+  const int grid = (int)min(256L, nt);   // persistent: one block per CU
+  hipLaunchKernelGGL(conv1_x3_kernel, dim3(grid), dim3(256), C1_LDS, ctx->stream, p);
+  DI_LAUNCH_CHECK();
+  return 0;
 }

@@ -229,6 +229,13 @@ class deepIM_flownet(object):
                 cin = cout
         if self.x3_conv:     # split-fp16 weights [hi 16 | lo 16] in MFMA octet order, scaled by a power of two into fp16's range
             self.packed_x3, self.x3_wscale = {}, {}
+            if self.cin == 8:    # conv1 on the split-fp16 patch kernel (built for the 8-channel input; otherwise fp32 conv1)
+                name = ENCODER[0][0]
+                m = float(np.abs(np.asarray(arg_params[name + "_weight"], np.float32)).max())
+                self.x3_wscale[name] = 2.0 ** int(np.floor(np.log2(1536.0 / m))) if m > 0 else 1.0
+                pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
+                lib.deepim_conv1_x3_pack_weights(h, pk, self.params[name + "_weight"], ctypes.c_float(self.x3_wscale[name]))
+                self.packed_x3[name] = pk
             cin = ENCODER[0][1]
             for name, cout, k, s_, p_ in ENCODER[1:]:
                 m = float(np.abs(np.asarray(arg_params[name + "_weight"], np.float32)).max())
@@ -314,8 +321,12 @@ class deepIM_flownet(object):
         A, h, B = self.act, self.ctx.handle, self.B
         c, sa = ctypes.c_float, self.X3_ACT_SCALE
         name, cin, hh, ww, cout, k, s, p = self.enc_geom[0]
-        lib.deepim_conv2d_forward_split16(h, A[name + "_x"], A["net_input"], self.packed[name], self.params[name + "_bias"], B,
-                                          cin, hh, ww, cout, k, k, s, p, c(SLOPE), c(sa))
+        if name in self.packed_x3:
+            lib.deepim_conv1_x3_forward(h, A[name + "_x"], A["net_input"], self.packed_x3[name], self.params[name + "_bias"], B,
+                                        hh, ww, c(SLOPE), c(sa), c(1.0 / (sa * self.x3_wscale[name])), c(sa))
+        else:
+            lib.deepim_conv2d_forward_split16(h, A[name + "_x"], A["net_input"], self.packed[name], self.params[name + "_bias"],
+                                              B, cin, hh, ww, cout, k, k, s, p, c(SLOPE), c(sa))
         src = A[name + "_x"]
         for name, cin, hh, ww, cout, k, s, p in self.enc_geom[1:]:
             lib.deepim_conv2d_x3_forward(h, A[name + "_x"], src, self.packed_x3[name], self.params[name + "_bias"], B, cin, hh,

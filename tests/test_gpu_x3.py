@@ -86,6 +86,37 @@ def test_conv_x3_is_fp32_grade(ctx, case):
     assert err < 4e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 50, 70), (3, 16, 64), (1, 480, 640)])
+def test_conv1_x3_patch_kernel(ctx, shape):
+    """conv1 (8 → 64 channels, 7x7 s2 p3) on the persistent split-fp16 patch kernel vs the fp32 oracle; also the fp32 conv1
+    with the split16 epilogue (the fallback for other channel counts)."""
+    B, H, W = shape
+    rng = np.random.default_rng(H + W)
+    x = rng.uniform(-1, 1, (B, 8, H, W)).astype(np.float32)
+    x[:, 6:] = (x[:, 6:] > 0.3)                                           # mask channels: exact 0 / 1
+    w = (rng.standard_normal((64, 8, 7, 7)) / np.sqrt(8 * 49)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    ref = onet.conv2d(x, w, b, 2, 3, 0.1)
+    ho, wo = ref.shape[2:]
+    h, sa, ws = ctx.handle, 16.0, _wscale(w)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
+    lib.deepim_conv1_x3_pack_weights(h, pk, ctx.array(w), cf(ws))
+    os_ = ctx.empty((B, ho, wo, 128), dtype=np.float16)
+    lib.deepim_conv1_x3_forward(h, os_, ctx.array(x), pk, ctx.array(b), B, H, W, cf(0.1), cf(sa), cf(1.0 / (sa * ws)), cf(sa))
+    out = ctx.empty((B, 64, ho, wo))
+    lib.deepim_split16_to_nchw_f32(h, out, os_, B, 64, ho, wo, cf(1.0 / sa))
+    err = np.abs(out.asnumpy().astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, err
+    # fp32 conv1 + split16 epilogue: the fp32 result carried as pairs
+    pk32 = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(64, 8, 7, 7) // 4,))
+    lib.deepim_conv_pack_weights(h, pk32, ctx.array(w), 64, 8, 7, 7)
+    os2 = ctx.empty((B, ho, wo, 128), dtype=np.float16)
+    lib.deepim_conv2d_forward_split16(h, os2, ctx.array(x), pk32, ctx.array(b), B, 8, H, W, 64, 7, 7, 2, 3, cf(0.1), cf(sa))
+    out2 = ctx.empty((B, 64, ho, wo))
+    lib.deepim_split16_to_nchw_f32(h, out2, os2, B, 64, ho, wo, cf(1.0 / sa))
+    assert np.abs(out2.asnumpy().astype(np.float64) - ref).max() / np.abs(ref).max() < 2e-6
+
+
 def test_conv_x3_small_and_large_magnitudes(ctx):
     """Activations 1e-4 … 1e+2 and weights around 1e-3: pairs stay accurate across fp16's normal range (and below it if the
     matrix cores keep fp16 subnormals); the result is held to 1e-5 of the output maximum."""

@@ -44,24 +44,30 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int iters, unsigned seed
   for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   out[blockIdx.x * 256 + tid] = s;
 }
+static int g_lds = 131072;
 template <int TM, int TN, int LDS>
 void run(const char* name, float* out, int blocks) {
-  hipFuncSetAttribute((const void*)k<TM, TN, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)k<TM, TN, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, g_lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int iters : {2000, 20000}) {
-    k<TM, TN, LDS><<<blocks, 256, 131072>>>(out, iters, 1u); hipDeviceSynchronize();
-    hipEventRecord(e0); k<TM, TN, LDS><<<blocks, 256, 131072>>>(out, iters, 7u); hipEventRecord(e1); hipEventSynchronize(e1);
+    k<TM, TN, LDS><<<blocks, 256, g_lds>>>(out, iters, 1u); hipDeviceSynchronize();
+    hipEventRecord(e0); k<TM, TN, LDS><<<blocks, 256, g_lds>>>(out, iters, 7u); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double fl = (double)blocks * 4 * iters * 4 * TM * TN * 32768.0;
     printf("%-34s blocks %d iters %5d: %8.3f ms  %7.1f TFLOP/s\n", name, blocks, iters, ms, fl / ms / 1e9);
   }
 }
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_lds = atoi(argv[1]);
+  printf("dynamic LDS %d bytes\n", g_lds);
   float* out; hipMalloc(&out, 4096 * 256 * 4);
   run<4, 4, 0>("4x4 tile, MFMA only", out, 256);
   run<4, 4, 1>("4x4 tile, + 8 ds_read_b128/k-step", out, 256);
   run<2, 4, 0>("2x4 tile, MFMA only", out, 256);
   run<2, 4, 1>("2x4 tile, + 6 ds_read_b128/k-step", out, 256);
+  run<2, 2, 0>("2x2 tile, MFMA only", out, 256);
+  run<1, 2, 0>("1x2 tile, MFMA only", out, 256);
+  run<1, 1, 0>("1x1 tile, MFMA only", out, 256);
   run<2, 2, 1>("2x2 tile, + 4 ds_read_b128/k-step", out, 256);
   run<2, 2, 1>("2x2 tile, 2 blocks/CU", out, 512);
   return 0;
