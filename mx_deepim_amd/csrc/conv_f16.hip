@@ -37,7 +37,13 @@ constexpr int HOCT = 8;   // octets per chunk (K chunk = 8 octets x 8 halves = 6
 //   Cout % 256 != 0 (conv2)   waves 2x2, wave tile 2x4: 128 x 256 block
 //   Cout % 256 == 0           waves 2x2, wave tile 4x4: 256 x 256 block (256 accumulator registers, one wave per SIMD)
 inline int f16_bm(int Cout) { return Cout <= 64 ? 64 : ((Cout & 255) == 0 ? 256 : 128); }
-inline int f16_bn(int Cout, bool dma) { return (f16_bm(Cout) == 128 && dma) ? 512 : 256; }
+// DMA kernel: 128x64 wave tiles, two blocks per CU (DEEPIM_F16_TN4=1 restores the 128x128 wave tiles, one block per CU)
+inline int f16_bn(int Cout, bool dma) {
+  if (!dma) return 256;
+  const bool tn4 = getenv("DEEPIM_F16_TN4") != nullptr;
+  if (f16_bm(Cout) == 256) return tn4 ? 256 : 128;
+  return f16_bm(Cout) == 128 ? (tn4 ? 512 : 256) : 256;
+}
 
 struct ConvF16Params {
   const void* in;       // NHWC fp16 (B,H,W,Cin)
@@ -271,16 +277,18 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
 //               ds_read_b128 lane group (16 pixels, one octet) then covers all 64 banks once.
 // WGM x WGN waves of 128x128 (4x4 MFMA tiles) each: <2,2> = 256x256 block, 4 ring stages of 32 KB; <1,4> = 128x512 block for
 // Cout == 128 (conv2), 3 stages of 40 KB.
-template <int WGM, int WGN, int NSTAGE, bool X3 = false>
-__global__ __launch_bounds__(256, 1) void conv_f16_dma_kernel(ConvF16Params p) {
-  constexpr int BM = WGM * 128, BN = WGN * 128, TM = 4, TN = 4;
+template <int WGM, int WGN, int NSTAGE, bool X3 = false, int TN = 4>
+__global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(ConvF16Params p) {
+  // TN = 2: 128x64 wave tiles (128 accumulator registers) so that two blocks share a CU, i.e. two waves per SIMD — one wave
+  // alone issues MFMAs at 71 % of the pipe's rate (tools/mfma_f16_probe.hip) and nothing covers its waits
+  constexpr int BM = WGM * 128, BN = WGN * TN * 32, TM = 4;
   constexpr int NPA = BM / 64, NPB = BN / 64, NP = NPA + NPB;   // 1 KB DMA pieces per wave per chunk: weights, activations
   constexpr int STAGE = (BM + BN) * 4;     // h8 per stage: BM*4 weights + BN*4 activations
   static_assert(WGM * WGN == 4 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave / WGN) * 128, wn0 = (wave % WGN) * 128;
+  const int wm0 = (wave / WGN) * 128, wn0 = (wave % WGN) * (TN * 32);
   int vid;
   {
     // XCD-aware order over the whole tiles; the tail slices keep the dispatch order (they must start last)
@@ -973,21 +981,23 @@ namespace {
 template <bool X3>
 int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1) {
   const int blocks = p.gx * p.gy;
+  const bool tn2 = (BM == 256 && BN == 128) || (BM == 128 && BN == 256);       // 128x64 wave tiles, two blocks per CU
+  const int slots = tn2 ? 512 : 256;
   int ks = 1, ts = 0;
   if (ctx->conv_max_split != 1) {
     float best = 1e30f;
     const float tile_w = (float)(BM * BN) / 16384.f;
     for (int s_ : {1, 2, 3, 4, 6, 8, 12, 16}) {
       if (s_ > 1 && ((long)blocks * s_ > 2048 || s_ > max(1, p.nchunk / 4))) continue;
-      const float cost = (float)di_div_up((long)blocks * s_, 256) * (float)di_div_up(p.nchunk, s_) +
+      const float cost = (float)di_div_up((long)blocks * s_, slots) * (float)di_div_up(p.nchunk, s_) +
                          (s_ > 1 ? c0 + c1 * (float)((long)blocks * s_) * tile_w : 0.f);
       if (cost < best * 0.985f) { best = cost; ks = s_; }
     }
-    const int R = blocks % 256;
-    if (blocks > 256 && R > 0 && ctx->conv_max_split == 0 && !getenv("DEEPIM_F16_NO_TAIL")) {
+    const int R = blocks % slots;
+    if (blocks > slots && R > 0 && ctx->conv_max_split == 0 && !getenv("DEEPIM_F16_NO_TAIL")) {
       for (int t_ : {2, 3, 4, 5, 6, 8}) {
         if (t_ > max(1, p.nchunk / 4)) continue;
-        const float cost = (float)(blocks / 256) * (float)p.nchunk + (float)di_div_up(R * t_, 256) * (float)di_div_up(p.nchunk, t_) +
+        const float cost = (float)(blocks / slots) * (float)p.nchunk + (float)di_div_up(R * t_, slots) * (float)di_div_up(p.nchunk, t_) +
                            c0 + c1 * (float)(R * t_) * tile_w;
         if (cost < best * 0.97f) { best = cost; ts = t_; ks = 1; }
       }
@@ -1005,7 +1015,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     if (rc) return rc;
     p.partial = (float*)scratch;
   } else if (ts > 1) {
-    const int R = blocks % 256;
+    const int R = blocks % slots;
     p.n_full = blocks - R;
     p.tail_cps = di_div_up(p.nchunk, ts);
     p.tail_s = di_div_up(p.nchunk, p.tail_cps);
@@ -1021,12 +1031,18 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     attr = true;
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
     fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
-  if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3>), dim3(grid), dim3(256), 122880, ctx->stream, p);
+  if (BM == 128 && tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
+  else if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3>), dim3(grid), dim3(256), 122880, ctx->stream, p);
+  else if (tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
   else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, X3>), dim3(grid), dim3(256), 131072, ctx->stream, p);
   if (p.ksplit > 1) {
     const long total4 = p.npix * p.Cout / 4;
