@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void split16_to_nchw_kernel(float* __restrict_
 //     ds_read_b128), for every tap; the next tile's patch is prefetched into registers while the current one is multiplied;
 //   * wave w owns output rows 2w, 2w+1 (two 32-pixel fragments) x all 64 channels: 8 ds_read_b128 per 12 MFMAs;
 //   * epilogue: accumulator → real units, bias, LeakyReLU, split16 records (NHWC) for conv2.
-constexpr int C1_TAPS = 49, C1_PAIRS = 25, C1_ROWS = 21, C1_RW = 35, C1_PIX = 21 * 69;
+constexpr int C1_TAPS = 49, C1_PAIRS = 25, C1_ROWS = 21, C1_RW = 35;
 constexpr int C1_WH = 50 * 64;                 // h8 entries of w_hi (and of w_lo)
 constexpr int C1_PH = C1_ROWS * 2 * C1_RW;     // h8 entries of a_hi (and of a_lo)
 constexpr int C1_LDS = (2 * C1_WH + 2 * C1_PH) * 16;
@@ -768,46 +768,60 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
   const int lrow = lane >> 5, lcol = lane & 31;
   for (int i = tid; i < 2 * C1_WH; i += 256) smem[i] = p.wp[i];
 
-  // patch pixels of this thread: q = k*256 + tid → (row q / 69, column q % 69)
-  int pr[6], pc[6];
+  // patch quads of this thread: the 21 x 69 patch inside 21 rows x 18 aligned quads of 4 consecutive pixels (72 columns
+  // starting one pixel left of the patch); quad k*256 + tid, k = 0, 1. One dwordx4 per channel per quad: 16 loads per thread instead of 48 dword
+  // loads — with the 16 stores of the previous tile still in flight 48 loads ran into the 63-instruction limit of vmcnt and
+  // the issue of the prefetch stalled until the stores had drained (measured: 5-10 k cycles per tile).
+  constexpr int C1_QUADS = C1_ROWS * 18;
+  int qr[2], qc[2];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int q = k * 256 + tid;
-    pr[k] = q / 69;
-    pc[k] = q - pr[k] * 69;
+  for (int k = 0; k < 2; ++k) {
+    const int q = min(k * 256 + tid, C1_QUADS - 1);
+    qr[k] = q / 18;
+    qc[k] = (q - qr[k] * 18) * 4;
   }
-  float v[6][8];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 v[2][8];
   const long plane = (long)p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((long)p.B * 8 * plane * 4), 0x00020000);
   auto load_patch = [&](int tile) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
-    const int gy0 = 2 * (ty * 8) - 3, gx0 = 2 * (tx * 32) - 3;
-    const float* src = p.in + (long)n * 8 * plane;
+    const int gy0 = 2 * (ty * 8) - 3, gx0 = 2 * (tx * 32) - 4;   // quads start one pixel left of the patch: 16-byte aligned
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int gy = gy0 + pr[k], gx = gx0 + pc[k];
-      const bool ok = (k * 256 + tid) < C1_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      const long o = ok ? (long)gy * p.W + gx : 0;
+    for (int k = 0; k < 2; ++k) {
+      const int gy = gy0 + qr[k], gx = gx0 + qc[k];
+      // W % 4 == 0, so an aligned quad is entirely inside or entirely outside the frame; outside (and the unused second quad
+      // of the upper threads): offset bit 31 → the load returns zeros
+      const bool row_ok = (k * 256 + tid) < C1_QUADS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      // one select per quad, not per load (the compiler turned per-load selects into branches with a vmcnt(0) between the
+      // loads); an invalid quad stays invalid for every channel: 0x80000000 + c·cstep < 2^32
+      const unsigned b0 = row_ok ? (unsigned)((((long)n * 8 * p.H + gy) * p.W + gx) * 4) : 0x80000000u;
+      const unsigned cstep = (unsigned)(plane * 4);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float x = src[o + c * plane];
-        v[k][c] = ok ? x : 0.f;
-      }
+      for (int c = 0; c < 8; ++c)
+        v[k][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(b0 + (unsigned)c * cstep), 0, 0));
     }
   };
   auto store_patch = [&]() {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      if (k * 256 + tid >= C1_PIX) continue;
-      h8 hi, lo;
+    for (int k = 0; k < 2; ++k) {
+      if (k * 256 + tid >= C1_QUADS) continue;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const X3Pair s2 = x3_split(v[k][c], p.in_scale);
-        hi[c] = s2.hi;
-        lo[c] = s2.lo;
+      for (int e = 0; e < 4; ++e) {
+        const int pc = qc[k] + e - 1;             // patch column of this element
+        if (pc < 0 || pc >= 69) continue;
+        h8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float x = e == 0 ? v[k][c].x : e == 1 ? v[k][c].y : e == 2 ? v[k][c].z : v[k][c].w;
+          const X3Pair s2 = x3_split(x, p.in_scale);
+          hi[c] = s2.hi;
+          lo[c] = s2.lo;
+        }
+        const int idx = (qr[k] * 2 + (pc & 1)) * C1_RW + (pc >> 1);
+        a_hi[idx] = hi;
+        a_lo[idx] = lo;
       }
-      const int idx = (pr[k] * 2 + (pc[k] & 1)) * C1_RW + (pc[k] >> 1);
-      a_hi[idx] = hi;
-      a_lo[idx] = lo;
     }
   };
 
@@ -1256,7 +1270,8 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
   p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
   const long nt = (long)p.tiles_x * p.tiles_y * B;
-  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W < (1L << 40), "conv1_x3: too many tiles");
+  DI_REQUIRE((W & 3) == 0, "conv1_x3: W must be a multiple of 4 (aligned quad loads); use deepim_conv2d_forward_split16 otherwise");
+  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W * 4 < 0x7fffffffL, "conv1_x3: input tensor must be < 2 GiB per launch");
   p.ntiles = (int)nt;
   p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale;
   static bool attr = false;

@@ -229,7 +229,7 @@ class deepIM_flownet(object):
                 cin = cout
         if self.x3_conv:     # split-fp16 weights [hi 16 | lo 16] in MFMA octet order, scaled by a power of two into fp16's range
             self.packed_x3, self.x3_wscale = {}, {}
-            if self.cin == 8:    # conv1 on the split-fp16 patch kernel (built for the 8-channel input; otherwise fp32 conv1)
+            if self.cin == 8 and self.W % 4 == 0:    # conv1 on the split-fp16 patch kernel (8-channel input; otherwise fp32 conv1)
                 name = ENCODER[0][0]
                 m = float(np.abs(np.asarray(arg_params[name + "_weight"], np.float32)).max())
                 self.x3_wscale[name] = 2.0 ** int(np.floor(np.log2(1536.0 / m))) if m > 0 else 1.0
