@@ -214,7 +214,9 @@ int deepim_zoom_inverse_factor(deepim_ctx* ctx, const float* zoom_factor, float*
  * bit0 (1) = a zoom-factor computation saw an observed mask/image with no valid pixel — the reference raises ValueError
  *            there (np.min of an empty array, zoom_mask.py:55); the zoom factor is NaN for that sample
  * bit1 (2) = GroupPicker index out of range
- * bit2 (4) = deepim_mask_box_forward / deepim_render_update_forward saw an empty mask (data_pair.py:98 raises) */
+ * bit2 (4) = deepim_mask_box_forward / deepim_render_update_forward saw an empty mask (data_pair.py:98 raises)
+ * bit3 (8) = split-fp16 conv path: a value left fp16's range after scaling (|v·scale| > 60000 or NaN) and was clamped — the
+ *            results of that call are not fp32-grade; lower the activation scale or use the fp32 path */
 int deepim_zoom_status(deepim_ctx* ctx, int* status);
 
 /* ------------------------------------------ N-group: matching network ops -- */

@@ -11,6 +11,7 @@ constexpr int DI_MAX_BOX_SAMPLES = 4096;
 // bits of the sticky status word (deepim_zoom_status)
 constexpr int DI_STATUS_ZOOM_EMPTY = 1;       // observed mask/image empty in a zoom-factor computation (zoom_mask.py:55 raises)
 constexpr int DI_STATUS_GROUP_RANGE = 2;      // GroupPicker index out of range
+constexpr int DI_STATUS_X3_SATURATED = 8;     // split-fp16 conv: a value left fp16's range after scaling and was clamped (results invalid)
 constexpr int DI_STATUS_MASK_BOX_EMPTY = 4;   // mask_box / fused re-render: empty mask (data_pair.py:98 np.min raises)
 
 struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry

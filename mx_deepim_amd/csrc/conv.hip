@@ -92,6 +92,7 @@ struct ConvParams {
   // channel-blocked activations ("NC8": [n][C/8][h][w][8]) between the encoder layers
   int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW, 1 = NC8; output only: 2 = split16 fp16 pairs)
   float out_scale;          // split16 output: stored value = result · out_scale
+  int* status;              // context status word (split16 output: saturation flag)
   const float* wd8;         // weights for NC8 inputs [Cout/32][group = (c8,ky,kx)][lane][4]
   const int2* tab8;         // per group: {byte offset (c8*H*W + ky*W + kx)*32, bit ky*8+kx}
 };
@@ -399,6 +400,7 @@ __device__ __forceinline__ void store_tile_split16(f32x16 (&acc)[TM][TN], const 
                                                    int lcol) {
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   _Float16* outh = reinterpret_cast<_Float16*>(p.out);
+  float amax = 0.f;   // largest scaled magnitude: a clamp is reported once per thread (bit DI_STATUS_X3_SATURATED)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long op = pix0 + j * 32 + lcol;
@@ -414,7 +416,9 @@ __device__ __forceinline__ void store_tile_split16(f32x16 (&acc)[TM][TN], const 
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][4 * g + r] + (p.bias ? p.bias[c + r] : 0.f);
           v = v > 0.f ? v : v * p.slope;
-          v = fminf(fmaxf(v * p.out_scale, -60000.f), 60000.f);
+          v *= p.out_scale;
+          amax = fmaxf(amax, fabsf(v));
+          v = fminf(fmaxf(v, -60000.f), 60000.f);
           const _Float16 h = (_Float16)v;
           vh[r] = h;
           vl[r] = (_Float16)(v - (float)h);
@@ -425,6 +429,7 @@ __device__ __forceinline__ void store_tile_split16(f32x16 (&acc)[TM][TN], const 
       }
     }
   }
+  if (amax > 60000.f) atomicOr(p.status, DI_STATUS_X3_SATURATED);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1437,7 +1442,7 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
-  p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8; p.out_scale = out_scale; p.wd8 = nullptr; p.tab8 = nullptr;
+  p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8; p.out_scale = out_scale; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
   if (out_nc8 == 2) DI_REQUIRE(!in_nc8, "conv2d: split16 output is built for the NCHW-input LDS-free kernel (conv1)");
   if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
   if (in_nc8) {

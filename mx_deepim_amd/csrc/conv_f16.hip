@@ -64,6 +64,7 @@ struct ConvF16Params {
   // round are cut into tail_s K slices of tail_cps chunks → tile-local fp32 partials [slice][R][BN pixels][BM channels]
   int n_full, tail_s, tail_cps;
   float* tail_partial;
+  int* status;                   // context status word (X3: saturation flag)
   float acc_scale, out_scale;    // X3 mode: accumulator → real units (2^-(s_act+s_w)), real units → stored activations (2^s_act)
 };
 
@@ -78,6 +79,15 @@ __device__ __forceinline__ X3Pair x3_split(float x, float scale) {
   v = fminf(fmaxf(v, -60000.f), 60000.f);     // saturate instead of inf (fp16 max 65504)
   const _Float16 h = (_Float16)v;
   return {h, (_Float16)(v - (float)h)};
+}
+// the same, tracking the largest scaled magnitude in `amax` (one v_max per value): the caller reports a clamp once per thread
+// through bit DI_STATUS_X3_SATURATED of the context's status word — saturation is never silent
+__device__ __forceinline__ X3Pair x3_split(float x, float scale, float& amax) {
+  amax = fmaxf(amax, fabsf(x * scale));
+  return x3_split(x, scale);
+}
+__device__ __forceinline__ void x3_report(float amax, int* status) {
+  if (amax > 60000.f) atomicOr(status, DI_STATUS_X3_SATURATED);
 }
 
 // validity of the (ky,kx) taps of a pixel as a 64-bit word (bit ky*8+kx), kh,kw <= 7: rows/columns hi0+k, wi0+k inside the frame
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(Conv
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DMA
 
+  float amax = 0.f;
   if (tail_slot >= 0) {   // raw fp32 partial sums of a tail slice, tile-local [pixel][channel]
     float* tp = p.tail_partial + (long)tail_slot * (BM * BN);
 #pragma unroll
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(Conv
           for (int r = 0; r < 4; ++r) {
             float x = acc[i][j][4 * g + r] * p.acc_scale + (p.bias ? p.bias[co0 + r] : 0.f);
             x = x > 0.f ? x : x * p.slope;
-            { const X3Pair s2 = x3_split(x, p.out_scale); vh[r] = s2.hi; vl[r] = s2.lo; }
+            { const X3Pair s2 = x3_split(x, p.out_scale, amax); vh[r] = s2.hi; vl[r] = s2.lo; }
           }
           _Float16* rec = p.out + op * (2 * p.Cout) + (co0 >> 4) * 32 + (co0 & 15);
           *reinterpret_cast<h4*>(rec) = vh;
@@ -508,12 +519,13 @@ __global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(Conv
         }
       }
   }
+  if (X3) x3_report(amax, p.status);
 }
 
 // X3 split-K second pass: Σ_s partial (fixed order) → real units → bias → LeakyReLU → split16 record
 __global__ __launch_bounds__(256) void splitk_x3_reduce_kernel(_Float16* __restrict__ out, const float* __restrict__ partial,
                                                                const float* __restrict__ bias, long total4, int S, int Cout,
-                                                               float slope, float acc_scale, float out_scale) {
+                                                               float slope, float acc_scale, float out_scale, int* status) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const float4* p4 = reinterpret_cast<const float4*>(partial);
@@ -528,12 +540,14 @@ __global__ __launch_bounds__(256) void splitk_x3_reduce_kernel(_Float16* __restr
   const int c0 = (int)(e - pix * Cout);
   float r[4] = {v.x, v.y, v.z, v.w};
   h4 vh, vl;
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float x = r[k] * acc_scale + (bias ? bias[c0 + k] : 0.f);
     x = x > 0.f ? x : x * slope;
-    { const X3Pair s2 = x3_split(x, out_scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+    { const X3Pair s2 = x3_split(x, out_scale, amax); vh[k] = s2.hi; vl[k] = s2.lo; }
   }
+  x3_report(amax, status);
   _Float16* rec = out + pix * (2 * Cout) + (c0 >> 4) * 32 + (c0 & 15);
   *reinterpret_cast<h4*>(rec) = vh;
   *reinterpret_cast<h4*>(rec + 16) = vl;
@@ -561,17 +575,19 @@ __global__ __launch_bounds__(256) void tail_f16_reduce_kernel(ConvF16Params p, i
   }
   float r[4] = {v.x, v.y, v.z, v.w};
   h4 vh, vl;
+  float amax = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float x = (X3 ? r[k] * p.acc_scale : r[k]) + (p.bias ? p.bias[co0 + k] : 0.f);
     x = x > 0.f ? x : x * p.slope;
-    if (X3) { const X3Pair s2 = x3_split(x, p.out_scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+    if (X3) { const X3Pair s2 = x3_split(x, p.out_scale, amax); vh[k] = s2.hi; vl[k] = s2.lo; }
     else vh[k] = (_Float16)x;
   }
   if (X3) {
     _Float16* rec = p.out + op * (2 * p.Cout) + (co0 >> 4) * 32 + (co0 & 15);
     *reinterpret_cast<h4*>(rec) = vh;
     *reinterpret_cast<h4*>(rec + 16) = vl;
+    x3_report(amax, p.status);
   } else {
     *reinterpret_cast<h4*>(p.out + op * p.Cout + co0) = vh;
   }
@@ -704,7 +720,7 @@ __global__ void pack_x3_kernel(_Float16* __restrict__ packed, const float* __res
 
 // NCHW fp32 → split16 NHWC; one thread per (pixel, 4 channels): two 8-byte stores
 __global__ __launch_bounds__(256) void nchw_to_split16_kernel(_Float16* __restrict__ out, const float* __restrict__ in, int C,
-                                                              long hw, float scale, long total) {
+                                                              long hw, float scale, long total, int* status) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int q4 = C >> 2;
@@ -712,12 +728,14 @@ __global__ __launch_bounds__(256) void nchw_to_split16_kernel(_Float16* __restri
   const long pix = i / q4;
   const long n = pix / hw, r = pix - n * hw;
   h4 vh, vl;
+  float amax = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { const X3Pair s2 = x3_split(in[(n * C + cq * 4 + k) * hw + r], scale); vh[k] = s2.hi; vl[k] = s2.lo; }
+  for (int k = 0; k < 4; ++k) { const X3Pair s2 = x3_split(in[(n * C + cq * 4 + k) * hw + r], scale, amax); vh[k] = s2.hi; vl[k] = s2.lo; }
   const int c0 = cq * 4;
   _Float16* rec = out + pix * (2 * C) + (c0 >> 4) * 32 + (c0 & 15);
   *reinterpret_cast<h4*>(rec) = vh;
   *reinterpret_cast<h4*>(rec + 16) = vl;
+  x3_report(amax, status);
 }
 
 // split16 NHWC → NCHW fp32 (hi + lo, back to real units); lanes run along pixels of one channel
@@ -755,6 +773,7 @@ struct Conv1Params {
   _Float16* out;        // split16 NHWC (B,Ho,Wo,128 halves)
   int B, H, W, Ho, Wo, tiles_x, tiles_y, ntiles;
   float slope, in_scale, acc_scale, out_scale;
+  int* status;
 };
 
 __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
@@ -782,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
   }
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 v[2][8];
+  float amax = 0.f;
   const long plane = (long)p.H * p.W;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((long)p.B * 8 * plane * 4), 0x00020000);
   auto load_patch = [&](int tile) {
@@ -814,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const float x = e == 0 ? v[k][c].x : e == 1 ? v[k][c].y : e == 2 ? v[k][c].z : v[k][c].w;
-          const X3Pair s2 = x3_split(x, p.in_scale);
+          const X3Pair s2 = x3_split(x, p.in_scale, amax);
           hi[c] = s2.hi;
           lo[c] = s2.lo;
         }
@@ -911,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
           for (int r = 0; r < 4; ++r) {
             float x = acc[i][j][4 * g + r] * p.acc_scale + bias_r[i][g][r];
             x = x > 0.f ? x : x * p.slope;
-            const X3Pair s2 = x3_split(x, p.out_scale);
+            const X3Pair s2 = x3_split(x, p.out_scale, amax);
             vh[r] = s2.hi;
             vl[r] = s2.lo;
           }
@@ -931,6 +951,7 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
       }
     }
   }
+  x3_report(amax, p.status);
 }
 
 // conv1 weights (64,8,7,7) fp32 → [hi|lo][50 taps][64 co][8 halves] of w·w_scale (tap 49 zero)
@@ -1062,7 +1083,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     const long total4 = p.npix * p.Cout / 4;
     if (X3)
       hipLaunchKernelGGL(splitk_x3_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, p.bias,
-                         total4, p.ksplit, p.Cout, p.slope, p.acc_scale, p.out_scale);
+                         total4, p.ksplit, p.Cout, p.slope, p.acc_scale, p.out_scale, p.status);
     else
       hipLaunchKernelGGL(splitk_f16_reduce_kernel, dim3(di_div_up(total4, 256)), dim3(256), 0, ctx->stream, p.out, p.partial, p.bias,
                          total4, p.ksplit, p.Cout, p.slope);
@@ -1111,7 +1132,7 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   const bool ut = ((Cin_pad >> 3) & 7) == 0;
   const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !getenv("DEEPIM_F16_NO_DMA"));
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
-  p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr; p.acc_scale = p.out_scale = 1.f;
+  p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr; p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
   if (ut && BM >= 128 && !getenv("DEEPIM_F16_NO_DMA")) return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f);
   const int blocks = p.gx * p.gy;
   // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when
@@ -1187,7 +1208,7 @@ extern "C" int deepim_nchw_f32_to_split16(deepim_ctx* ctx, void* out_split16, co
   const long total = (long)B * H * W * (C / 4);
   if (total == 0) return 0;
   hipLaunchKernelGGL(nchw_to_split16_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, (_Float16*)out_split16, in,
-                     C, (long)H * W, scale, total);
+                     C, (long)H * W, scale, total, ctx->status);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -1236,7 +1257,7 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   p.Wo = (W + 2 * pad - kw) / stride + 1;
   p.stride = stride; p.pad = pad; p.slope = slope;
   p.stride_kw = (kh << 16) | kw;
-  p.acc_scale = acc_scale; p.out_scale = out_scale;
+  p.acc_scale = acc_scale; p.out_scale = out_scale; p.status = ctx->status;
   p.nchunk = f16_chunks(Cv, kh, kw);
   p.npix = (long)B * p.Ho * p.Wo;
   p.pad_bytes = (pad * W + pad) * Cv * 2;
@@ -1273,7 +1294,7 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   DI_REQUIRE((W & 3) == 0, "conv1_x3: W must be a multiple of 4 (aligned quad loads); use deepim_conv2d_forward_split16 otherwise");
   DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W * 4 < 0x7fffffffL, "conv1_x3: input tensor must be < 2 GiB per launch");
   p.ntiles = (int)nt;
-  p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale;
+  p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale; p.status = ctx->status;
   static bool attr = false;
   if (!attr) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));

@@ -62,6 +62,34 @@ def test_split16_round_trip(ctx):
     back = ctx.empty(x.shape)
     lib.deepim_split16_to_nchw_f32(ctx.handle, back, xs, 2, 32, 5, 7, cf(1.0 / 16.0))
     np.testing.assert_allclose(back.asnumpy(), np.clip(x, -3750, 3750), rtol=2.0 ** -20, atol=2.0 ** -27)
+    # the two out-of-range values were clamped, and the status word says so (bit 3); reading clears it
+    st = ctypes.c_int(0)
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value & 8
+    x[0, 1, 0, 0] = x[0, 2, 0, 0] = 1.0
+    lib.deepim_nchw_f32_to_split16(ctx.handle, xs, ctx.array(x), 2, 32, 5, 7, cf(16.0))
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value == 0
+
+
+def test_conv_x3_flags_saturation_and_is_deterministic(ctx):
+    """An output beyond fp16's range after scaling sets status bit 3 (the clamp is not silent); two runs are bit-identical."""
+    rng = np.random.default_rng(9)
+    B, cin, H, W, cout = 1, 32, 8, 8, 128
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / 17).astype(np.float32)
+    b = np.zeros(cout, np.float32)
+    st = ctypes.c_int(0)
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    a = _conv_x3(ctx, x, w, b, 1, 1, 1.0)
+    a2 = _conv_x3(ctx, x, w, b, 1, 1, 1.0)
+    np.testing.assert_array_equal(a, a2)
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value == 0
+    b[3] = 1e6                                              # 1e6 · 16 > 60000: clamped
+    _conv_x3(ctx, x, w, b, 1, 1, 1.0)
+    lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    assert st.value & 8
 
 
 X3_CASES = [(1, 64, 60, 80, 128, 5, 2, 2), (2, 128, 30, 40, 256, 5, 2, 2), (2, 256, 15, 20, 256, 3, 1, 1), (1, 256, 30, 40, 512, 3, 2, 1),
