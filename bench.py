@@ -277,8 +277,8 @@ def main():
         zoom_bytes = 2 * (net.cin * 480 * 640 * 4) * B   # read + write every zoomed channel once
         traffic, traffic_src = None, None                # HBM bytes per conv launch group from a recorded PMC pass
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not args.fp16 and not args.x3:
-            tj = json.load(open(tpath)).get("B%d" % B)
+        if os.path.exists(tpath) and not args.fp16:
+            tj = json.load(open(tpath)).get(("x3_B%d" if args.x3 else "B%d") % B)
             if tj:
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         out = {

@@ -24,7 +24,9 @@ def short(name):
 
 
 def is_conv(n):
-    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "splitk_reduce", "tail_reduce"))
+    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "splitk_reduce", "tail_reduce",
+                         "conv_f16", "conv1_x3", "splitk_x3", "splitk_f16", "tail_f16", "split16_to_nchw", "nchw_to_split16",
+                         "_ZN12_GLOBAL__N_123splitk_x3", "_ZN12_GLOBAL__N_122split16_to"))
 
 
 def cmd_stats(a):
@@ -98,8 +100,8 @@ def cmd_traffic(a):
     open(a.md, "w").write("\n".join(lines) + "\n")
     import os
     allj = json.load(open(a.json)) if os.path.exists(a.json) else {}
-    allj = {k: v for k, v in allj.items() if k.startswith("B")}          # one entry per per-GPU batch size
-    allj["B%d" % a.batch] = {"conv_launch_group_bytes_corrected": (2 * fr + wr) * 1e6, "conv_launch_group_bytes_raw": (fr + wr) * 1e6,
+    allj = {k: v for k, v in allj.items() if k.startswith(("B", "x3_"))}          # one entry per mode / per-GPU batch size
+    allj[a.key or "B%d" % a.batch] = {"conv_launch_group_bytes_corrected": (2 * fr + wr) * 1e6, "conv_launch_group_bytes_raw": (fr + wr) * 1e6,
                              "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=%d, FETCH doubled per MI355X_MICROARCH.md)" % (a.md, a.batch)}
     json.dump(allj, open(a.json, "w"), indent=1)
     print("\n".join(lines))
@@ -111,6 +113,6 @@ s = sub.add_parser("stats"); s.add_argument("trace"); s.add_argument("stats"); s
 s.add_argument("--iters", type=int, default=20); s.add_argument("--batch", type=int, default=16)
 t = sub.add_parser("traffic"); t.add_argument("fetch"); t.add_argument("write"); t.add_argument("--iters", type=int, default=8)
 t.add_argument("--batch", type=int, default=16); t.add_argument("--md", required=True); t.add_argument("--json", required=True)
-t.add_argument("--note", default="")
+t.add_argument("--note", default=""); t.add_argument("--key", default="", help="JSON key instead of B<batch> (e.g. x3_B32)")
 a = ap.parse_args()
 {"stats": cmd_stats, "traffic": cmd_traffic}[a.cmd](a)
