@@ -338,7 +338,8 @@ def other_configs():
     import subprocess
     runs = {"configs[1]_ape_batch16": ["--batch", "16"], "configs[2]_per_gpu_share_batch4": ["--batch", "4"],
             "configs[3]_decoder_mask_flow_heads_batch32": ["--heads"], "configs[4]_fp16_conv_per_gpu_share_batch8": ["--fp16", "--batch", "8"],
-            "fp16_conv_batch32": ["--fp16"], "split_fp16_x3_conv_batch32": ["--x3"], "split_fp16_x3_conv_batch4": ["--x3", "--batch", "4"]}
+            "fp16_conv_batch32": ["--fp16"], "split_fp16_x3_conv_batch32": ["--x3"], "split_fp16_x3_conv_batch4": ["--x3", "--batch", "4"],
+            "configs[3]_heads_split_fp16_x3_batch32": ["--x3", "--heads"]}
     res = {}
     for name, extra in runs.items():
         try:

@@ -276,6 +276,10 @@ int deepim_conv1_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /
 int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const float* in /*B,8,H,W*/, const void* packed_w,
                             const float* bias, int B, int H, int W, float slope, float in_scale, float acc_scale,
                             float out_scale);
+/* the same kernel with plain fp16 operands = conv1 of the fp16 path (config 5): NCHW fp32 in → NHWC fp16 (B,Ho,Wo,64) out;
+ * packed_w = the first half (hi parts) of deepim_conv1_x3_pack_weights(..., w_scale = 1) */
+int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in /*B,8,H,W*/, const void* packed_w,
+                             const float* bias, int B, int H, int W, float slope);
 int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
                              int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                              float acc_scale, float out_scale);

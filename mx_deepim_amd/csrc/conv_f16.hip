@@ -765,6 +765,7 @@ constexpr int C1_TAPS = 49, C1_PAIRS = 25, C1_ROWS = 21, C1_RW = 35;
 constexpr int C1_WH = 50 * 64;                 // h8 entries of w_hi (and of w_lo)
 constexpr int C1_PH = C1_ROWS * 2 * C1_RW;     // h8 entries of a_hi (and of a_lo)
 constexpr int C1_LDS = (2 * C1_WH + 2 * C1_PH) * 16;
+constexpr int C1_LDS_F16 = (C1_WH + C1_PH) * 16;   // plain fp16 variant: hi parts only (73.7 KB → two blocks per CU)
 
 struct Conv1Params {
   const float* in;      // (B,8,H,W) fp32
@@ -776,16 +777,19 @@ struct Conv1Params {
   int* status;
 };
 
-__global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
+// X3 = false: the same kernel with plain fp16 operands (BASELINE config 5): one MFMA per tile pair and k-step, NHWC fp16
+// output (128 B per pixel), half the LDS — two blocks share a CU and cover each other's load / epilogue phases.
+template <bool X3>
+__global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p) {
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   h8* w_hi = smem;
-  h8* w_lo = smem + C1_WH;
-  h8* a_hi = smem + 2 * C1_WH;
-  h8* a_lo = a_hi + C1_PH;
+  h8* w_lo = smem + C1_WH;                         // X3 only
+  h8* a_hi = smem + (X3 ? 2 : 1) * C1_WH;
+  h8* a_lo = a_hi + C1_PH;                         // X3 only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 5, lcol = lane & 31;
-  for (int i = tid; i < 2 * C1_WH; i += 256) smem[i] = p.wp[i];
+  for (int i = tid; i < (X3 ? 2 : 1) * C1_WH; i += 256) smem[i] = p.wp[i];
 
   // patch quads of this thread: the 21 x 69 patch inside 21 rows x 18 aligned quads of 4 consecutive pixels (72 columns
   // starting one pixel left of the patch); quad k*256 + tid, k = 0, 1. One dwordx4 per channel per quad: 16 loads per thread instead of 48 dword
@@ -834,13 +838,17 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const float x = e == 0 ? v[k][c].x : e == 1 ? v[k][c].y : e == 2 ? v[k][c].z : v[k][c].w;
-          const X3Pair s2 = x3_split(x, p.in_scale, amax);
-          hi[c] = s2.hi;
-          lo[c] = s2.lo;
+          if constexpr (X3) {
+            const X3Pair s2 = x3_split(x, p.in_scale, amax);
+            hi[c] = s2.hi;
+            lo[c] = s2.lo;
+          } else {
+            hi[c] = (_Float16)x;
+          }
         }
         const int idx = (qr[k] * 2 + (pc & 1)) * C1_RW + (pc >> 1);
         a_hi[idx] = hi;
-        a_lo[idx] = lo;
+        if constexpr (X3) a_lo[idx] = lo;
       }
     }
   };
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
   const int b_base0 = (2 * (2 * wave) * 2) * C1_RW + lcol, b_base1 = (2 * (2 * wave + 1) * 2) * C1_RW + lcol;
   // epilogue staging (the patch region, once every wave is done with it): this wave's 32 pixels of one output row as
   // records of 256 B at a 272-byte pitch, so the lane-per-pixel writes spread over the banks
-  constexpr int C1_PITCH = 272;
+  constexpr int C1_REC = X3 ? 256 : 128, C1_PITCH = C1_REC + 16;
   char* stage = reinterpret_cast<char*>(a_hi) + wave * (32 * C1_PITCH);
   h8 fr[2][8];   // [set][ah0 ah1 al0 al1 bh0 bh1 bl0 bl1]
   auto read_frags = [&](int set, int pp) {
@@ -874,10 +882,12 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
     fr[set][1] = w_hi[t0 * 64 + a_base + 32];
     fr[set][4] = a_hi[b_base0 + bo];
     fr[set][5] = a_hi[b_base1 + bo];
-    fr[set][6] = a_lo[b_base0 + bo];
-    fr[set][7] = a_lo[b_base1 + bo];
-    fr[set][2] = w_lo[t0 * 64 + a_base];
-    fr[set][3] = w_lo[t0 * 64 + a_base + 32];
+    if constexpr (X3) {
+      fr[set][6] = a_lo[b_base0 + bo];
+      fr[set][7] = a_lo[b_base1 + bo];
+      fr[set][2] = w_lo[t0 * 64 + a_base];
+      fr[set][3] = w_lo[t0 * 64 + a_base + 32];
+    }
   };
   for (; tile < p.ntiles; tile += gridDim.x) {
     __syncthreads();                       // every wave is done with the staging area (and the weights are in place)
@@ -903,21 +913,23 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+        if constexpr (X3) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][6 + j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][6 + j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][2 + i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][2 + i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();                       // all waves are past their last patch read: the region becomes the staging area
     // epilogue: real units, bias, LeakyReLU, split → LDS record → 16 B per lane, 1 KB (4 pixel records) per wave store
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + (long)n * p.Ho * p.Wo * 128), 0, (int)((long)p.Ho * p.Wo * 256), 0x00020000);
+        (void*)(p.out + (long)n * p.Ho * p.Wo * (C1_REC / 2)), 0, (int)((long)p.Ho * p.Wo * C1_REC), 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int oy = ty * 8 + 2 * wave + j;
@@ -929,29 +941,38 @@ __global__ __launch_bounds__(256, 1) void conv1_x3_kernel(Conv1Params p) {
           h4 vh, vl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float x = acc[i][j][4 * g + r] * p.acc_scale + bias_r[i][g][r];
+            float x = (X3 ? acc[i][j][4 * g + r] * p.acc_scale : acc[i][j][4 * g + r]) + bias_r[i][g][r];
             x = x > 0.f ? x : x * p.slope;
-            const X3Pair s2 = x3_split(x, p.out_scale, amax);
-            vh[r] = s2.hi;
-            vl[r] = s2.lo;
+            if constexpr (X3) {
+              const X3Pair s2 = x3_split(x, p.out_scale, amax);
+              vh[r] = s2.hi;
+              vl[r] = s2.lo;
+            } else {
+              vh[r] = (_Float16)x;
+            }
           }
-          char* rec = stage + lcol * C1_PITCH + (co0 >> 4) * 64 + (co0 & 15) * 2;
-          *reinterpret_cast<h4*>(rec) = vh;
-          *reinterpret_cast<h4*>(rec + 32) = vl;
+          if constexpr (X3) {
+            char* rec = stage + lcol * C1_PITCH + (co0 >> 4) * 64 + (co0 & 15) * 2;
+            *reinterpret_cast<h4*>(rec) = vh;
+            *reinterpret_cast<h4*>(rec + 32) = vl;
+          } else {
+            *reinterpret_cast<h4*>(stage + lcol * C1_PITCH + co0 * 2) = vh;
+          }
         }
       // the wave reads back its own writes (LDS operations of a wave complete in order)
+      constexpr int CPP = C1_REC / 16, PPI = 64 / CPP;    // 16-byte chunks per pixel record, pixels per wave store
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int px = k * 4 + (lane >> 4), chunk = lane & 15;
+      for (int k = 0; k < 32 / PPI; ++k) {
+        const int px = k * PPI + lane / CPP, chunk = lane % CPP;
         const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * C1_PITCH + chunk * 16);
         const int ox = tx * 32 + px;
         const bool ok = oy < p.Ho && ox < p.Wo;
-        const unsigned off = ok ? (unsigned)((oy * p.Wo + ox) * 256 + chunk * 16) : 0x80000000u;
+        const unsigned off = ok ? (unsigned)((oy * p.Wo + ox) * C1_REC + chunk * 16) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(d, rs_out, (int)off, 0, 0);
       }
     }
   }
-  x3_report(amax, p.status);
+  if constexpr (X3) x3_report(amax, p.status);
 }
 
 // conv1 weights (64,8,7,7) fp32 → [hi|lo][50 taps][64 co][8 halves] of w·w_scale (tap 49 zero)
@@ -1297,11 +1318,38 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale; p.status = ctx->status;
   static bool attr = false;
   if (!attr) {
-    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
     attr = true;
   }
   const int grid = (int)min(256L, nt);   // persistent: one block per CU
-  hipLaunchKernelGGL(conv1_x3_kernel, dim3(grid), dim3(256), C1_LDS, ctx->stream, p);
+  hipLaunchKernelGGL(conv1_x3_kernel<true>, dim3(grid), dim3(256), C1_LDS, ctx->stream, p);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// conv1 of the plain fp16 path on the same patch kernel: NCHW fp32 net input → NHWC fp16 (B,Ho,Wo,64); the packed weights are
+// the hi half of deepim_conv1_x3_pack_weights(..., w_scale = 1)
+extern "C" int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w,
+                                        const float* bias, int B, int H, int W, float slope) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  Conv1Params p;
+  p.in = in; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_nhwc_f16;
+  p.B = B; p.H = H; p.W = W;
+  p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
+  p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
+  const long nt = (long)p.tiles_x * p.tiles_y * B;
+  DI_REQUIRE((W & 3) == 0, "conv1_f16: W must be a multiple of 4 (aligned quad loads)");
+  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W * 4 < 0x7fffffffL, "conv1_f16: input tensor must be < 2 GiB per launch");
+  p.ntiles = (int)nt;
+  p.slope = slope; p.in_scale = p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
+  static bool attr = false;
+  if (!attr) {
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_F16));
+    attr = true;
+  }
+  const int grid = (int)min(512L, nt);   // persistent: two blocks per CU
+  hipLaunchKernelGGL(conv1_x3_kernel<false>, dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);
   DI_LAUNCH_CHECK();
   return 0;
 }

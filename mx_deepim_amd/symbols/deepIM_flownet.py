@@ -227,6 +227,10 @@ class deepIM_flownet(object):
                 lib.deepim_conv_f16_pack_weights(h, pk, self.params[name + "_weight"], cout, cin, cpad, k, k)
                 self.packed_f16[name] = pk
                 cin = cout
+            if self.cin == 8 and self.W % 4 == 0:   # conv1 on the patch kernel, straight from the NCHW fp32 net input
+                pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
+                lib.deepim_conv1_x3_pack_weights(h, pk, self.params[ENCODER[0][0] + "_weight"], ctypes.c_float(1.0))
+                self.packed_f16["conv1_patch"] = pk
         if self.x3_conv:     # split-fp16 weights [hi 16 | lo 16] in MFMA octet order, scaled by a power of two into fp16's range
             self.packed_x3, self.x3_wscale = {}, {}
             if self.cin == 8 and self.W % 4 == 0:    # conv1 on the split-fp16 patch kernel (8-channel input; otherwise fp32 conv1)
@@ -304,9 +308,16 @@ class deepIM_flownet(object):
         """Same 10 layers on the fp16 matrix cores: NCHW fp32 net input → NHWC fp16 → convs → conv6_1 back to
         NCHW fp32 for the (fp32) FC head."""
         A, h, B = self.act, self.ctx.handle, self.B
-        lib.deepim_nchw_f32_to_nhwc_f16(h, A["net_input_h"], A["net_input"], B, self.cin, self.H, self.W, self.cin_pad)
-        src = A["net_input_h"]
-        for name, cin, hh, ww, cout, k, s, p in self.enc_geom:
+        geom = self.enc_geom
+        if "conv1_patch" in self.packed_f16:
+            name = geom[0][0]
+            lib.deepim_conv1_f16_forward(h, A[name + "_h"], A["net_input"], self.packed_f16["conv1_patch"],
+                                         self.params[name + "_bias"], B, self.H, self.W, ctypes.c_float(SLOPE))
+            src, geom = A[name + "_h"], geom[1:]
+        else:
+            lib.deepim_nchw_f32_to_nhwc_f16(h, A["net_input_h"], A["net_input"], B, self.cin, self.H, self.W, self.cin_pad)
+            src = A["net_input_h"]
+        for name, cin, hh, ww, cout, k, s, p in geom:
             cpad = (cin + 7) // 8 * 8
             lib.deepim_conv2d_f16_forward(h, A[name + "_h"], src, self.packed_f16[name], self.params[name + "_bias"], B,
                                           cpad, hh, ww, cout, k, k, s, p, ctypes.c_float(SLOPE))

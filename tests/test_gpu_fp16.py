@@ -88,3 +88,24 @@ def test_fp16_iteration_vs_emulation_and_fp32(ctx, small_batch):
     dev = np.abs(pose - ref32["pose_est"]).max() / np.abs(ref32["pose_est"]).max()
     assert dev < 2e-2, dev
     print("fp16 vs fp32 pose deviation: %.3g" % dev)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 50, 68), (1, 480, 640)])
+def test_conv1_f16_patch_kernel(ctx, shape):
+    """conv1 of the fp16 path on the persistent patch kernel (NCHW fp32 in → NHWC fp16 out) vs the fp16 emulation."""
+    B, H, W = shape
+    rng = np.random.default_rng(H)
+    x = rng.uniform(-1, 1, (B, 8, H, W)).astype(np.float32)
+    w = (rng.standard_normal((64, 8, 7, 7)) / np.sqrt(8 * 49)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    ref = opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w), b, 2, 3, 0.1))
+    ho, wo = ref.shape[2:]
+    pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
+    lib.deepim_conv1_x3_pack_weights(ctx.handle, pk, ctx.array(w), cf(1.0))
+    oh = ctx.empty((B, ho, wo, 64), dtype=np.float16)
+    lib.deepim_conv1_f16_forward(ctx.handle, oh, ctx.array(x), pk, ctx.array(b), B, H, W, cf(0.1))
+    out = ctx.empty((B, 64, ho, wo))
+    lib.deepim_nhwc_f16_to_nchw_f32(ctx.handle, out, oh, B, 64, ho, wo)
+    got = out.asnumpy()
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
+    assert np.mean(got != ref) < 0.02

@@ -24,3 +24,16 @@ ms = t.elapsed_ms() / 5
 fl = 2.0 * 64 * 8 * 49 * 240 * 320 * B
 print("conv1 x3 patch kernel B=%d: %.3f ms  %.0f TFLOP/s fp32-equivalent (%.0f executed), in+out %.0f GB/s"
       % (B, ms, fl / ms / 1e9, 3 * fl * 50 / 49 / ms / 1e9, (B * 8 * 480 * 640 * 4 + B * 240 * 320 * 256) / ms / 1e6))
+# plain fp16 variant (config 5): NHWC fp16 output
+lib.deepim_conv1_x3_pack_weights(ctx.handle, pk, w, c(1.0))
+outh = ctx.empty((B, 240, 320, 64), dtype=np.float16)
+argsh = (ctx.handle, outh, x, pk, bias, B, 480, 640, c(0.1))
+for _ in range(2):
+    lib.deepim_conv1_f16_forward(*argsh)
+t = ctx.timer(); t.start()
+for _ in range(5):
+    lib.deepim_conv1_f16_forward(*argsh)
+t.stop()
+ms = t.elapsed_ms() / 5
+print("conv1 f16 patch kernel B=%d: %.3f ms  %.0f TFLOP/s, in+out %.0f GB/s"
+      % (B, ms, fl / ms / 1e9, (B * 8 * 480 * 640 * 4 + B * 240 * 320 * 128) / ms / 1e6))
