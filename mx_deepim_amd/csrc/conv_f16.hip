@@ -41,7 +41,7 @@ inline int f16_bm(int Cout) { return Cout <= 64 ? 64 : ((Cout & 255) == 0 ? 256 
 inline int f16_bn(int Cout, bool dma) {
   if (!dma) return 256;
   const bool tn4 = getenv("DEEPIM_F16_TN4") != nullptr;
-  if (f16_bm(Cout) == 256) return tn4 ? 256 : 128;
+  if (f16_bm(Cout) == 256) return (tn4 || getenv("DEEPIM_F16_W8")) ? 256 : 128;
   return f16_bm(Cout) == 128 ? (tn4 ? 512 : 256) : 256;
 }
 
@@ -288,13 +288,15 @@ __global__ __launch_bounds__(256, 1) void conv_f16_kernel(ConvF16Params p) {
 // WGM x WGN waves of 128x128 (4x4 MFMA tiles) each: <2,2> = 256x256 block, 4 ring stages of 32 KB; <1,4> = 128x512 block for
 // Cout == 128 (conv2), 3 stages of 40 KB.
 template <int WGM, int WGN, int NSTAGE, bool X3 = false, int TN = 4>
-__global__ __launch_bounds__(256, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(ConvF16Params p) {
+__global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_kernel(ConvF16Params p) {
   // TN = 2: 128x64 wave tiles (128 accumulator registers) so that two blocks share a CU, i.e. two waves per SIMD — one wave
   // alone issues MFMAs at 71 % of the pipe's rate (tools/mfma_f16_probe.hip) and nothing covers its waits
-  constexpr int BM = WGM * 128, BN = WGN * TN * 32, TM = 4;
-  constexpr int NPA = BM / 64, NPB = BN / 64, NP = NPA + NPB;   // 1 KB DMA pieces per wave per chunk: weights, activations
+  // WGM * WGN = 8 (512 threads, TN = 2): eight 128x64 wave tiles share ONE 256x256 LDS image — two waves per SIMD as with two
+  // 4-wave blocks, but a third fewer DMA bytes per MFMA and a 4-stage ring
+  constexpr int BM = WGM * 128, BN = WGN * TN * 32, TM = 4, NW = WGM * WGN;
+  constexpr int NPA = BM / (16 * NW), NPB = BN / (16 * NW), NP = NPA + NPB;   // 1 KB DMA pieces per wave per chunk: weights, activations
   constexpr int STAGE = (BM + BN) * 4;     // h8 per stage: BM*4 weights + BN*4 activations
-  static_assert(WGM * WGN == 4 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
+  static_assert((NW == 4 || NW == 8) && NPA >= 1 && NPB >= 1 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1037,6 +1039,7 @@ namespace {
 template <bool X3>
 int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1) {
   const int blocks = p.gx * p.gy;
+  const bool w8 = BM == 256 && BN == 256 && getenv("DEEPIM_F16_W8") != nullptr;   // dev: one 8-wave block per CU on a 256x256 tile
   const bool tn2 = (BM == 256 && BN == 128) || (BM == 128 && BN == 256);       // 128x64 wave tiles, two blocks per CU
   const int slots = tn2 ? 512 : 256;
   int ks = 1, ts = 0;
@@ -1091,6 +1094,8 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     attr = true;
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
@@ -1098,6 +1103,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
   if (BM == 128 && tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
   else if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3>), dim3(grid), dim3(256), 122880, ctx->stream, p);
+  else if (w8) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 4, 4, X3, 2>), dim3(grid), dim3(512), 131072, ctx->stream, p);
   else if (tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
   else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, X3>), dim3(grid), dim3(256), 131072, ctx->stream, p);
   if (p.ksplit > 1) {
