@@ -1277,6 +1277,23 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   DI_REQUIRE((Cin & 31) == 0 && (Cout & 127) == 0, "conv2d_x3: needs Cin % 32 == 0 and Cout % 128 == 0");
   DI_REQUIRE(kh <= 7 && kw <= 7, "conv2d_x3: kernel larger than 7 not supported");
   const int Cv = 2 * Cin;   // virtual fp16 channels
+  {
+    // one raw-buffer descriptor with bit 31 of the offset as the padding marker addresses < 2 GiB of input per launch: larger
+    // batches run as consecutive sub-batches (samples are independent)
+    const size_t per_sample = (size_t)H * W * Cv * 2, limit = 0x7fffffffUL - (size_t)(pad * W + pad) * Cv * 2;
+    if ((size_t)B * per_sample >= limit) {
+      const int Bc = (int)((limit - 1) / per_sample);
+      DI_REQUIRE(Bc >= 1, "conv2d_x3: one sample exceeds 2 GiB");
+      const size_t out_sample = (size_t)((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1) * 2 * Cout;
+      for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int rc = deepim_conv2d_x3_forward(ctx, (_Float16*)out_split16 + (size_t)b0 * out_sample,
+                                                (const _Float16*)in_split16 + (size_t)b0 * H * W * Cv, packed_w, bias,
+                                                min(Bc, B - b0), Cin, H, W, Cout, kh, kw, stride, pad, slope, acc_scale, out_scale);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   ConvF16Params p;
   p.in = in_split16; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_split16; p.tab = nullptr;
   p.B = B; p.Cin = Cv; p.H = H; p.W = W; p.Cout = Cout;
@@ -1319,7 +1336,17 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
   const long nt = (long)p.tiles_x * p.tiles_y * B;
   DI_REQUIRE((W & 3) == 0, "conv1_x3: W must be a multiple of 4 (aligned quad loads); use deepim_conv2d_forward_split16 otherwise");
-  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W * 4 < 0x7fffffffL, "conv1_x3: input tensor must be < 2 GiB per launch");
+  if ((long)B * 8 * H * W * 4 >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
+    const int Bc = (int)(0x7ffffffeL / ((long)8 * H * W * 4));
+    DI_REQUIRE(Bc >= 1, "conv1_x3: one sample exceeds 2 GiB");
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int rc = deepim_conv1_x3_forward(ctx, (_Float16*)out_split16 + (size_t)b0 * p.Ho * p.Wo * 128, in + (size_t)b0 * 8 * H * W,
+                                             packed_w, bias, min(Bc, B - b0), H, W, slope, in_scale, acc_scale, out_scale);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  DI_REQUIRE(nt < (1L << 30), "conv1_x3: too many tiles");
   p.ntiles = (int)nt;
   p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale; p.status = ctx->status;
   static bool attr = false;

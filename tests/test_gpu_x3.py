@@ -189,3 +189,35 @@ def test_x3_iteration_meets_the_fp32_bar(ctx, heads):
         f, fr = net.act["flow_est"].asnumpy(), ref["flow_est"]
         assert np.abs(f - fr).max() <= 1e-4 * max(1.0, np.abs(fr).max())
         assert np.mean(net.act["mask_observed_pred"].asnumpy() != ref["mask_observed_pred"]) < 1e-4
+
+
+def test_conv_x3_more_than_2gib_of_input_runs_as_sub_batches(ctx):
+    """conv2's geometry at B = 112: 2.2 GB of split16 input, more than one raw-buffer descriptor addresses (bit 31 of the offset
+    is the padding marker) → consecutive sub-batches inside the entry; every sample equals the 4-sample run."""
+    rng = np.random.default_rng(11)
+    B0, reps, cin, H, W, cout = 4, 28, 64, 240, 320, 128
+    x = rng.standard_normal((B0, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 5, 5)) / 40).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    h, sa, ws = ctx.handle, 16.0, _wscale(w)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_x3_packed_size(cout, cin, 5, 5) // 2,), dtype=np.float16)
+    lib.deepim_conv_x3_pack_weights(h, pk, ctx.array(w), cout, cin, 5, 5, cf(ws))
+    xs = ctx.empty((B0, H, W, 2 * cin), dtype=np.float16)
+    lib.deepim_nchw_f32_to_split16(h, xs, ctx.array(x), B0, cin, H, W, cf(sa))
+    big = ctx.empty((B0 * reps, H, W, 2 * cin), dtype=np.float16)
+    for r in range(reps):
+        big[r * B0:(r + 1) * B0].copyfrom(xs)
+    assert big.nbytes > 2 ** 31
+    ho, wo = 120, 160
+    args = (pk, ctx.array(b))
+    small = ctx.empty((B0, ho, wo, 2 * cout), dtype=np.float16)
+    lib.deepim_conv2d_x3_forward(h, small, xs, *args, B0, cin, H, W, cout, 5, 5, 2, 2, cf(0.1), cf(1.0 / (sa * ws)), cf(sa))
+    out = ctx.empty((B0 * reps, ho, wo, 2 * cout), dtype=np.float16)
+    lib.deepim_conv2d_x3_forward(h, out, big, *args, B0 * reps, cin, H, W, cout, 5, 5, 2, 2, cf(0.1), cf(1.0 / (sa * ws)), cf(sa))
+    ref = ctx.empty((B0, cout, ho, wo))
+    lib.deepim_split16_to_nchw_f32(h, ref, small, B0, cout, ho, wo, cf(1.0 / sa))
+    ref = ref.asnumpy()
+    got = ctx.empty((B0, cout, ho, wo))
+    for r in (0, 13, reps - 1):
+        lib.deepim_split16_to_nchw_f32(h, got, out[r * B0:(r + 1) * B0], B0, cout, ho, wo, cf(1.0 / sa))
+        assert np.abs(got.asnumpy() - ref).max() <= 1e-5 * np.abs(ref).max()
