@@ -484,6 +484,58 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     return;
   }
+  if constexpr (TN == 2) if (!p.partial && (p.Cout & 127) == 0) {
+    // Final output, whole 128-channel wave tiles: stage the tile through LDS (the ring is free once every wave has left the
+    // K loop) so that a wave writes each pixel's run of its 128 channels — 256 B of fp16, 512 B of split16 records — as
+    // contiguous 16-byte pieces, 1 KB per store instruction. The direct form below (8-byte quads, 64 different cache lines
+    // per instruction) cost 10-12 % of the kernel (measured with the stores removed).
+    constexpr int RUN = X3 ? 512 : 256, PITCH = RUN + 16, CPP = RUN / 16, PPI = 64 / CPP;
+    static_assert(4 * 32 * PITCH <= NSTAGE * STAGE * 16 || NW != 4, "staging area");
+    __syncthreads();
+    char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
+    const int cw0 = mb * BM + wm0;                                     // first channel of this wave's tile
+    const size_t rec_bytes = (size_t)p.Cout * (X3 ? 4 : 2);            // bytes per output pixel
+    const size_t run_off = X3 ? (size_t)(cw0 >> 4) * 64 : (size_t)cw0 * 2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = i * 32 + 8 * g + 4 * lrow;                    // channel within the wave tile
+          const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bias_q[4] = {bq.x, bq.y, bq.z, bq.w};
+          h4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = (X3 ? acc[i][j][4 * g + r] * p.acc_scale : acc[i][j][4 * g + r]) + bias_q[r];
+            x = x > 0.f ? x : x * p.slope;
+            if constexpr (X3) { const X3Pair s2 = x3_split(x, p.out_scale, amax); vh[r] = s2.hi; vl[r] = s2.lo; }
+            else vh[r] = (_Float16)x;
+          }
+          if constexpr (X3) {
+            char* rec = stage + lcol * PITCH + (cl >> 4) * 64 + (cl & 15) * 2;
+            *reinterpret_cast<h4*>(rec) = vh;
+            *reinterpret_cast<h4*>(rec + 32) = vl;
+          } else {
+            *reinterpret_cast<h4*>(stage + lcol * PITCH + cl * 2) = vh;
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one quad at a time: hoisting all 32 quads' arithmetic ahead of the writes spills
+        }
+      // the wave reads back its own writes (LDS operations of a wave complete in order)
+#pragma unroll
+      for (int k = 0; k < 32 / PPI; ++k) {
+        const int px = k * PPI + lane / CPP, chunk = lane % CPP;
+        const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * PITCH + chunk * 16);
+        const long op = n0 + wn0 + j * 32 + px;
+        if (op < p.npix)
+          *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(p.out) + (size_t)op * rec_bytes + run_off + chunk * 16) = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (X3) x3_report(amax, p.status);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long op = n0 + wn0 + j * 32 + lcol;
@@ -1088,8 +1140,6 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
   if (!attr) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
@@ -1102,10 +1152,14 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
   if (BM == 128 && tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
-  else if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3>), dim3(grid), dim3(256), 122880, ctx->stream, p);
   else if (w8) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 4, 4, X3, 2>), dim3(grid), dim3(512), 131072, ctx->stream, p);
   else if (tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
-  else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, X3>), dim3(grid), dim3(256), 131072, ctx->stream, p);
+  else if constexpr (!X3) {   // 128x128 wave tiles, one block per CU (DEEPIM_F16_TN4=1; plain fp16 only)
+    if (BM == 128) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, false>), dim3(grid), dim3(256), 122880, ctx->stream, p);
+    else hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 4, false>), dim3(grid), dim3(256), 131072, ctx->stream, p);
+  } else {
+    DI_REQUIRE(false, "conv2d_x3: tile shape not built");
+  }
   if (p.ksplit > 1) {
     const long total4 = p.npix * p.Cout / 4;
     if (X3)
@@ -1308,7 +1362,7 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   const size_t in_bytes = (size_t)B * H * W * Cv * 2;
   DI_REQUIRE(in_bytes + p.pad_bytes < 0x7fffffffUL, "conv2d_x3: input tensor must be < 2 GiB per launch");
   p.in_bytes = (unsigned)in_bytes;
-  const int BM = f16_bm(Cout), BN = f16_bn(Cout, true);
+  const int BM = f16_bm(Cout), BN = getenv("DEEPIM_F16_W8") && BM == 256 ? 256 : (BM == 256 ? 128 : 256);   // 128x64 wave tiles
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   // the plan model of the fp16 path with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
   return launch_f16_dma<true>(ctx, p, BM, BN, 1.0f, 0.006f);
