@@ -7,6 +7,7 @@ bench.py times) against the CPU oracle:
             rendered mask and box_rendered rectangle bit-exact against the oracle renderer at the same pose.
   config 4  Occlusion-LINEMOD: an occluder rectangle painted over the observed frame, B = 2, full test graph (decoder +
             mask / flow heads).  Bars: flow ≤ 1e-4, mask flips < 1e-4 of the pixels, se3 ≤ 1e-4.
+  configs 3 and 4 run twice: on the default fp32 kernels and with network.X3_CONV (split-fp16 convs) — the same bars.
   config 5  ModelNet RGB-D: INPUT_DEPTH=True (C_in = 10 → padded to 16 in the fp16 NHWC layout), conv stack on the
             fp16 matrix cores.  Bars (fp16 cannot meet 1e-4): conv6_1 ≤ 5e-3, se3 ≤ 5e-3, pose ≤ 2e-3 against the oracle's
             fp16 emulation (fp16-rounded operands/outputs, fp32 accumulate).
@@ -52,8 +53,11 @@ def _render_frame(mesh, pose, K):
     return img, dep
 
 
-def test_config3_thirteen_objects_mixed_batch_two_closed_loop_iterations(ctx):
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "split_fp16_x3"])
+def test_config3_thirteen_objects_mixed_batch_two_closed_loop_iterations(ctx, x3):
+    """x3: the same bars with the encoder on the split-fp16 kernels (fp32-grade, not bit-exact: the pose bar is 1e-4 either way)."""
     cfg = default_config()
+    cfg.network.X3_CONV = x3
     K = cfg.dataset.INTRINSIC_MATRIX
     meshes = _meshes13()
     class_index = np.array([3, 3, 11, 7])            # a run of two 'can's, then 'lamp', then 'eggbox'
@@ -124,10 +128,12 @@ def test_config3_thirteen_objects_mixed_batch_two_closed_loop_iterations(ctx):
     assert rel(pose2, p1) > 1e-4                                                      # the second iteration moved the pose
 
 
-def test_config4_occluded_batch_with_decoder_and_heads(ctx):
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32", "split_fp16_x3"])
+def test_config4_occluded_batch_with_decoder_and_heads(ctx, x3):
     d = synthetic.make_batch(2, seed=404, n_frames=1, occlude=True)
     B = 2
     cfg = default_config()
+    cfg.network.X3_CONV = x3
     cfg.TEST.FAST_TEST = False
     net = deepIM_flownet().get_symbol(cfg)
     assert net.with_mask_head and net.with_flow_head
