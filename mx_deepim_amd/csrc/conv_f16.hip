@@ -472,6 +472,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
 #undef DMA
 
   float amax = 0.f;
+  if constexpr (TN == 2) if (tail_slot >= 0 || p.partial) {
+    // Raw fp32 partial sums (a tail slice: tile-local [pixel][BM channels]; a split-K slice: [slice][pixel][Cout]) through the
+    // same LDS staging as the final tiles below: a pixel's 128 channels of this wave are 512 contiguous bytes
+    constexpr int PITCH = 512 + 16;
+    __syncthreads();
+    char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
+    float* dst;
+    size_t row_floats;
+    if (tail_slot >= 0) { dst = p.tail_partial + (long)tail_slot * (BM * BN) + (long)wn0 * BM + wm0; row_floats = BM; }
+    else { dst = p.partial + ((long)split * p.npix + n0 + wn0) * p.Cout + mb * BM + wm0; row_floats = p.Cout; }
+    const bool co_ok = tail_slot >= 0 || mb * BM + wm0 + 128 <= p.Cout;   // Cout % 128 == 0 on this path except ragged fp16 layers
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(stage + lcol * PITCH + (i * 32 + 8 * g + 4 * lrow) * 4) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int px = k * 2 + (lane >> 5), chunk = lane & 31;
+        const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * PITCH + chunk * 16);
+        const long op = n0 + wn0 + j * 32 + px;
+        const bool ok = tail_slot >= 0 || (op < p.npix && (co_ok || mb * BM + wm0 + chunk * 4 < p.Cout));
+        if (ok) *reinterpret_cast<i32x4*>(dst + (size_t)(j * 32 + px) * row_floats + chunk * 4) = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
   if (tail_slot >= 0) {   // raw fp32 partial sums of a tail slice, tile-local [pixel][channel]
     float* tp = p.tail_partial + (long)tail_slot * (BM * BN);
 #pragma unroll
