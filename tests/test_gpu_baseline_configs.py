@@ -184,3 +184,31 @@ def test_config5_rgbd_input_fp16_conv_path(ctx):
     assert np.abs(c - emu["conv6_1"]).max() <= 5e-3 * np.abs(emu["conv6_1"]).max()
     assert rel(net.act["se3"].asnumpy(), emu["se3"]) < 5e-3
     assert rel(pose, emu["pose_est"]) < 2e-3
+
+
+def test_config5_rgbd_input_split_fp16_meets_the_fp32_bar(ctx):
+    """Config 5's input as written (INPUT_DEPTH, C_in = 10) with the split-fp16 convs instead of plain fp16: conv1 takes the
+    fp32 kernel with the split16 epilogue (the patch kernel is built for 8 channels), and the result meets the fp32 bar
+    (se3 / pose ≤ 1e-4 of the fp32 oracle) that plain fp16 cannot."""
+    d = synthetic.make_batch(2, seed=506, n_frames=1)
+    B = 2
+    cfg = default_config()
+    cfg.network.INPUT_DEPTH = True
+    cfg.network.X3_CONV = True
+    net = deepIM_flownet().get_symbol(cfg)
+    assert net.cin == 10 and net.x3_conv
+    params = net.init_weights(cfg, seed=56)
+    net.bind(ctx, B, params)
+    assert "flow_conv1" not in net.packed_x3
+    npd = {"image_observed": d["image_observed"], "image_rendered": d["image_rendered"][0], "mask_observed": d["mask_observed"],
+           "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0],
+           "depth_observed": d["depth_gt_observed"], "depth_rendered": d["depth_rendered"][0]}
+    pose = net.refine_iteration({k: ctx.array(v) for k, v in npd.items()}).asnumpy()
+    ref = opipe.refine_iteration(params, npd, d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds, cfg.network.ROT_COORD)
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), ref["net_input"])
+    assert rel(net.act["conv6_1"].asnumpy(), ref["conv6_1"]) < 1e-5
+    assert rel(net.act["se3"].asnumpy(), ref["se3"]) < 1e-4
+    assert rel(pose, ref["pose_est"]) < 1e-4
+    st = __import__("ctypes").c_int(0)
+    lib.deepim_zoom_status(ctx.handle, __import__("ctypes").byref(st))
+    assert st.value == 0            # nothing saturated: depth values (metres) times 16 stay far inside fp16's range
