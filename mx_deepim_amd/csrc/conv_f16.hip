@@ -1458,7 +1458,17 @@ extern "C" int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, con
   p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
   const long nt = (long)p.tiles_x * p.tiles_y * B;
   DI_REQUIRE((W & 3) == 0, "conv1_f16: W must be a multiple of 4 (aligned quad loads)");
-  DI_REQUIRE(nt < (1L << 30) && (long)B * 8 * H * W * 4 < 0x7fffffffL, "conv1_f16: input tensor must be < 2 GiB per launch");
+  if ((long)B * 8 * H * W * 4 >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
+    const int Bc = (int)(0x7ffffffeL / ((long)8 * H * W * 4));
+    DI_REQUIRE(Bc >= 1, "conv1_f16: one sample exceeds 2 GiB");
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+      const int rc = deepim_conv1_f16_forward(ctx, (_Float16*)out_nhwc_f16 + (size_t)b0 * p.Ho * p.Wo * 64, in + (size_t)b0 * 8 * H * W,
+                                              packed_w, bias, min(Bc, B - b0), H, W, slope);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  DI_REQUIRE(nt < (1L << 30), "conv1_f16: too many tiles");
   p.ntiles = (int)nt;
   p.slope = slope; p.in_scale = p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
   static bool attr = false;
