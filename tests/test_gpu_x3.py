@@ -221,3 +221,47 @@ def test_conv_x3_more_than_2gib_of_input_runs_as_sub_batches(ctx):
     for r in (0, 13, reps - 1):
         lib.deepim_split16_to_nchw_f32(h, got, out[r * B0:(r + 1) * B0], B0, cout, ho, wo, cf(1.0 / sa))
         assert np.abs(got.asnumpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_x3_closed_loop_tracks_the_fp32_loop(ctx):
+    """Four closed-loop iterations (refine → re-render → mask update → …, as bench.py runs them) on the same 4 pairs: the final
+    poses of the split-fp16 mode stay within 1e-6 of the canonical-order fp32 run — the distance at which the default fp32
+    kernels (other summation order, split-K) land as well; rasterisation and the zoom crop do not amplify the difference."""
+    from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import update_test_batch
+    from mx_deepim_amd.lib.render_glumpy.render_py_multi import Render_Py
+    B = 4
+    batch = synthetic.make_batch(B, seed=2333, n_frames=1, with_depth=False)
+    mesh = dict(synthetic.ellipsoid_mesh([0.05, 0.04, 0.035]), texture=synthetic.procedural_texture())
+    mesh.pop("colors")
+
+    def run(mode):
+        cfg = default_config()
+        cfg.network.X3_CONV = mode == "x3"
+        net = deepIM_flownet().get_symbol(cfg)
+        params = net.init_weights(cfg, seed=7)
+        params["trans_weight"] = params["trans_weight"] * np.float32(0.02)      # keep the object in frame (as bench.py does)
+        params["trans_bias"] = params["trans_bias"] * np.float32(0.02)
+        if mode == "canonical":
+            net.nc8 = False
+        net.bind(ctx, B, params)
+        rm = Render_Py("synthetic", ["ellipsoid"], batch["K"], 640, 480, 0.25, 6.0, meshes={"ellipsoid": mesh}, ctx=ctx,
+                       pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 1 if mode == "canonical" else 0)
+        try:
+            pose = ctx.array(batch["src_pose"][0])
+            data = {"image_observed": ctx.array(batch["image_observed"]), "image_rendered": ctx.array(batch["image_rendered"][0]),
+                    "mask_rendered": ctx.array(batch["mask_rendered"][0]),
+                    "mask_observed": ctx.array(batch["mask_observed_frames"][0]), "src_pose": pose}
+            for it in range(4):
+                net.refine_iteration(data, pose)
+                if it < 3:
+                    data = update_test_batch(cfg, data, rm, pose)
+                    data["src_pose"] = pose
+            return pose.asnumpy()
+        finally:
+            lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+
+    ref = run("canonical")
+    assert np.abs(ref - batch["src_pose"][0]).max() > 1e-3          # the loop moved the poses
+    assert np.abs(run("default") - ref).max() < 1e-6
+    assert np.abs(run("x3") - ref).max() < 1e-6
