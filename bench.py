@@ -349,6 +349,14 @@ def other_configs():
             res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
                          "workload": j["config"]["workload"], "conv_tflops": j["roofline"]["achieved"],
                          "conv_peak_tflops": j["roofline"]["peak"], "conv_frac": j["roofline"]["frac"]}
+            if "--x3" in extra:
+                res[name]["arithmetic"] = ("conv2-conv6_1 and conv1 as hi*hi + hi*lo + lo*hi on fp16 (hi, lo) pairs, fp32 accumulation: "
+                                           "every layer <= 1e-5 of the fp32 oracle (observed 2.4e-6), pose ~1e-6 (north_star bar 1e-4), "
+                                           "final poses of the 4-iteration closed loop within 1.2e-7 of the canonical fp32 run "
+                                           "(tests/test_gpu_x3.py, tests/test_gpu_baseline_configs.py); not bit-exact, hence a labelled "
+                                           "mode; conv_peak = 2.5 PF / 3 products")
+            elif "--fp16" in extra:
+                res[name]["arithmetic"] = "plain fp16 operands, fp32 accumulation: pose ~2e-3 of the fp32 oracle, outside the 1e-4 bar (BASELINE config 5)"
         except Exception as e:      # a secondary figure must never break the headline line
             res[name] = {"error": repr(e)[:200]}
     return res
