@@ -258,13 +258,17 @@ int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* i
  * of two), a product is hi·hi + hi·lo + lo·hi (v_mfma_f32_32x32x16_f16, fp32 accumulation; the dropped lo·lo term is 2^-22
  * relative). Tensors are "split16" NHWC: per pixel, per 16 channels, 32 halves [hi 0..15 | lo 0..15].
  * acc_scale = 1 / (s_in · s_w) returns the accumulator to real units before bias; out_scale = s of the stored output.
- * Needs Cin % 32 == 0, Cout % 128 == 0 (conv2 … conv6_1 of the encoder; conv1 runs in fp32 and is converted). */
+ * Needs Cin % 32 == 0, Cout % 128 == 0 (conv2 … conv6_1 of the encoder; conv1: deepim_conv1_x3_forward, or the fp32 conv with a
+ * split16 epilogue for other channel counts). Inputs beyond 2 GiB run as sub-batches. A value that leaves fp16's range after
+ * scaling is clamped and reported through bit 3 of the status word (deepim_zoom_status). Not bit-exact against the fp32 path:
+ * every layer within 1e-5 of the float64-accumulating oracle (tests/test_gpu_x3.py). */
 int deepim_nchw_f32_to_split16(deepim_ctx* ctx, void* out_split16, const float* in, int B, int C, int H, int W, float scale);
 int deepim_split16_to_nchw_f32(deepim_ctx* ctx, float* out, const void* in_split16, int B, int C, int H, int W, float inv_scale);
 size_t deepim_conv_x3_packed_size(int Cout, int Cin, int kh, int kw);
 int deepim_conv_x3_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*Cout,Cin,kh,kw dev f32*/, int Cout, int Cin,
                                 int kh, int kw, float w_scale);
-/* conv1 of that encoder: the fp32 MFMA convolution (NCHW fp32 in, bit-exact products) writing split16 from its epilogue */
+/* conv1 of that encoder for channel counts other than 8: the fp32 MFMA convolution (NCHW fp32 in, exact products) writing
+ * split16 from its epilogue; Cout % 16 == 0, even Cin */
 int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16, const float* in, const float* packed_w, const float* bias,
                                   int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                                   float out_scale);
