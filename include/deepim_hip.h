@@ -97,6 +97,13 @@ int deepim_comm_allreduce_f64(deepim_ctx* ctx, double* buf, int n, int op);
 void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt,
            float* KT, float* Kinv, int batch_size, int height, int width,
            int device_id);
+/* The one body behind `_flow`.  gpu_flow.hpp:1-3 has C++ linkage (no extern "C") and the reference's Cython
+ * extension is built language="c++" (gpu_flow.pyx:13-16, setup_linux.py:116-125), so it links the mangled
+ * _Z5_flowPfS_S_S_S_S_iiii: the library exports that symbol too (csrc/flow_cxx.cpp; not declarable in this C header),
+ * forwarding here like the C-linkage `_flow` above. */
+void deepim_flow_host(float* flow, float* valid, float* depth_src, float* depth_tgt,
+                      float* KT, float* Kinv, int batch_size, int height, int width,
+                      int device_id);
 int deepim_flow_status(void);
 /* device-pointer variant of the same kernel (gpu_flow_kernel.cu:32-69) */
 int deepim_flow_forward(deepim_ctx* ctx, float* flow, float* valid,

@@ -326,10 +326,13 @@ extern "C" int deepim_flow_forward(deepim_ctx* ctx, float* flow, float* valid, c
 static int g_flow_status = 0;
 extern "C" int deepim_flow_status(void) { return g_flow_status; }
 
-// B2 drop-in: host pointers, synchronous (gpu_flow_kernel.cu:82-148). A per-device
-// context + device buffers are cached between calls instead of malloc/free per call.
-extern "C" void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt, float* KT, float* Kinv,
-                      int batch_size, int height, int width, int device_id) {
+// B2 drop-in body: host pointers, synchronous (gpu_flow_kernel.cu:82-148). A per-device
+// context + device buffers are cached between calls instead of malloc/free per call.  Two symbols forward here:
+// the C-linkage `_flow` below (ctypes / cgo-style binders) and the C++-linkage `_flow` of flow_cxx.cpp, which is
+// the symbol the reference's own Cython extension links (gpu_flow.hpp:1-3 has no extern "C"; gpu_flow.pyx:13-16 is
+// built language="c++", setup_linux.py:116-125).
+extern "C" void deepim_flow_host(float* flow, float* valid, float* depth_src, float* depth_tgt, float* KT, float* Kinv,
+                                 int batch_size, int height, int width, int device_id) {
   static deepim_ctx* ctxs[64] = {nullptr};
   static float* bufs[64] = {nullptr};
   static size_t caps[64] = {0};
@@ -381,6 +384,11 @@ extern "C" void _flow(float* flow, float* valid, float* depth_src, float* depth_
     return;
   }
   g_flow_status = 0;
+}
+
+extern "C" void _flow(float* flow, float* valid, float* depth_src, float* depth_tgt, float* KT, float* Kinv,
+                      int batch_size, int height, int width, int device_id) {
+  deepim_flow_host(flow, valid, depth_src, depth_tgt, KT, Kinv, batch_size, height, width, device_id);
 }
 
 extern "C" int deepim_calc_flow_forward(deepim_ctx* ctx, float* flow, float* visible, const float* depth_src,

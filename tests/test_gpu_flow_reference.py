@@ -88,3 +88,32 @@ def test_flow_vs_reference_kernel_with_fma_contraction(small_batch):
         print("%s: valid flips %.2e, flow max rel diff %.2e, flow words differing %.3f" % (name, flips, err, bitdiff))
         assert flips < 1e-4, (name, flips)
         assert err < 1e-4, (name, err)
+
+
+def test_flow_through_the_reference_header_binding(ctx, small_batch):
+    """B2 as the reference binds it: oracle/_ref/libflow_hpp_client.so is a C++ TU that includes the reference's
+    gpu_flow.hpp UNMODIFIED (gpu_flow.pyx:13-16 does the same) and is linked against libdeepim_hip.so — it resolves
+    the C++-mangled `_flow`.  Its result must equal the C-linkage `_flow` and deepim_flow_forward bit for bit."""
+    path = os.path.join(REF_DIR, "libflow_hpp_client.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libflow_hpp_client.so not built (needs /root/reference at build time)")
+    lib.load()
+    call = ctypes.CDLL(path).flow_hpp_client_call
+    call.restype = None
+    call.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4
+    for name, src, tgt, KT, Kinv in _cases(small_batch):
+        B, _, H, W = src.shape
+        flow = np.zeros((B, 2, H, W), np.float32)
+        valid = np.zeros((B, 1, H, W), np.float32)
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (src, tgt, KT, Kinv)]
+        call(flow.ctypes.data, valid.ctypes.data, *[a.ctypes.data for a in arrs], B, H, W, 0)
+        assert lib.load().deepim_flow_status() == 0, lib.last_error()
+        f, v = gpu_flow(src, tgt, KT, Kinv)
+        assert v.sum() > 20, name
+        np.testing.assert_array_equal(valid, v, err_msg=name)
+        np.testing.assert_array_equal(flow.view(np.uint32), f.view(np.uint32), err_msg=name)
+        dflow, dvalid = ctx.empty((B, 2, H, W)), ctx.empty((B, 1, H, W))
+        lib.deepim_flow_forward(ctx.handle, dflow, dvalid, ctx.array(src), ctx.array(tgt), ctx.array(KT),
+                                np.ascontiguousarray(Kinv), B, H, W)
+        np.testing.assert_array_equal(dvalid.asnumpy(), valid, err_msg=name)
+        np.testing.assert_array_equal(dflow.asnumpy().view(np.uint32), flow.view(np.uint32), err_msg=name)
