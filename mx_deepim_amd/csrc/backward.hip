@@ -19,8 +19,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void lrelu_backward_kernel(float* __restrict__ dz, const float* __restrict__ dy,
-                                                             const float* __restrict__ y, float slope, size_t n) {
+// called in place (dz == dy) by the training graph: no __restrict__ on that pair
+__global__ __launch_bounds__(256) void lrelu_backward_kernel(float* dz, const float* dy, const float* __restrict__ y,
+                                                             float slope, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
 }

@@ -14,6 +14,12 @@ constexpr int DI_STATUS_GROUP_RANGE = 2;      // GroupPicker index out of range
 constexpr int DI_STATUS_X3_SATURATED = 8;     // split-fp16 conv: a value left fp16's range after scaling and was clamped (results invalid)
 constexpr int DI_STATUS_MASK_BOX_EMPTY = 4;   // mask_box / fused re-render: empty mask (data_pair.py:98 np.min raises)
 
+// deepim_set_option(ctx, "f16_dev_flags", bits): measurement switches of csrc/conv_f16.hip
+constexpr int DI_F16_TN4 = 1;      // 128x128 wave tiles, one block per CU (the round-2 starting point)
+constexpr int DI_F16_W8 = 2;       // one 8-wave block per CU on a 256x256 tile
+constexpr int DI_F16_NO_TAIL = 4;  // no tail split of the under-filled last round
+constexpr int DI_F16_NO_DMA = 8;   // register-staged kernel instead of the LDS-DMA ring
+
 struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry
 
 struct ConvPlanKey { int mode, B, Cin, H, W, Cout, Ho, Wo, stride, pad, nchunk, below, target; };
@@ -45,7 +51,16 @@ struct deepim_ctx {
   int conv_autotune;  // 1: time split-K candidates on the first call of a geometry (default 0: deterministic cost-model plan)
   int conv_max_split;  // 0 auto, 1 off, n cap
   int conv_xcd_swizzle;  // 1: XCD-aware tile order (default), 0: plain
+  int f16_dev_flags;     // dev: DI_F16_* bits — alternative tilings of the fp16 / x3 conv kernels (default 0)
+  std::vector<const void*> attr_done;  // hipFuncSetAttribute groups already applied on THIS context's device (di_attr_needed)
 };
+
+// true the first time `tag` is seen on this context: guards one-off hipFuncSetAttribute calls (per device, hence per context)
+static inline bool di_attr_needed(deepim_ctx* ctx, const void* tag) {
+  for (const void* t : ctx->attr_done) if (t == tag) return false;
+  ctx->attr_done.push_back(tag);
+  return true;
+}
 
 void deepim_set_error(const char* where, hipError_t e);
 void deepim_set_error_msg(const char* msg);

@@ -38,10 +38,12 @@ constexpr int HOCT = 8;   // octets per chunk (K chunk = 8 octets x 8 halves = 6
 //   Cout % 256 == 0           waves 2x2, wave tile 4x4: 256 x 256 block (256 accumulator registers, one wave per SIMD)
 inline int f16_bm(int Cout) { return Cout <= 64 ? 64 : ((Cout & 255) == 0 ? 256 : 128); }
 // DMA kernel: 128x64 wave tiles, two blocks per CU (DEEPIM_F16_TN4=1 restores the 128x128 wave tiles, one block per CU)
-inline int f16_bn(int Cout, bool dma) {
+// Dev switches live in the context (deepim_set_option "f16_dev_flags", DI_F16_*), never in the process environment:
+// tiling decides the summation order, and every rank must take the same plan.
+inline int f16_bn(int Cout, bool dma, int dev) {
   if (!dma) return 256;
-  const bool tn4 = getenv("DEEPIM_F16_TN4") != nullptr;
-  if (f16_bm(Cout) == 256) return (tn4 || getenv("DEEPIM_F16_W8")) ? 256 : 128;
+  const bool tn4 = (dev & DI_F16_TN4) != 0;
+  if (f16_bm(Cout) == 256) return (tn4 || (dev & DI_F16_W8)) ? 256 : 128;
   return f16_bm(Cout) == 128 ? (tn4 ? 512 : 256) : 256;
 }
 
@@ -1122,7 +1124,7 @@ namespace {
 template <bool X3>
 int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1) {
   const int blocks = p.gx * p.gy;
-  const bool w8 = BM == 256 && BN == 256 && getenv("DEEPIM_F16_W8") != nullptr;   // dev: one 8-wave block per CU on a 256x256 tile
+  const bool w8 = BM == 256 && BN == 256 && (ctx->f16_dev_flags & DI_F16_W8) != 0;   // dev: one 8-wave block per CU on a 256x256 tile
   const bool tn2 = (BM == 256 && BN == 128) || (BM == 128 && BN == 256);       // 128x64 wave tiles, two blocks per CU
   const int slots = tn2 ? 512 : 256;
   int ks = 1, ts = 0;
@@ -1136,7 +1138,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
       if (cost < best * 0.985f) { best = cost; ks = s_; }
     }
     const int R = blocks % slots;
-    if (blocks > slots && R > 0 && ctx->conv_max_split == 0 && !getenv("DEEPIM_F16_NO_TAIL")) {
+    if (blocks > slots && R > 0 && ctx->conv_max_split == 0 && !(ctx->f16_dev_flags & DI_F16_NO_TAIL)) {
       for (int t_ : {2, 3, 4, 5, 6, 8}) {
         if (t_ > max(1, p.nchunk / 4)) continue;
         const float cost = (float)(blocks / slots) * (float)p.nchunk + (float)di_div_up(R * t_, slots) * (float)di_div_up(p.nchunk, t_) +
@@ -1167,8 +1169,8 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     p.tail_partial = (float*)scratch;
     grid = p.n_full + R * p.tail_s;
   }
-  static bool attr = false;
-  if (!attr) {
+  static const char attr_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
@@ -1177,7 +1179,6 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    attr = true;
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
     fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
@@ -1242,10 +1243,10 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   }
   p.tab = tab;
   const bool ut = ((Cin_pad >> 3) & 7) == 0;
-  const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !getenv("DEEPIM_F16_NO_DMA"));
+  const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !(ctx->f16_dev_flags & DI_F16_NO_DMA), ctx->f16_dev_flags);
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr; p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
-  if (ut && BM >= 128 && !getenv("DEEPIM_F16_NO_DMA")) return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f);
+  if (ut && BM >= 128 && !(ctx->f16_dev_flags & DI_F16_NO_DMA)) return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f);
   const int blocks = p.gx * p.gy;
   // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when
   // the grid cannot fill the 256 CUs; deterministic (cost model of csrc/conv.hip's plan_ksplit, one slot per CU)
@@ -1270,8 +1271,8 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     p.partial = (float*)scratch;
   }
   const size_t lds = (size_t)2 * HOCT * (BM + BN) * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const char attr_set_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &attr_set_tag)) {
 #define DI_F16_ATTR(A, B2, C, D, BMv, BNv)                                                                                  \
   DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_kernel<A, B2, C, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                2 * HOCT * (BMv + BNv) * 16));                                                              \
@@ -1281,7 +1282,6 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     DI_F16_ATTR(2, 2, 2, 4, 128, 256)
     DI_F16_ATTR(2, 2, 4, 4, 256, 256)
 #undef DI_F16_ATTR
-    attr_set = true;
   }
   const dim3 grid(blocks * p.ksplit);
 #define DI_F16_LAUNCH(A, B2, C, D)                                                                                 \
@@ -1289,13 +1289,12 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
     if (ut) hipLaunchKernelGGL((conv_f16_kernel<A, B2, C, D, true>), grid, dim3(256), lds, ctx->stream, p);         \
     else hipLaunchKernelGGL((conv_f16_kernel<A, B2, C, D, false>), grid, dim3(256), lds, ctx->stream, p);           \
   }
-  static bool dma_attr = false;
-  if (!dma_attr) {
+  static const char dma_attr_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &dma_attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
-    dma_attr = true;
   }
-  const bool dma = ut && !getenv("DEEPIM_F16_NO_DMA");
+  const bool dma = ut && !(ctx->f16_dev_flags & DI_F16_NO_DMA);
   if (BM == 64) DI_F16_LAUNCH(1, 4, 2, 2)
   else if (BM == 128 && dma) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3>), grid, dim3(256), 122880, ctx->stream, p);
   else if (BM == 128) DI_F16_LAUNCH(2, 2, 2, 4)
@@ -1393,7 +1392,7 @@ extern "C" int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, cons
   const size_t in_bytes = (size_t)B * H * W * Cv * 2;
   DI_REQUIRE(in_bytes + p.pad_bytes < 0x7fffffffUL, "conv2d_x3: input tensor must be < 2 GiB per launch");
   p.in_bytes = (unsigned)in_bytes;
-  const int BM = f16_bm(Cout), BN = getenv("DEEPIM_F16_W8") && BM == 256 ? 256 : (BM == 256 ? 128 : 256);   // 128x64 wave tiles
+  const int BM = f16_bm(Cout), BN = (ctx->f16_dev_flags & DI_F16_W8) && BM == 256 ? 256 : (BM == 256 ? 128 : 256);   // 128x64 wave tiles
   p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   // the plan model of the fp16 path with a chunk 1.5x as long (96 instead of 64 MFMAs per wave)
   return launch_f16_dma<true>(ctx, p, BM, BN, 1.0f, 0.006f);
@@ -1434,10 +1433,9 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   DI_REQUIRE(nt < (1L << 30), "conv1_x3: too many tiles");
   p.ntiles = (int)nt;
   p.slope = slope; p.in_scale = in_scale; p.acc_scale = acc_scale; p.out_scale = out_scale; p.status = ctx->status;
-  static bool attr = false;
-  if (!attr) {
+  static const char attr_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
-    attr = true;
   }
   const int grid = (int)min(256L, nt);   // persistent: one block per CU
   hipLaunchKernelGGL(conv1_x3_kernel<true>, dim3(grid), dim3(256), C1_LDS, ctx->stream, p);
@@ -1471,10 +1469,9 @@ extern "C" int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, con
   DI_REQUIRE(nt < (1L << 30), "conv1_f16: too many tiles");
   p.ntiles = (int)nt;
   p.slope = slope; p.in_scale = p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
-  static bool attr = false;
-  if (!attr) {
+  static const char attr_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_F16));
-    attr = true;
   }
   const int grid = (int)min(512L, nt);   // persistent: two blocks per CU
   hipLaunchKernelGGL(conv1_x3_kernel<false>, dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);

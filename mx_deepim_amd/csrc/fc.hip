@@ -310,10 +310,9 @@ extern "C" int deepim_fc_forward_packed(deepim_ctx* ctx, float* out, const float
   if (rc) return rc;
   float* partial = (float*)scratch;
   const size_t lds = (size_t)2 * OT * 1024 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const char attr_set_tag = 0;   // function attributes are per DEVICE: remember them per context
+  if (di_attr_needed(ctx, &attr_set_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)fc_mfma_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   for (int b0 = 0; b0 < B; b0 += 32) {   // one weight pass per 32 batch rows
     hipLaunchKernelGGL(fc_mfma_kernel<OT>, dim3(S), dim3(256), lds, ctx->stream, partial, in, packed_w, B, b0, I, steps_total,

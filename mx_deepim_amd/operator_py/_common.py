@@ -39,6 +39,10 @@ def targets(out_data, req):
 def check_zoom_status(ctx, what):
     st = ctypes.c_int(0)
     lib.deepim_zoom_status(ctx.handle, ctypes.byref(st))
+    if st.value & 8:
+        # DI_STATUS_X3_SATURATED: reading the word clears it, so it must be reported here, not dropped
+        raise FloatingPointError("%s: a split-fp16 (x3) convolution saturated fp16's range earlier on this context — "
+                                 "its results are invalid (network.X3_CONV needs activations < 65504/16)" % what)
     if st.value & 1:
         # the reference dies in np.min(nz_x) with this ValueError (zoom_mask.py:55 / zoom_image.py:46)
         raise ValueError("zero-size array to reduction operation minimum which has no identity (%s: "

@@ -7,9 +7,10 @@ stream, no host sync inside the loop.  The reference's counterpart is the per-de
 outputs of all GPUs for the host (deepim/core/DataParallelExecutorGroup.py:364-388, deepim/test.py:135).
 
 Host side:
-  * `Rendezvous` — a tiny TCP star (rank 0 listens on MASTER_ADDR:MASTER_PORT+1, the others connect) used to ship
-    the 128-byte RCCL unique id at start-up and for the few host-side collectives a launcher needs (barrier,
-    all-gather of small Python objects, max-over-ranks of a timing).  It reads the same environment variables
+  * `Rendezvous` — a tiny TCP star (rank 0 listens on MASTER_ADDR:MASTER_PORT+1 — 127.0.0.1 for a single-node job —
+    the others connect) used to ship the 128-byte RCCL unique id at start-up and for the few host-side collectives a
+    launcher needs (barrier, all-gather of small typed values, max-over-ranks of a timing).  Typed binary frames (no
+    pickle), HMAC-authenticated membership.  It reads the same environment variables
     `python -m torch.distributed.run` sets (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT) but does not
     import torch.  Works without a GPU, which is how the world_size-2 CPU tests exercise it.
   * `PoseComm` — the RCCL communicator of a `Context`: `init` (bootstrap through a Rendezvous), `all_gather_poses`
@@ -17,8 +18,9 @@ Host side:
   * `shard_bounds` / `shard_pairs` — the partition itself.
 """
 import ctypes
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -57,6 +59,78 @@ def shard_pairs(batch, world_size, rank, n_pairs=None, replicated=("K",)):
 
 
 # ----------------------------------------------------------------------------------------------- rendezvous ----
+# Wire format: fixed binary framing, no pickle — a peer can only ever hand us one of the five value kinds below, and
+# nothing on the wire is executable.  frame = <u64 length><payload>;  payload = <u8 kind> + body:
+#   N  none                      F  <f64>                  I  <i64>                  B  raw bytes
+#   A  <u8 dtype code><u8 ndim><u32 shape[ndim]> raw C-order data           L  <u32 count> then `count` nested frames
+_MAX_FRAME = 64 << 20           # control plane only: ids, timings, (B,3,4) poses
+_DTYPES = {0: np.dtype("<f4"), 1: np.dtype("<f8"), 2: np.dtype("<i4"), 3: np.dtype("<i8"), 4: np.dtype("u1")}
+_DTYPE_CODE = {v: k for k, v in _DTYPES.items()}
+
+
+def _encode(obj):
+    if obj is None:
+        return b"N"
+    if isinstance(obj, (bytes, bytearray)):
+        return b"B" + bytes(obj)
+    if isinstance(obj, (bool, int, np.integer)):
+        return b"I" + struct.pack("<q", int(obj))
+    if isinstance(obj, (float, np.floating)):
+        return b"F" + struct.pack("<d", float(obj))
+    if isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.newbyteorder("<") if a.dtype.byteorder == ">" else a.dtype
+        if dt not in _DTYPE_CODE:
+            raise TypeError("rendezvous: unsupported array dtype %s" % a.dtype)
+        if a.ndim > 8:
+            raise TypeError("rendezvous: arrays of at most 8 dimensions")
+        return (b"A" + struct.pack("<BB", _DTYPE_CODE[dt], a.ndim) + struct.pack("<%dI" % a.ndim, *a.shape) +
+                a.astype(dt, copy=False).tobytes())
+    if isinstance(obj, (list, tuple)):
+        parts = [_encode(o) for o in obj]
+        return b"L" + struct.pack("<I", len(parts)) + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+    raise TypeError("rendezvous: cannot send %r (None, int, float, bytes, ndarray or a list of those)" % type(obj))
+
+
+def _decode(buf):
+    if not buf:
+        raise ValueError("rendezvous: empty frame")
+    kind, body = buf[:1], memoryview(buf)[1:]
+    if kind == b"N" and len(body) == 0:
+        return None
+    if kind == b"B":
+        return bytes(body)
+    if kind == b"I" and len(body) == 8:
+        return struct.unpack("<q", body)[0]
+    if kind == b"F" and len(body) == 8:
+        return struct.unpack("<d", body)[0]
+    if kind == b"A" and len(body) >= 2:
+        code, ndim = struct.unpack("<BB", body[:2])
+        if code in _DTYPES and ndim <= 8 and len(body) >= 2 + 4 * ndim:
+            shape = struct.unpack("<%dI" % ndim, body[2:2 + 4 * ndim])
+            data = body[2 + 4 * ndim:]
+            n = 1
+            for d in shape:
+                n *= d
+            if n * _DTYPES[code].itemsize == len(data):
+                return np.frombuffer(data, dtype=_DTYPES[code]).reshape(shape).copy()
+    if kind == b"L" and len(body) >= 4:
+        (count,) = struct.unpack("<I", body[:4])
+        out, off = [], 4
+        for _ in range(count):
+            if off + 8 > len(body):
+                break
+            (ln,) = struct.unpack("<Q", body[off:off + 8])
+            off += 8
+            if ln > len(body) - off:
+                break
+            out.append(_decode(bytes(body[off:off + ln])))
+            off += ln
+        if len(out) == count and off == len(body):
+            return out
+    raise ValueError("rendezvous: malformed frame (kind %r, %d bytes)" % (kind, len(buf)))
+
+
 def _send_msg(sock, payload):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
@@ -73,14 +147,25 @@ def _recv_exact(sock, n):
 
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_FRAME:
+        raise ValueError("rendezvous: frame of %d bytes exceeds the %d-byte limit" % (n, _MAX_FRAME))
     return _recv_exact(sock, n)
+
+
+def _is_loopback(addr):
+    return addr in ("localhost", "::1") or addr.startswith("127.")
 
 
 class Rendezvous(object):
     """TCP star between the ranks of one job: rank 0 is the hub.  Every collective is gather-to-hub + broadcast;
-    payloads are small (ids, timings), this is control plane only."""
+    payloads are small (ids, timings), this is control plane only.
 
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+    Trust: frames are decoded by `_decode` (typed binary, nothing executable).  Membership is authenticated with an
+    HMAC-SHA256 challenge in both directions over a job token (`DEEPIM_RDZV_TOKEN`, or the `token` argument).  A
+    single-node job (the supported deployment: WORLD_SIZE == LOCAL_WORLD_SIZE, or a loopback MASTER_ADDR) binds and
+    connects on 127.0.0.1 only and may run without an explicit token; a routable MASTER_ADDR REQUIRES the token."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
         env = os.environ
         self.rank = int(env.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(env.get("WORLD_SIZE", "1")) if world is None else int(world)
@@ -88,28 +173,59 @@ class Rendezvous(object):
         # MASTER_PORT itself belongs to the launcher's own store; the job's rendezvous sits one above it
         self.port = int(env.get("DEEPIM_RDZV_PORT", int(env.get("MASTER_PORT", "29500")) + 1)) if port is None else int(port)
         self.timeout = float(timeout)
+        single_node = int(env.get("LOCAL_WORLD_SIZE", "0")) == self.world or _is_loopback(self.addr)
+        if single_node:
+            self.addr = "127.0.0.1"
+        tok = token if token is not None else env.get("DEEPIM_RDZV_TOKEN")
+        if tok is None:
+            if not single_node and self.world > 1:
+                raise RuntimeError("rendezvous over a routable address (%s) needs a shared secret: set DEEPIM_RDZV_TOKEN "
+                                   "to the same random string on every rank" % self.addr)
+            # loopback only: the launcher's run id separates concurrent jobs of one host; it is not a secret
+            tok = "deepim-local:%s:%d:%d" % (env.get("TORCHELASTIC_RUN_ID", "none"), self.port, self.world)
+        self._key = hashlib.sha256(tok.encode() if isinstance(tok, str) else bytes(tok)).digest()
         self._peers = {}      # hub: rank -> socket
         self._hub = None      # spoke: socket to rank 0
         self._listener = None
         if self.world > 1:
             self._connect()
 
+    def _mac(self, *parts):
+        return hmac.new(self._key, b"|".join(parts), hashlib.sha256).digest()
+
     def _connect(self):
         if self.rank == 0:
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            ls.bind((self.addr if self.addr not in ("localhost",) else "127.0.0.1", self.port))
+            try:
+                ls.bind((self.addr, self.port))
+            except OSError as e:
+                ls.close()
+                raise RuntimeError("rendezvous: cannot bind %s:%d (%s) — MASTER_PORT+1 is taken, set DEEPIM_RDZV_PORT to a "
+                                   "free port on every rank" % (self.addr, self.port, e))
             ls.listen(self.world)
             ls.settimeout(self.timeout)
             self._listener = ls
+            deadline = time.time() + self.timeout
             while len(self._peers) < self.world - 1:
+                if time.time() > deadline:
+                    raise RuntimeError("rendezvous: only %d of %d ranks joined" % (len(self._peers) + 1, self.world))
                 conn, _ = ls.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(self.timeout)
-                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
-                if r <= 0 or r >= self.world or r in self._peers:
+                conn.settimeout(min(self.timeout, 10.0))
+                try:            # a stranger (wrong token, bad rank, garbage) is dropped; it cannot take a rank's slot
+                    nonce = os.urandom(16)
+                    conn.sendall(nonce)
+                    hello = _recv_exact(conn, 4 + 16 + 32)      # rank, the spoke's own nonce, HMAC(nonce | rank)
+                    (r,) = struct.unpack("<I", hello[:4])
+                    ok = hmac.compare_digest(hello[20:], self._mac(b"spoke", nonce, hello[:4]))
+                    if not ok or r <= 0 or r >= self.world or r in self._peers:
+                        raise ValueError("rejected")
+                    conn.sendall(self._mac(b"hub", hello[4:20]))   # prove the hub knows the token too
+                except (ValueError, OSError, ConnectionError):
                     conn.close()
-                    raise RuntimeError("rendezvous: unexpected rank %d" % r)
+                    continue
+                conn.settimeout(self.timeout)
                 self._peers[r] = conn
         else:
             deadline = time.time() + self.timeout
@@ -123,25 +239,45 @@ class Rendezvous(object):
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(self.timeout)
-            s.sendall(struct.pack("<I", self.rank))
+            nonce = _recv_exact(s, 16)
+            mine, rk = os.urandom(16), struct.pack("<I", self.rank)
+            s.sendall(rk + mine + self._mac(b"spoke", nonce, rk))
+            try:
+                proof = _recv_exact(s, 32)
+            except ConnectionError:
+                raise RuntimeError("rendezvous: the hub rejected rank %d (token mismatch or duplicate rank)" % self.rank)
+            if not hmac.compare_digest(proof, self._mac(b"hub", mine)):
+                s.close()
+                raise RuntimeError("rendezvous: %s:%d is not this job's hub (token mismatch)" % (self.addr, self.port))
             self._hub = s
 
     def all_gather(self, obj):
-        """-> list of every rank's `obj` (picklable, small), in rank order, on every rank."""
+        """-> list of every rank's `obj` (None / int / float / bytes / ndarray / list of those), in rank order, on
+        every rank."""
         if self.world == 1:
             return [obj]
-        mine = pickle.dumps(obj)
+        mine = _encode(obj)
         if self.rank == 0:
             parts = [mine] + [None] * (self.world - 1)
             for r, s in self._peers.items():
                 parts[r] = _recv_msg(s)
-            blob = pickle.dumps(parts)
+            blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
             for s in self._peers.values():
                 _send_msg(s, blob)
         else:
             _send_msg(self._hub, mine)
-            parts = pickle.loads(_recv_msg(self._hub))
-        return [pickle.loads(p) for p in parts]
+            blob, parts, off = _recv_msg(self._hub), [], 0
+            while off < len(blob):
+                if off + 8 > len(blob):
+                    raise ValueError("rendezvous: truncated gather frame")
+                (ln,) = struct.unpack("<Q", blob[off:off + 8])
+                if ln > len(blob) - off - 8:
+                    raise ValueError("rendezvous: truncated gather frame")
+                parts.append(blob[off + 8:off + 8 + ln])
+                off += 8 + ln
+            if len(parts) != self.world:
+                raise ValueError("rendezvous: gather frame holds %d parts for %d ranks" % (len(parts), self.world))
+        return [_decode(p) for p in parts]
 
     def broadcast(self, obj, root=0):
         return self.all_gather(obj if self.rank == root else None)[root]

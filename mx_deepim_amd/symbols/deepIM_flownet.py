@@ -73,6 +73,9 @@ class deepIM_flownet(object):
         n = cfg.network
         if not cfg.train_iter.SE3_PM_LOSS:
             raise NotImplementedError("training graph needs train_iter.SE3_PM_LOSS")
+        if getattr(n, "FP16_CONV", False) or getattr(n, "X3_CONV", False):
+            # encoder_fp16 / encoder_x3 fill only the fp16 / split16 activations; backward() reads the NCHW fp32 ones
+            raise NotImplementedError("training graph runs the fp32 convolutions only (network.FP16_CONV / X3_CONV unset)")
         self.get_test_symbol_share(cfg)
         self.is_train = True
         self.nc8 = False          # NCHW activations: what the backward kernels read

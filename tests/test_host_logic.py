@@ -129,3 +129,65 @@ def test_rendezvous_under_torchrun_matches_gloo(counts):
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_rendezvous_wire_format_is_typed_binary_not_pickle():
+    """nothing a peer sends may be unpickled.  Values round-trip through the typed codec; malformed or
+    oversized frames raise instead of being interpreted."""
+    src = open(parallel.__file__).read()
+    assert "import pickle" not in src and "pickle.loads" not in src
+    vals = [None, 3, -7, 2.5, b"\x00\x01id", np.arange(24, dtype=np.float32).reshape(2, 3, 4), np.zeros((0, 3, 4), np.float32),
+            np.array([1.5, 2.5]), [None, 1.0, b"x", np.ones((2, 2), np.int32)]]
+    for v in vals:
+        back = parallel._decode(parallel._encode(v))
+        if isinstance(v, np.ndarray):
+            assert back.dtype == v.dtype and back.shape == v.shape and np.array_equal(back, v)
+        elif isinstance(v, list):
+            assert len(back) == len(v) and back[1] == 1.0 and back[2] == b"x" and np.array_equal(back[3], v[3])
+        else:
+            assert back == v and type(back) is type(v)
+    import pickle
+    for bad in (b"", b"Z", b"F\x00", b"A\x09\x01", b"A\x00\x01\x05\x00\x00\x00abc", b"L\x02\x00\x00\x00", pickle.dumps({"a": 1})):
+        with pytest.raises(ValueError):
+            parallel._decode(bad)
+    with pytest.raises(TypeError):
+        parallel._encode({"a": 1})
+
+
+def _token_worker(rank, port, token, q):
+    try:
+        rd = parallel.Rendezvous(rank, 2, "127.0.0.1", port, timeout=20.0, token=token)
+        got = rd.all_gather(float(rank))
+        rd.close()
+        q.put((rank, got))
+    except Exception as e:
+        q.put((rank, type(e).__name__))
+
+
+def test_rendezvous_rejects_a_peer_with_the_wrong_token():
+    """A process that does not hold the job token cannot take a rank's slot: the hub drops it and keeps waiting for
+    the real rank 1, which then joins normally."""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 35000 + os.getpid() % 2000
+    hub = ctxm.Process(target=_token_worker, args=(0, port, "job-secret", q))
+    hub.start()
+    intruder = ctxm.Process(target=_token_worker, args=(1, port, "guess", q))
+    intruder.start()
+    r = q.get(timeout=60)
+    assert r == (1, "RuntimeError"), r             # the intruder is told no
+    intruder.join(timeout=30)
+    real = ctxm.Process(target=_token_worker, args=(1, port, "job-secret", q))
+    real.start()
+    res = sorted([q.get(timeout=60), q.get(timeout=60)])
+    hub.join(timeout=30)
+    real.join(timeout=30)
+    assert res == [(0, [0.0, 1.0]), (1, [0.0, 1.0])], res
+
+
+def test_rendezvous_needs_a_token_on_a_routable_address(monkeypatch):
+    monkeypatch.delenv("DEEPIM_RDZV_TOKEN", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    with pytest.raises(RuntimeError, match="DEEPIM_RDZV_TOKEN"):
+        parallel.Rendezvous(1, 2, "10.1.2.3", 29999, timeout=1.0)
