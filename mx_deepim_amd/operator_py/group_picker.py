@@ -5,6 +5,15 @@ from ..runtime import lib
 from ._common import check_zoom_status, targets
 
 
+def _rows_cols(shape):
+    """(B, C, ...) → (B, C·inner): the picked channel group [g·C/G, (g+1)·C/G) of a sample is one contiguous run of
+    (C/G)·inner elements, so trailing axes (group_picker.py:29-39 slices axis 1 of any rank) fold into the channel count."""
+    cols = 1
+    for d in shape[1:]:
+        cols *= int(d)
+    return int(shape[0]), cols
+
+
 class GroupPickerOperator(mx.operator.CustomOp):
     def __init__(self, group_num):
         super(GroupPickerOperator, self).__init__()
@@ -12,8 +21,8 @@ class GroupPickerOperator(mx.operator.CustomOp):
 
     def forward(self, is_train, req, in_data, out_data, aux):
         ctx = in_data[0].context
-        B, C = in_data[0].shape[0], in_data[0].shape[1]
-        assert C % self.group_num == 0
+        B, C = _rows_cols(in_data[0].shape)
+        assert in_data[0].shape[1] % self.group_num == 0       # group_picker.py:33
         t = targets(out_data, req)
         lib.deepim_group_picker_forward(ctx.handle, t[0], in_data[0], in_data[1], self.group_num, B, C)
         check_zoom_status(ctx, "GroupPicker")
@@ -21,7 +30,7 @@ class GroupPickerOperator(mx.operator.CustomOp):
 
     def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
         ctx = in_data[0].context
-        B, C = in_data[0].shape[0], in_data[0].shape[1]
+        B, C = _rows_cols(in_data[0].shape)
         g = in_grad[0] if req[0] in ("write", "inplace") else ctx.empty(in_grad[0].shape)
         lib.deepim_group_picker_backward(ctx.handle, g, out_grad[0], in_data[1], self.group_num, B, C)
         check_zoom_status(ctx, "GroupPicker")

@@ -47,7 +47,7 @@ def mask_logistic(logits, label, grad_scale=1.0):
 def group_picker(x, group_idx, group_num):
     x = np.asarray(x, f32)
     cg = x.shape[1] // group_num
-    out = np.zeros((x.shape[0], cg), f32)
+    out = np.zeros((x.shape[0], cg) + x.shape[2:], f32)       # group_picker.py:29-31: only the channel axis shrinks
     for b in range(x.shape[0]):
         g = int(np.squeeze(group_idx[b]))
         assert 0 <= g < group_num
@@ -58,7 +58,7 @@ def group_picker(x, group_idx, group_num):
 def group_picker_backward(out_grad, group_idx, group_num, C):
     og = np.asarray(out_grad, f32)
     cg = C // group_num
-    g_in = np.zeros((og.shape[0], C), f32)
+    g_in = np.zeros((og.shape[0], C) + og.shape[2:], f32)
     for b in range(og.shape[0]):
         g = int(np.squeeze(group_idx[b]))
         g_in[b, cg * g:cg * (g + 1)] = og[b]

@@ -204,26 +204,74 @@ def _dot3_f32(A, B):
     return ((A[:, 0:1] * B[0:1] + A[:, 1:2] * B[1:2]).astype(f32) + A[:, 2:3] * B[2:3]).astype(f32)
 
 
-def transform3d_forward(points, rotation, translation, pose_src, T_means, T_stds, rot_coord="MODEL"):
-    """transform3dOperator.forward (transform3d.py:34-97). points (B,3,N) -> (B,3,N) float32."""
+def _mm(A, B, accum):
+    """float32 GEMM under one of the two readings of MXNet's `batch_dot` (a BLAS sgemm whose order of accumulation is
+    not specified): "seq" = the K terms of an output added one at a time in float32, left to right, unfused;
+    "f64" = float64 accumulation rounded once.  Same switch as tests/golden/fake_mxnet.py:set_accum."""
+    A, B = np.asarray(A, f32), np.asarray(B, f32)
+    if accum == "f64":
+        return (A.astype(f64) @ B.astype(f64)).astype(f32)
+    out = np.zeros((A.shape[0], B.shape[1]), f32)
+    for k in range(A.shape[1]):
+        out = (out + (A[:, k:k + 1] * B[k:k + 1, :]).astype(f32)).astype(f32)
+    return out
+
+
+def _sum_last(x, accum):
+    """mx.nd.sum(x, axis=-1) of float32 data under the same two readings."""
+    x = np.asarray(x, f32)
+    if accum == "f64":
+        return x.astype(f64).sum(axis=-1).astype(f32)
+    return np.add.accumulate(x, axis=-1, dtype=f32)[..., -1]
+
+
+def _t3d_T_transform(T_src, T_delta, T_means, T_stds, rot_coord):
+    """RT_transform.py:74-95 as transform3d.py:88-93 calls it: every operand float32 (the Prop parses T_means / T_stds
+    with dtype=np.float32, transform3d.py:288-289), so the whole chain runs in float32; the float64 T_tgt it is stored
+    into holds float32 values."""
+    Ts, Td = np.asarray(T_src, f32), np.asarray(T_delta, f32)
+    mu, sd = np.asarray(T_means, f32), np.asarray(T_stds, f32)
+    assert Ts[2] != 0, "T_src: {}".format(Ts)
+    d1 = ((Td * sd).astype(f32) + mu).astype(f32)
+    z2 = f32(Ts[2] / np.exp(d1[2], dtype=f32))
+    rc = rot_coord.lower()
+    if rc in ("camera", "model"):
+        return np.array([z2 * f32(d1[0] + f32(Ts[0] / Ts[2])), z2 * f32(d1[1] + f32(Ts[1] / Ts[2])), z2], f32)
+    if rc == "camera_new":
+        return np.array([f32(f32(Ts[2] * d1[0]) + Ts[0]), f32(f32(Ts[2] * d1[1]) + Ts[1]), z2], f32)
+    raise Exception("Unknown: {}".format(rot_coord))
+
+
+def transform3d_forward(points, rotation, translation, pose_src, T_means, T_stds, rot_coord="MODEL", accum="seq",
+                        host_blas=False):
+    """transform3dOperator.forward (transform3d.py:34-97). points (B,3,N) -> (B,3,N) float32.
+    Pinned by tests/golden/ops_golden.npz (the reference file run unmodified): Rm_delta bit-exact; the output bit-exact
+    with `host_blas=True`, ~1 ulp otherwise — Rm_tgt (and NAIVE's R·T_src) go through the reference's own np.dot
+    (R_transform / T_transform_naive, RT_transform.py:47-60,98-102), i.e. whatever sgemm the host BLAS runs for a 3x3
+    product; the default restates it as an unfused sequential float32 sum, `host_blas` calls this host's np.dot."""
     points = np.asarray(points, f32)
     B = points.shape[0]
     out = np.zeros_like(points)
     rc = rot_coord.lower()
+    dot3 = (lambda A, B_: np.dot(np.asarray(A, f32), np.asarray(B_, f32))) if host_blas else _dot3_f32
     for b in range(B):
         P = np.asarray(pose_src[b], f32)
         Rd = t3d_quat2mat_forward(rotation[b])
-        Rt = _dot3_f32(P[:, :3], Rd) if rc == "model" else _dot3_f32(Rd, P[:, :3])
+        Rt = dot3(P[:, :3], Rd) if rc == "model" else dot3(Rd, P[:, :3])
         if rc == "naive":
-            Tt = (_dot3_f32(Rd, P[:, 3:4])[:, 0] + np.asarray(translation[b], f32)).astype(f32)
+            Tt = (dot3(Rd, P[:, 3:4])[:, 0] + np.asarray(translation[b], f32)).astype(f32)
         else:
-            Tt = T_transform(P[:, 3], np.asarray(translation[b], f32), T_means, T_stds, rot_coord).astype(f32)
-        out[b] = (_dot3_f32(Rt, points[b]) + Tt[:, None]).astype(f32)
+            Tt = _t3d_T_transform(P[:, 3], translation[b], T_means, T_stds, rot_coord)
+        out[b] = (_mm(Rt, points[b], accum) + Tt[:, None]).astype(f32)
     return out
 
 
-def transform3d_backward(out_grad, points, rotation, translation, pose_src, T_means, T_stds, rot_coord="MODEL"):
-    """transform3dOperator.backward (transform3d.py:99-151, :153-183, :214-281) -> (d_rot (B,4), d_trans (B,3))."""
+def transform3d_backward(out_grad, points, rotation, translation, pose_src, T_means, T_stds, rot_coord="MODEL", accum="f64"):
+    """transform3dOperator.backward (transform3d.py:99-151, :153-183, :214-281) -> (d_rot (B,4), d_trans (B,3)).
+    NumPy-1.x promotion written out: in quat2mat_backward the products of two float32 scalars are float32, a Python
+    int times a float32 scalar is float64 (`2 * x_`, `0 * D[0, 0]`), sums mixing the two are float64; the NDArray
+    arithmetic of T_transform_backward is float32 throughout.  `accum` picks the reading of the third-party reductions
+    (see _mm).  Bit-exact against the reference-run fixture under both readings (tests/test_oracle_ops_golden.py)."""
     out_grad, points = np.asarray(out_grad, f32), np.asarray(points, f32)
     B = points.shape[0]
     rc = rot_coord.lower()
@@ -231,51 +279,58 @@ def transform3d_backward(out_grad, points, rotation, translation, pose_src, T_me
     mu, sd = np.asarray(T_means, f32), np.asarray(T_stds, f32)
     for b in range(B):
         P = np.asarray(pose_src[b], f32)
-        g = out_grad[b].astype(f64)  # accumulate in float64; the device reduces in float32 (tolerance test)
-        Dt = g.sum(axis=1).astype(f32)
-        src = points[b]
-        if rc == "naive":
-            src = (_dot3_f32(P[:, :3], points[b]) + P[:, 3:4]).astype(f32)
-        Dr = (g @ src.astype(f64).T).astype(f32)
+        g = out_grad[b]
+        Dt = _sum_last(g, accum)                                   # T_tgt_diff, transform3d.py:115
         Td, Tsrc = np.asarray(translation[b], f32), P[:, 3]
         if rc == "naive":
             d_trans[b] = Dt
-        else:
-            d1 = (Td * sd + mu).astype(f32)
+        else:                                                       # T_transform_backward, :153-183 (float32 NDArray ops)
+            d1 = ((Td * sd).astype(f32) + mu).astype(f32)
             z2 = f32(Tsrc[2] / np.exp(d1[2], dtype=f32))
+            share = f32(f32(-sd[2]) * z2)
             if rc in ("camera", "model"):
-                share = f32(-sd[2] * z2)
-                d_trans[b, 0] = Dt[0] * f32(sd[0] * z2)
-                d_trans[b, 1] = Dt[1] * f32(sd[1] * z2)
-                d_trans[b, 2] = (Dt[0] * (share * (d1[0] + Tsrc[0] / Tsrc[2])) + Dt[1] * (share * (d1[1] + Tsrc[1] / Tsrc[2]))
-                                 + Dt[2] * (-sd[2] * z2))
+                d_trans[b, 0] = f32(Dt[0] * f32(sd[0] * z2))
+                d_trans[b, 1] = f32(Dt[1] * f32(sd[1] * z2))
+                a0 = f32(Dt[0] * f32(share * f32(d1[0] + f32(Tsrc[0] / Tsrc[2]))))
+                a1 = f32(Dt[1] * f32(share * f32(d1[1] + f32(Tsrc[1] / Tsrc[2]))))
+                d_trans[b, 2] = f32(f32(a0 + a1) + f32(Dt[2] * share))
             else:
-                d_trans[b, 0] = Dt[0] * f32(sd[0] * Tsrc[2])
-                d_trans[b, 1] = Dt[1] * f32(sd[1] * Tsrc[2])
-                d_trans[b, 2] = Dt[2] * (-sd[2] * z2)
-        if rc == "model":
-            D = _dot3_f32(P[:, :3].T, Dr)
-        elif rc == "naive":
-            D = Dr
+                d_trans[b, 0] = f32(Dt[0] * f32(sd[0] * Tsrc[2]))
+                d_trans[b, 1] = f32(Dt[1] * f32(sd[1] * Tsrc[2]))
+                d_trans[b, 2] = f32(Dt[2] * share)
+        # R diff, :128-141
+        Rsrc = P[:, :3]
+        if rc == "naive":
+            src = (_mm(Rsrc, points[b], accum) + P[:, 3:4]).astype(f32)
+            D = _mm(g, src.T, accum)
         else:
-            D = _dot3_f32(Dr, P[:, :3].T)
+            Dr = _mm(g, points[b].T, accum)
+            D = _mm(Rsrc.T, Dr, accum) if rc == "model" else _mm(Dr, Rsrc.T, accum)
+        # quat2mat_backward, :214-281
         q = np.asarray(rotation[b], f32)
         w, x, y, z = q
         Nq = f32(f32(f32(w * w + x * x) + y * y) + z * z)
-        if not (-1e-4 < f64(f32(Nq - f32(1))) < 1e-4):
+        if not (-1e-4 < f64(Nq) - 1.0 < 1e-4):
             continue
         Ns = f32(np.sqrt(Nq))
         w_, x_, y_, z_ = (q / Ns).astype(f32)
-        wd = (0 * D[0, 0] - z_ * D[0, 1] + y_ * D[0, 2] + z_ * D[1, 0] + 0 * D[1, 1] - x_ * D[1, 2] - y_ * D[2, 0]
-              + x_ * D[2, 1] + 0 * D[2, 2])
-        xd = (0 * D[0, 0] + y_ * D[0, 1] + z_ * D[0, 2] + y_ * D[1, 0] - 2 * x_ * D[1, 1] - w_ * D[1, 2] + z_ * D[2, 0]
-              + w_ * D[2, 1] - 2 * x_ * D[2, 2])
-        yd = (-2 * y_ * D[0, 0] + x_ * D[0, 1] + w_ * D[0, 2] + x_ * D[1, 0] + 0 * D[1, 1] + z_ * D[1, 2] - w_ * D[2, 0]
-              + z_ * D[2, 1] - 2 * y_ * D[2, 2])
-        zd = (-2 * z_ * D[0, 0] - w_ * D[0, 1] + x_ * D[0, 2] + w_ * D[1, 0] - 2 * z_ * D[1, 1] + y_ * D[1, 2] + x_ * D[2, 0]
-              + y_ * D[2, 1] + 0 * D[2, 2])
-        wD, xD, yD, zD = f64(f32(wd)) * 2.0, f64(f32(xd)) * 2.0, f64(f32(yd)) * 2.0, f64(f32(zd)) * 2.0
-        share = f64(f32(Ns * Ns * Ns)) * (f64(w) * wD + f64(x) * xD + f64(y) * yD + f64(z) * zD)
+
+        def p32(a, c):            # float32 scalar x float32 scalar
+            return f64(f32(a * c))
+
+        def p64(k, a, c):         # (python int x float32 scalar) x float32 scalar: float64 throughout
+            return (k * f64(a)) * f64(c)
+
+        wd = (0.0 - p32(z_, D[0, 1]) + p32(y_, D[0, 2]) + p32(z_, D[1, 0]) + 0.0 - p32(x_, D[1, 2]) - p32(y_, D[2, 0])
+              + p32(x_, D[2, 1]) + 0.0)
+        xd = (0.0 + p32(y_, D[0, 1]) + p32(z_, D[0, 2]) + p32(y_, D[1, 0]) - p64(2, x_, D[1, 1]) - p32(w_, D[1, 2])
+              + p32(z_, D[2, 0]) + p32(w_, D[2, 1]) - p64(2, x_, D[2, 2]))
+        yd = (p64(-2, y_, D[0, 0]) + p32(x_, D[0, 1]) + p32(w_, D[0, 2]) + p32(x_, D[1, 0]) + 0.0 + p32(z_, D[1, 2])
+              - p32(w_, D[2, 0]) + p32(z_, D[2, 1]) - p64(2, y_, D[2, 2]))
+        zd = (p64(-2, z_, D[0, 0]) - p32(w_, D[0, 1]) + p32(x_, D[0, 2]) + p32(w_, D[1, 0]) - p64(2, z_, D[1, 1])
+              + p32(y_, D[1, 2]) + p32(x_, D[2, 0]) + p32(y_, D[2, 1]) + 0.0)
+        wD, xD, yD, zD = wd * 2.0, xd * 2.0, yd * 2.0, zd * 2.0
+        share = (f64(Ns) ** 3) * (f64(w) * wD + f64(x) * xD + f64(y) * yD + f64(z) * zD)
         d_rot[b] = [f64(Ns) * wD - f64(w) * share, f64(Ns) * xD - f64(x) * share, f64(Ns) * yD - f64(y) * share,
                     f64(Ns) * zD - f64(z) * share]
     return d_rot, d_trans

@@ -2,8 +2,9 @@
 deepim/operator_py/zoom_*.py files touch, so those files can be imported UNMODIFIED from
 /root/reference and their own arithmetic lines executed to make golden vectors.
 
-TEST INFRASTRUCTURE ONLY: used by tests/golden/make_zoom_golden.py in the build container (the
-reference checkout does not exist on the GPU box). Nothing under mx_deepim_amd/ imports it.
+TEST INFRASTRUCTURE ONLY: used by tests/golden/make_zoom_golden.py and tests/golden/make_ops_golden.py
+(transform3d.py, flow_updater.py, group_picker.py) in the build container (the reference checkout does
+not exist on the GPU box). Nothing under mx_deepim_amd/ imports it.
 
 Two things live here:
 
@@ -28,7 +29,19 @@ import types
 import numpy as np
 
 f32, f64 = np.float32, np.float64
-_STATE = {"promotion": "legacy", "sample": True, "affines": []}
+# accum: how the fake's reductions (batch_dot, sum) add up — MXNet hands them to a BLAS / mshadow reduce whose order is
+# not specified, so fixtures are made under two readings: "seq" = unfused float32, left to right; "f64" = float64
+# accumulation rounded once.  py2_shapes: NDArray.shape items behave like Python-2-era integers (group_picker.py).
+_STATE = {"promotion": "legacy", "sample": True, "affines": [], "accum": "seq", "py2_shapes": False}
+
+
+def set_accum(mode):
+    assert mode in ("seq", "f64")
+    _STATE["accum"] = mode
+
+
+def set_py2_shapes(on):
+    _STATE["py2_shapes"] = bool(on)
 
 
 def set_promotion(mode):
@@ -49,13 +62,37 @@ def captured_affines(clear=True):
 
 
 # ------------------------------------------------------------------ legacy float32 scalar ----
+_BIN_UFUNCS = {np.add: lambda a, b: a + b, np.subtract: lambda a, b: a - b, np.multiply: lambda a, b: a * b,
+               np.true_divide: lambda a, b: a / b, np.power: lambda a, b: a ** b}
+_CMP_UFUNCS = {np.equal: lambda a, b: a == b, np.not_equal: lambda a, b: a != b, np.less: lambda a, b: a < b,
+               np.less_equal: lambda a, b: a <= b, np.greater: lambda a, b: a > b, np.greater_equal: lambda a, b: a >= b}
+_UNARY_UFUNCS = (np.sqrt, np.exp, np.log, np.absolute, np.negative, np.sin, np.cos)
+
+
 class LegacyF32(object):
     """np.float32 scalar with NumPy-1.x promotion against Python / int64 / float64 scalars."""
-    __array_ufunc__ = None          # make np.int64.__sub__(LegacyF32) return NotImplemented
     __slots__ = ("v",)
 
     def __init__(self, v):
         self.v = f32(v)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        """np.sqrt / np.exp of a float32 scalar stay float32 in every NumPy; a binary ufunc reached from a NumPy
+        scalar's operator (np.int64(3) - x) goes through the same promotion table as the Python operators."""
+        if method != "__call__" or kw:
+            return NotImplemented
+        if len(inputs) == 1 and ufunc in _UNARY_UFUNCS:
+            return LegacyF32(ufunc(self.v))
+        if len(inputs) == 2 and (ufunc in _BIN_UFUNCS or ufunc in _CMP_UFUNCS):
+            a, b = inputs
+            swap = a is not self
+            o = a if swap else b
+            if ufunc in _CMP_UFUNCS:
+                ov, _ = self._other(o)
+                x, y = (f64(ov), f64(self.v)) if swap else (f64(self.v), f64(ov))
+                return bool(_CMP_UFUNCS[ufunc](x, y))
+            return self._bin(o, _BIN_UFUNCS[ufunc], swap)
+        return NotImplemented
 
     @staticmethod
     def _other(o):
@@ -71,6 +108,13 @@ class LegacyF32(object):
         raise TypeError("LegacyF32: operand %r not modelled" % type(o))
 
     def _bin(self, o, fn, swap=False):
+        if isinstance(o, np.ndarray) and o.ndim > 0:
+            # NumPy-1.x value-based casting: an array of float kind keeps its dtype against any float scalar
+            if o.dtype not in (np.dtype(f32), np.dtype(f64)):
+                raise TypeError("LegacyF32: array operand of dtype %s not modelled" % o.dtype)
+            arr = np.asarray(o).view(np.ndarray)
+            r = fn(arr, self.v.astype(arr.dtype)) if swap else fn(self.v.astype(arr.dtype), arr)
+            return _as_legacy(r.astype(arr.dtype))
         ov, same = self._other(o)
         if same:
             a, b = (ov, self.v) if swap else (self.v, ov)
@@ -87,6 +131,9 @@ class LegacyF32(object):
     def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
     def __rtruediv__(self, o): return self._bin(o, lambda a, b: a / b, True)
     def __neg__(self): return LegacyF32(-self.v)
+    def __abs__(self): return LegacyF32(abs(self.v))
+    def __pow__(self, o): return self._bin(o, lambda a, b: a ** b)
+    def __rpow__(self, o): return self._bin(o, lambda a, b: a ** b, True)
 
     def _cmp(self, o, fn):
         ov, _ = self._other(o)
@@ -101,6 +148,7 @@ class LegacyF32(object):
     __hash__ = None
 
     def __float__(self): return float(self.v)
+    def __int__(self): return int(self.v)
     def __repr__(self): return "LegacyF32(%r)" % float(self.v)
     def __format__(self, spec): return format(float(self.v), spec)
 
@@ -113,6 +161,33 @@ class LegacyArray(np.ndarray):
     def __getitem__(self, idx):
         r = np.ndarray.__getitem__(self, idx)
         if isinstance(r, np.float32):
+            return LegacyF32(r)
+        return r
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        """NumPy-1.x value-based casting for array ⊕ scalar: a NumPy float64 / int64 *scalar* never widens a float32
+        array (NumPy 2 would: np.float64 scalars are strong there), so such scalars are handed on as Python
+        scalars, which NEP 50 treats as weak — the same result dtype as the old rule for these operands."""
+        conv = []
+        for x in inputs:
+            if isinstance(x, LegacyF32):
+                conv.append(x.v)
+            elif isinstance(x, LegacyArray):
+                conv.append(np.asarray(x).view(np.ndarray))
+            elif isinstance(x, np.float64):
+                conv.append(float(x))
+            elif isinstance(x, np.integer) and not isinstance(x, np.bool_):
+                conv.append(int(x))
+            else:
+                conv.append(x)
+        if "out" in kw:
+            kw["out"] = tuple(np.asarray(o).view(np.ndarray) if isinstance(o, LegacyArray) else o for o in kw["out"])
+        r = getattr(ufunc, method)(*conv, **kw)
+        if isinstance(r, np.ndarray) and r.ndim > 0 and _STATE["promotion"] == "legacy":
+            return r.view(LegacyArray)
+        if isinstance(r, np.ndarray) and r.ndim == 0:
+            r = r[()]
+        if isinstance(r, np.float32) and _STATE["promotion"] == "legacy":
             return LegacyF32(r)
         return r
 
@@ -134,6 +209,55 @@ def _plain(x):
     return x
 
 
+# ------------------------------------------------------------------------ Python-2-era ints ----
+class Py2Int(object):
+    """A shape entry as group_picker.py:22-56 needs it.  That file computes `output_shape[1] /= self.group_num` on
+    np.copy(shape) and slices with `input_shape[1] / self.group_num` under `from __future__ import division`: on the
+    NumPy of its day (< 1.10: in-place true-divide into an int array cast back unsafely; < 1.12: float indices
+    accepted with a DeprecationWarning) both yield the integer quotient; on NumPy 2 / Python 3 both raise.  This
+    object is an integer whose true division, when exact, is again that integer — and refuses inexact division."""
+    __slots__ = ("i",)
+
+    def __init__(self, i):
+        self.i = int(i)
+
+    def __index__(self): return self.i
+    def __int__(self): return self.i
+    def __repr__(self): return "Py2Int(%d)" % self.i
+    def __hash__(self): return hash(self.i)
+    def _v(self, o): return o.i if isinstance(o, Py2Int) else o
+
+    def __truediv__(self, o):
+        o = int(self._v(o))
+        if self.i % o:
+            raise TypeError("Py2Int: inexact division %d / %d (the reference asserts divisibility)" % (self.i, o))
+        return Py2Int(self.i // o)
+
+    def __mod__(self, o): return self.i % int(self._v(o))
+    def __mul__(self, o): return Py2Int(self.i * int(self._v(o)))
+    __rmul__ = __mul__
+    def __add__(self, o): return Py2Int(self.i + int(self._v(o)))
+    __radd__ = __add__
+    def __sub__(self, o): return Py2Int(self.i - int(self._v(o)))
+    def __eq__(self, o): return self.i == self._v(o)
+    def __ne__(self, o): return self.i != self._v(o)
+    def __lt__(self, o): return self.i < self._v(o)
+    def __le__(self, o): return self.i <= self._v(o)
+    def __gt__(self, o): return self.i > self._v(o)
+    def __ge__(self, o): return self.i >= self._v(o)
+
+
+class Py2Shape(tuple):
+    def __new__(cls, shape):
+        return tuple.__new__(cls, [Py2Int(v) for v in shape])
+
+
+def _int_shape(shape):
+    if isinstance(shape, np.ndarray):
+        shape = shape.tolist()
+    return tuple(int(v) for v in shape)
+
+
 # ------------------------------------------------------------------------------ NDArray ----
 class NDArray(object):
     """float32 device array stand-in (MXNet's default dtype)."""
@@ -143,7 +267,13 @@ class NDArray(object):
         self.context = ctx
 
     @property
-    def shape(self): return self.a.shape
+    def shape(self):
+        if _STATE["py2_shapes"]:
+            return Py2Shape(self.a.shape)
+        return self.a.shape
+
+    @property
+    def dtype(self): return self.a.dtype
     def asnumpy(self): return _as_legacy(self.a)
     def reshape(self, shape): return NDArray(self.a.reshape(shape), self.context)
     def copy(self): return NDArray(self.a.copy(), self.context)
@@ -159,6 +289,12 @@ class NDArray(object):
     def __sub__(self, o): return NDArray(self.a - self._scalar(o), self.context)
     def __mul__(self, o): return NDArray(self.a * self._scalar(o), self.context)
     def __truediv__(self, o): return NDArray(self.a / self._scalar(o), self.context)
+
+    def __radd__(self, o): return NDArray(self._scalar(o) + self.a, self.context)
+    def __rsub__(self, o): return NDArray(self._scalar(o) - self.a, self.context)
+    def __rmul__(self, o): return NDArray(self._scalar(o) * self.a, self.context)
+    def __rtruediv__(self, o): return NDArray(self._scalar(o) / self.a, self.context)
+    def __neg__(self): return NDArray(-self.a, self.context)
 
     def __iadd__(self, o): self.a += self._scalar(o); return self
     def __isub__(self, o): self.a -= self._scalar(o); return self
@@ -195,7 +331,85 @@ def _nd_array(src, ctx=None, dtype=f32):
 
 
 def _nd_zeros(shape, ctx=None, dtype=f32):
-    return NDArray(np.zeros(tuple(shape), f32), ctx)
+    return NDArray(np.zeros(_int_shape(shape) if not isinstance(shape, int) else (shape,), f32), ctx)
+
+
+def _nd_ones(shape, ctx=None, dtype=f32):
+    return NDArray(np.ones(_int_shape(shape), f32), ctx)
+
+
+def _nd_zeros_like(x, ctx=None, dtype=f32):
+    return NDArray(np.zeros_like(x.a), x.context)
+
+
+def _slice_axis(x, axis, begin, end):
+    idx = [slice(None)] * x.a.ndim
+    idx[axis] = slice(begin, end)
+    return NDArray(x.a[tuple(idx)].copy(), x.context)
+
+
+def _expand_dims(x, axis):
+    return NDArray(np.expand_dims(x.a, axis), x.context)
+
+
+def _nd_add(a, b):
+    return NDArray(a.a + b.a, a.context)          # elementwise float32 with NumPy broadcasting (broadcast_add)
+
+
+def _broadcast_mul(a, b):
+    return NDArray(a.a * b.a, a.context)
+
+
+def _seq_matmul(A, B):
+    """float32 GEMM, the K terms of every output added one at a time, left to right, no fusion"""
+    out = np.zeros(A.shape[:-1] + (B.shape[-1],), f32)
+    for k in range(A.shape[-1]):
+        out = (out + (A[..., :, k:k + 1] * B[..., k:k + 1, :]).astype(f32)).astype(f32)
+    return out
+
+
+def _batch_dot(a, b, transpose_a=False, transpose_b=False):
+    """mx.nd.batch_dot: per-sample GEMM (MXNet: a batched BLAS sgemm; accumulation order unspecified → two readings)."""
+    A = np.swapaxes(a.a, 1, 2) if transpose_a else a.a
+    B = np.swapaxes(b.a, 1, 2) if transpose_b else b.a
+    if _STATE["accum"] == "f64":
+        return NDArray(np.matmul(A.astype(f64), B.astype(f64)).astype(f32), a.context)
+    return NDArray(_seq_matmul(A, B), a.context)
+
+
+def _nd_sum(x, axis=None):
+    if _STATE["accum"] == "f64":
+        return NDArray(x.a.astype(f64).sum(axis=axis).astype(f32), x.context)
+    acc = np.add.accumulate(x.a, axis=axis, dtype=f32)      # strictly sequential float32
+    return NDArray(np.take(acc, -1, axis=axis), x.context)
+
+
+def _nd_transpose(x, axes=None):
+    return NDArray(np.transpose(x.a, axes), x.context)
+
+
+def _nd_exp(x):
+    return NDArray(np.exp(x.a), x.context)        # MXNet: expf per element; NumPy's float32 exp (third-party either way)
+
+
+def _nd_concat(*xs, **kw):
+    return NDArray(np.concatenate([x.a for x in xs], axis=kw.get("dim", 1)), xs[0].context)
+
+
+def _nd_split(x, axis=1, num_outputs=1):
+    return [NDArray(p, x.context) for p in np.split(x.a, num_outputs, axis=axis)]
+
+
+def _nd_tile(x, reps):
+    return NDArray(np.tile(x.a, reps), x.context)
+
+
+def _scalar_or_nd(v):
+    return v.a if isinstance(v, NDArray) else f32(float(v))      # *_scalar ops: the attr is cast to DType
+
+
+def _minimum(a, b):
+    return NDArray(np.minimum(_scalar_or_nd(a), _scalar_or_nd(b)), a.context if isinstance(a, NDArray) else b.context)
 
 
 def _grid_generator(data, transform_type="affine", target_shape=None):
@@ -266,7 +480,7 @@ def _round(x):
 
 
 def _maximum(a, b):
-    return NDArray(np.maximum(a.a, b.a), a.context)
+    return NDArray(np.maximum(_scalar_or_nd(a), _scalar_or_nd(b)), a.context if isinstance(a, NDArray) else b.context)
 
 
 # -------------------------------------------------------------------- operator protocol ----
@@ -309,7 +523,11 @@ def install():
     mx = types.ModuleType("mxnet")
     nd = types.ModuleType("mxnet.ndarray")
     for name, fn in (("array", _nd_array), ("zeros", _nd_zeros), ("GridGenerator", _grid_generator),
-                     ("BilinearSampler", _bilinear_sampler), ("round", _round), ("maximum", _maximum)):
+                     ("BilinearSampler", _bilinear_sampler), ("round", _round), ("maximum", _maximum),
+                     ("minimum", _minimum), ("ones", _nd_ones), ("zeros_like", _nd_zeros_like), ("slice_axis", _slice_axis),
+                     ("expand_dims", _expand_dims), ("add", _nd_add), ("broadcast_mul", _broadcast_mul),
+                     ("batch_dot", _batch_dot), ("sum", _nd_sum), ("transpose", _nd_transpose), ("exp", _nd_exp),
+                     ("concat", _nd_concat), ("split", _nd_split), ("tile", _nd_tile)):
         setattr(nd, name, fn)
     nd.NDArray = NDArray
     op = types.ModuleType("mxnet.operator")
