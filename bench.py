@@ -50,7 +50,7 @@ def encoder_flops_per_pair(cin=8, H=480, W=640):
     return total
 
 
-def cpu_baseline(params, cfg, batch, budget_s=12.0):
+def cpu_baseline(params, cfg, batch, budget_s=12.0, with_depth=False):
     """Oracle ('port' of the reference CPU path; MXNet itself is not installable offline) timed on the host cores over a
     bounded sample of the same workload: whole pair-iterations until `budget_s` seconds of CPU work are spent."""
     from oracle import pipeline as opipe
@@ -63,6 +63,8 @@ def cpu_baseline(params, cfg, batch, budget_s=12.0):
         data = {"image_observed": batch["image_observed"][b:b + 1], "image_rendered": batch["image_rendered"][0][b:b + 1],
                 "mask_observed": batch["mask_observed"][b:b + 1], "mask_rendered": batch["mask_rendered"][0][b:b + 1],
                 "src_pose": batch["src_pose"][0][b:b + 1]}
+        if with_depth:
+            data.update(depth_observed=batch["depth_gt_observed"][b:b + 1], depth_rendered=batch["depth_rendered"][0][b:b + 1])
         opipe.refine_iteration(params, data, batch["K"], means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds,
                                cfg.network.ROT_COORD)
         pairs += 1
@@ -102,6 +104,74 @@ def cpu_onednn_secondary(cfg, seconds=8.0, pairs=4):
             "kind": "secondary: torch-CPU (oneDNN) conv stack + fc6/fc7 only, batch %d, %d forwards in %.1f s" % (pairs, n, dt)}
 
 
+def verify_parity(args, cfg, net, params, ctx, step, pose_cur, K, B):
+    """Parity of the configuration that was just timed (same context, same plans, same batch): one more step with taps
+    that copy, for `--verify` sampled pairs, the inputs of every refinement iteration (observed frame, the frame the GPU
+    rendered, masks, [depth], the src pose of that iteration) and its outputs; each iteration is then replayed through the
+    CPU oracle on exactly those inputs (tests/test_gpu_baseline_configs.py does the same at B = 4).  TEST-SIDE use of
+    oracle/: checker only, after the timed region."""
+    from oracle import pipeline as opipe
+    from oracle import zoom as oz
+    idx = sorted(set(int(i) for i in np.linspace(0, B - 1, max(1, args.verify))))
+    in_keys = ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "depth_observed", "depth_rendered", "src_pose")
+    out_keys = ["zoom_factor", "se3", "net_input"] + (["flow_est", "mask_observed_pred"] if args.heads else [])
+    snaps = {}
+
+    def rows(a):
+        return np.concatenate([a[i:i + 1].asnumpy() for i in idx])
+
+    def tap(kind, it, data):
+        if kind == "in":
+            snaps[it] = {k: rows(data[k]) for k in in_keys if data.get(k) is not None}
+        else:
+            snaps[it]["out"] = {k: rows(net.act[k]) for k in out_keys}
+            snaps[it]["out"]["pose_est"] = rows(pose_cur)
+            zi = ctx.empty((B, 2, net.H, net.W), dtype=np.int32)
+            lib.deepim_zoom_indices(ctx.handle, net.act["zoom_factor"], zi, B, net.H, net.W)
+            snaps[it]["out"]["zoom_idx"] = rows(zi)
+
+    step(tap=tap)
+    ctx.sync()
+    means_rev = np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a, np.float64) - b).max() / max(1e-30, np.abs(b).max()))
+
+    res = {"pairs": len(idx), "pair_index": idx, "iters": len(snaps), "pose_max_rel": 0.0, "se3_max_rel": 0.0,
+           "zoom_factor_bit_exact": True, "zoom_idx_bit_exact": True, "net_input_bit_exact": True}
+    if args.heads:
+        res.update(flow_max_rel=0.0, mask_flip_frac=0.0)
+    t0 = time.time()
+    for it in sorted(snaps):
+        d = {k: v for k, v in snaps[it].items() if k != "out"}
+        got = snaps[it]["out"]
+        ref = opipe.refine_iteration(params, d, K, means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds,
+                                     cfg.network.ROT_COORD, heads=bool(args.heads), fp16_conv=bool(args.fp16), nc8=True)
+        res["pose_max_rel"] = max(res["pose_max_rel"], rel(got["pose_est"], ref["pose_est"]))
+        res["se3_max_rel"] = max(res["se3_max_rel"], rel(got["se3"], ref["se3"]))
+        res["zoom_factor_bit_exact"] &= bool(np.array_equal(got["zoom_factor"], ref["zoom_factor"]))
+        res["net_input_bit_exact"] &= bool(np.array_equal(got["net_input"], ref["net_input"]))
+        res["zoom_idx_bit_exact"] &= bool(np.array_equal(got["zoom_idx"], oz.sample_indices(ref["zoom_factor"], net.H, net.W)))
+        if args.heads:
+            res["flow_max_rel"] = max(res["flow_max_rel"], rel(got["flow_est"], ref["flow_est"]))
+            res["mask_flip_frac"] = max(res["mask_flip_frac"], float(np.mean(got["mask_observed_pred"] != ref["mask_observed_pred"])))
+    if args.fp16:
+        res["against"] = "oracle fp16 emulation (oracle/pipeline.py:encoder_fp16: fp16-rounded operands and outputs, fp32 accumulation)"
+        res["bar"] = {"pose_max_rel": 2e-3, "se3_max_rel": 5e-3}
+    else:
+        res["against"] = "CPU oracle, fp32 (float64-accumulating convolutions in the NC8 summation order), every iteration fed the GPU's own inputs"
+        res["bar"] = {"pose_max_rel": 1e-4, "se3_max_rel": 1e-4, "zoom": "bit-exact"}
+        if args.heads:
+            res["bar"].update(flow_max_rel=1e-4, mask_flip_frac=1e-4)
+    ok = res["pose_max_rel"] <= res["bar"]["pose_max_rel"] and res["se3_max_rel"] <= res["bar"]["se3_max_rel"] and \
+        res["zoom_factor_bit_exact"] and res["zoom_idx_bit_exact"] and res["net_input_bit_exact"]
+    if args.heads and not args.fp16:
+        ok = ok and res["flow_max_rel"] <= 1e-4 and res["mask_flip_frac"] <= 1e-4
+    res["within_bar"] = bool(ok)
+    res["oracle_seconds"] = time.time() - t0
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +199,16 @@ def main():
                     "the first call instead of using the deterministic cost-model plan")
     ap.add_argument("--prestaged", action="store_true", help="feed pre-staged rendered frames instead of re-rendering "
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
+    ap.add_argument("--depth", action="store_true", help="BASELINE config 5 input as written: RGB-D pairs, network.INPUT_DEPTH "
+                    "(ZoomDepth of observed + rendered depth inside the timed front end, C_in = 10)")
+    ap.add_argument("--verify", type=int, default=2, help="parity of THIS configuration, outside the timed region, N=1 only: "
+                    "after the timed loop one more step is run and for this many sampled pairs every one of its refinement "
+                    "iterations is replayed through the CPU oracle (fed the frames the GPU rendered) → `parity` in the JSON "
+                    "line; 0 = off")
+    ap.add_argument("--extras-budget", type=float, default=200.0, help="wall-clock budget in seconds for everything after the "
+                    "timed region (parity, CPU baseline, other configs); what does not fit is reported as skipped")
     args = ap.parse_args()
+    t_start_extras = [None]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +237,7 @@ def main():
     cfg = default_config()
     cfg.network.FP16_CONV = bool(args.fp16)
     cfg.network.X3_CONV = bool(args.x3)
+    cfg.network.INPUT_DEPTH = bool(args.depth)
     if args.heads:
         cfg.TEST.FAST_TEST = False
     net = deepIM_flownet().get_symbol(cfg)
@@ -169,13 +249,17 @@ def main():
     # only the pre-staged mode needs the later frames ray-cast on the host; the closed loop renders them on the device
     nfr = NIT if args.prestaged else 1
     if args.global_batch:   # every rank builds the same global batch and keeps its block (contiguous blocks)
-        batch = parallel.shard_pairs(synthetic.make_batch(args.global_batch, seed=2333, n_frames=nfr, with_depth=False),
+        batch = parallel.shard_pairs(synthetic.make_batch(args.global_batch, seed=2333, n_frames=nfr, with_depth=args.depth),
                                      world, rank, args.global_batch)
     else:
-        batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=nfr, with_depth=False)
+        batch = synthetic.make_batch(B, seed=2333 + rank, n_frames=nfr, with_depth=args.depth)
     image_observed = ctx.array(batch["image_observed"])
+    depth_observed = ctx.array(batch["depth_gt_observed"]) if args.depth else None
     frames = [{"image_rendered": ctx.array(batch["image_rendered"][f]), "mask_rendered": ctx.array(batch["mask_rendered"][f]),
                "mask_observed": ctx.array(batch["mask_observed_frames"][f])} for f in range(nfr)]
+    if args.depth:
+        for f in range(nfr):
+            frames[f]["depth_rendered"] = ctx.array(batch["depth_rendered"][f])
     pose_init = ctx.array(batch["src_pose"][0])
     pose_cur = ctx.empty((B, 3, 4))
     # closed loop (tester.py:420-455): re-render at the refined pose on the device between iterations
@@ -195,13 +279,17 @@ def main():
     zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
     render_timers = [[ctx.timer() for _ in range(NIT - 1)] for _ in range(args.steps)]
 
-    def step(timers=None, ztimers=None, rtimers=None):
+    def step(timers=None, ztimers=None, rtimers=None, tap=None):
         lib.deepim_d2d(h, pose_cur, pose_init, pose_cur.nbytes)
         data = {"image_observed": image_observed, "src_pose": pose_cur}
+        if args.depth:
+            data["depth_observed"] = depth_observed
         data.update(frames[0])
         for it in range(NIT):
             if args.prestaged:
                 data.update(frames[it])
+            if tap is not None:
+                tap("in", it, data)
             if ztimers:
                 ztimers[it].start()
             net.zoom(data)
@@ -217,6 +305,8 @@ def main():
                 net.heads()
             net.pose_head()
             net.pose_update(pose_cur, pose_cur)   # refined pose becomes the next iteration's src_pose
+            if tap is not None:
+                tap("out", it, data)
             if world > 1:                          # every rank/host gets all refined poses
                 src = pose_cur
                 if B != Bmax:
@@ -290,7 +380,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": "f16" if args.fp16 else ("f16x3" if args.x3 else "f32"), "data": "synthetic",
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, %s, %d refinement iters, 480x640, "
-                                   "%s (8-ch input), %s" % ("global batch %d sharded %d per GPU" % (args.global_batch, Bmax) if args.global_batch else "batch %d per GPU" % B, NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph", "pre-staged rendered frames (render excluded)"
+                                   "%s (" + ("RGB-D, 10-ch input incl. ZoomDepth" if args.depth else "8-ch input") + "), %s" % ("global batch %d sharded %d per GPU" % (args.global_batch, Bmax) if args.global_batch else "batch %d per GPU" % B, NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph", "pre-staged rendered frames (render excluded)"
                                    if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT,
                        "parallelism": "pairs sharded across %d GPU(s), one process per GPU, one ncclAllGather (RCCL) of the "
@@ -311,44 +401,85 @@ def main():
         }
         if not args.prestaged and NIT > 1:
             out["render_ms"] = float(np.mean([t.elapsed_ms() for row in render_timers for t in row]))
+        # ---- everything below is OUTSIDE the timed region and bounded by --extras-budget; the headline above is
+        # complete already, and is printed even if the process is told to stop while the extras run
+        emitted = [False]
+
+        def emit(*_sig):
+            if not emitted[0]:
+                emitted[0] = True
+                print(json.dumps(out))
+                sys.stdout.flush()
+            if _sig:
+                os._exit(0)
+        import signal
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(sg, emit)
+        deadline = time.time() + args.extras_budget
+
+        def left():
+            return deadline - time.time()
         if args.layers:
             out["layers"] = layer_timings(ctx, net)
+        if world == 1 and args.verify > 0:
+            try:
+                out["parity"] = verify_parity(args, cfg, net, params, ctx, step, pose_cur, batch["K"], B)
+            except Exception as e:                       # a checker failure must not lose the measured line — but it is loud
+                out["parity"] = {"error": repr(e)[:300], "within_bar": False}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, cfg, batch)
-            if not args.no_cpu_onednn:
+            out["cpu_baseline"] = cpu_baseline(params, cfg, batch, with_depth=args.depth)
+        default_run = (world == 1 and not (args.fp16 or args.x3 or args.heads or args.prestaged or args.global_batch or args.layers
+                                           or args.depth)
+                       and args.batch == 32 and not args.no_other_configs and not args.no_cpu_baseline)
+        if default_run:
+            out["other_configs"] = other_configs(left)
+        if world == 1 and not args.no_cpu_baseline and not args.no_cpu_onednn:
+            if left() > 25:
                 try:
                     out["cpu_baseline"]["secondary_onednn"] = cpu_onednn_secondary(cfg)
                 except ImportError as e:       # torch is test/bench tooling only; the figure is optional
                     out["cpu_baseline"]["secondary_onednn"] = {"skipped": str(e)}
-        default_run = (world == 1 and not (args.fp16 or args.x3 or args.heads or args.prestaged or args.global_batch or args.layers)
-                       and args.batch == 32 and not args.no_other_configs and not args.no_cpu_baseline)
-        if default_run:
-            out["other_configs"] = other_configs()
-        print(json.dumps(out))
+            else:
+                out["cpu_baseline"]["secondary_onednn"] = {"skipped": "extras budget spent"}
+        emit()
     if comm is not None:
         comm.close()
     rdzv.close()
 
 
-def other_configs():
+def other_configs(left=lambda: 1e9):
     """Short secondary runs (separate processes, after the timed region of the headline) of the other BASELINE.json
     configurations on this GPU, so that they are measured by the same driver command: configs[1] (batch 16), the per-GPU share
-    of configs[2] (batch 4), configs[3] (decoder + mask / flow heads in every iteration) and configs[4] (fp16 conv path at
-    its per-GPU share, batch 8). Each entry: value (it/s), ms_per_step, conv-stack TFLOP/s and its fraction of the peak."""
+    of configs[2] (batch 4), configs[3] (decoder + mask / flow heads in every iteration) and configs[4] AS WRITTEN (RGB-D pairs,
+    INPUT_DEPTH, fp16 conv path) at its per-GPU share (batch 8) and at batch 32. Each entry: value (it/s), ms_per_step,
+    conv-stack TFLOP/s and its fraction of the peak, and — where the run carries one — its own `parity` block.
+    `left()` = seconds of the extras budget still available; runs that no longer fit are reported as skipped."""
     import subprocess
-    runs = {"configs[1]_ape_batch16": ["--batch", "16"], "configs[2]_per_gpu_share_batch4": ["--batch", "4"],
-            "configs[3]_decoder_mask_flow_heads_batch32": ["--heads"], "configs[4]_fp16_conv_per_gpu_share_batch8": ["--fp16", "--batch", "8"],
-            "fp16_conv_batch32": ["--fp16"], "split_fp16_x3_conv_batch32": ["--x3"], "split_fp16_x3_conv_batch4": ["--x3", "--batch", "4"],
-            "configs[3]_heads_split_fp16_x3_batch32": ["--x3", "--heads"]}
+    runs = [("configs[1]_ape_batch16", ["--batch", "16", "--verify", "1"]),
+            ("configs[2]_per_gpu_share_batch4", ["--batch", "4", "--verify", "1"]),
+            ("configs[3]_decoder_mask_flow_heads_batch32", ["--heads", "--verify", "1"]),
+            ("configs[4]_rgbd_fp16_conv_per_gpu_share_batch8", ["--fp16", "--depth", "--batch", "8", "--verify", "1"]),
+            ("configs[4]_rgbd_fp16_conv_batch32", ["--fp16", "--depth", "--verify", "0"]),
+            ("fp16_conv_8ch_batch32", ["--fp16", "--verify", "0"]),
+            ("split_fp16_x3_conv_batch32", ["--x3", "--verify", "1"]),
+            ("split_fp16_x3_conv_batch4", ["--x3", "--batch", "4", "--verify", "0"]),
+            ("configs[3]_heads_split_fp16_x3_batch32", ["--x3", "--heads", "--verify", "0"])]
     res = {}
-    for name, extra in runs.items():
+    for name, extra in runs:
+        if left() < 30:
+            res[name] = {"skipped": "extras budget spent"}
+            continue
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
-                                "--no-other-configs"] + extra, capture_output=True, text=True, timeout=240)
+                                "--no-other-configs"] + extra, capture_output=True, text=True, timeout=max(30.0, min(150.0, left())))
             j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
                          "workload": j["config"]["workload"], "conv_tflops": j["roofline"]["achieved"],
                          "conv_peak_tflops": j["roofline"]["peak"], "conv_frac": j["roofline"]["frac"]}
+            if "parity" in j:
+                res[name]["parity"] = {k: j["parity"].get(k) for k in ("pairs", "iters", "pose_max_rel", "se3_max_rel", "flow_max_rel",
+                                                                        "mask_flip_frac", "zoom_idx_bit_exact", "net_input_bit_exact",
+                                                                        "within_bar", "bar", "error") if k in j["parity"]}
             if "--x3" in extra:
                 res[name]["arithmetic"] = ("conv2-conv6_1 and conv1 as hi*hi + hi*lo + lo*hi on fp16 (hi, lo) pairs, fp32 accumulation: "
                                            "every layer <= 1e-5 of the fp32 oracle (observed 2.4e-6), pose ~1e-6 (north_star bar 1e-4), "

@@ -23,8 +23,8 @@ def _last_json(out):
 
 
 def test_bench_line_single_gpu():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+                        "--verify", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for k in REQUIRED:
@@ -35,6 +35,42 @@ def test_bench_line_single_gpu():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 0 < rf["frac"] < 1 and d["config"]["workload"]
+
+
+@pytest.mark.parametrize("extra,bar", [([], 1e-4), (["--batch", "16"], 1e-4)], ids=["bs32_headline", "bs16_configs1"])
+def test_bench_reports_parity_of_the_timed_configuration(extra, bar):
+    """BASELINE.md §3's "max rel. error vs oracle" column, measured by bench.py itself on the configuration it times:
+    B = 32 (the headline) and B = 16 (configs[1]) under the DEFAULT split-K plan, all 4 closed-loop iterations of two
+    sampled pairs replayed through the CPU oracle.  Bars: pose and se3 <= 1e-4 relative, zoom factors / crop indices /
+    net input bit-exact."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+                        "--verify", "2"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    p = d["parity"]
+    print("bench parity %s: pose %.2e se3 %.2e (pairs %s, %d iterations, oracle %.0f s)" % (
+        extra, p["pose_max_rel"], p["se3_max_rel"], p["pair_index"], p["iters"], p["oracle_seconds"]))
+    assert "error" not in p, p
+    assert p["pairs"] == 2 and p["iters"] == 4
+    assert p["pose_max_rel"] <= bar and p["se3_max_rel"] <= bar
+    assert p["zoom_factor_bit_exact"] and p["zoom_idx_bit_exact"] and p["net_input_bit_exact"] and p["within_bar"]
+
+
+def test_bench_parity_heads_and_config5_modes():
+    """The same field for `--heads` (config 4 mode: + flow <= 1e-4, mask flips <= 1e-4 of the pixels) and for config 5 as
+    written (`--fp16 --depth`: RGB-D input, against the oracle's fp16 emulation, bars 2e-3 / 5e-3)."""
+    for extra in (["--heads", "--batch", "4"], ["--fp16", "--depth", "--batch", "8"]):
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+                            "--verify", "1"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _last_json(r.stdout)
+        p = d["parity"]
+        print("bench parity %s: %s" % (extra, {k: v for k, v in p.items() if k not in ("against", "bar")}))
+        assert "error" not in p and p["within_bar"], p
+        if "--depth" in extra:
+            assert d["dtype"] == "f16" and "RGB-D" in d["config"]["workload"] and p["net_input_bit_exact"]
+        else:
+            assert p["flow_max_rel"] <= 1e-4 and p["mask_flip_frac"] <= 1e-4
 
 
 def _run_two_ranks(port, extra):
