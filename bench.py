@@ -172,6 +172,76 @@ def verify_parity(args, cfg, net, params, ctx, step, pose_cur, K, B):
     return res
 
 
+def headline(args, world, B, Bmax, NIT, dt, pairs_total):
+    """The part of the JSON line that does not depend on device measurements (shared by the real run and --dry-run)."""
+    iters_total = pairs_total * NIT * args.steps
+    return {
+        "metric": "pose-refinement iters/sec (%d-iter loop, 480x640, bs%d)" % (NIT, args.global_batch or B),
+        "value": iters_total / dt,
+        "unit": "pose-refinement iters/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+        "dtype": "f16" if args.fp16 else ("f16x3" if args.x3 else "f32"), "data": "synthetic",
+    }
+
+
+def dry_run(args, rank, world, rdzv):
+    """No GPU: every rank owns its block of a global pose table; one 'refinement' = pose += 1 on the host; the per-iteration
+    exchange, the ragged padding, the barrier-bracketed timing, the max over ranks and the rank-0 line are bench.py's own."""
+    NIT = args.iters
+    if args.global_batch:
+        lo, hi = parallel.shard_bounds(args.global_batch, world, rank)
+        counts = parallel.shard_counts(args.global_batch, world)
+        B, Bmax, total = hi - lo, max(counts), args.global_batch
+        assert B > 0, "more GPUs than pairs"
+    else:
+        B = Bmax = args.batch
+        lo, counts, total = rank * B, [B] * world, world * B
+    if world > 1:       # the RCCL bootstrap's host half (parallel.PoseComm.__init__): rank 0's 128-byte id reaches every rank
+        uid = rdzv.broadcast(bytes(range(128)) if rank == 0 else None, 0)
+        assert isinstance(uid, bytes) and uid == bytes(range(128))
+    table = np.arange(total * 12, dtype=np.float32).reshape(total, 3, 4)
+    pose = table[lo:lo + B].copy()
+    gathered = None
+
+    def step():
+        nonlocal pose, gathered
+        pose = table[lo:lo + B].copy()
+        for it in range(NIT):
+            pose = pose + np.float32(1.0)
+            if world > 1:
+                src = np.zeros((Bmax, 3, 4), np.float32)
+                src[:B] = pose
+                gathered = np.concatenate(rdzv.all_gather(src), 0)
+
+    for _ in range(1 + args.warmup):
+        step()
+    rdzv.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    rdzv.barrier()
+    dt = rdzv.max(time.perf_counter() - t0) if world > 1 else time.perf_counter() - t0
+    if world > 1:                                   # gather order: rank-major, each rank's block at r * Bmax, padding zero
+        got = gathered.reshape(world, Bmax, 12)
+        off = 0
+        for r in range(world):
+            want = (table[off:off + counts[r]] + np.float32(NIT)).reshape(counts[r], 12)
+            assert np.array_equal(got[r, :counts[r]], want), "all-gather returned wrong poses for rank %d" % r
+            assert not got[r, counts[r]:].any()
+            off += counts[r]
+    if rank == 0:
+        out = headline(args, world, B, Bmax, NIT, dt, total)
+        out["config"] = {"workload": "DRY RUN (no GPU): launch rehearsal of the %d-rank path" % world, "pairs_per_gpu": B,
+                         "global_batch": total, "iters": NIT, "shard_counts": counts}
+        out["roofline"] = None
+        out["dry_run"] = True
+        print(json.dumps(out))
+        sys.stdout.flush()
+    rdzv.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +271,9 @@ def main():
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     ap.add_argument("--depth", action="store_true", help="BASELINE config 5 input as written: RGB-D pairs, network.INPUT_DEPTH "
                     "(ZoomDepth of observed + rendered depth inside the timed front end, C_in = 10)")
+    ap.add_argument("--dry-run", action="store_true", help="launch rehearsal without a GPU: the same rank / rendezvous / shard / "
+                    "per-iteration pose all-gather (host backend) / max-over-ranks / one-JSON-line-from-rank-0 code path with a "
+                    "host stand-in for the refinement step; the line carries \"dry_run\": true and no roofline")
     ap.add_argument("--verify", type=int, default=2, help="parity of THIS configuration, outside the timed region, N=1 only: "
                     "after the timed loop one more step is run and for this many sampled pairs every one of its refinement "
                     "iterations is replayed through the CPU oracle (fed the frames the GPU rendered) → `parity` in the JSON "
@@ -221,6 +294,8 @@ def main():
     lib.load().deepim_device_count(ctypes.byref(ndev))
     device_id = local_rank % max(1, ndev.value)
     rdzv = parallel.Rendezvous(rank, world)          # no-op at world == 1
+    if args.dry_run:
+        return dry_run(args, rank, world, rdzv)
 
     ctx = Context.get(device_id)
     h = ctx.handle
@@ -356,7 +431,6 @@ def main():
 
     if rank == 0:
         pairs_total = args.global_batch if args.global_batch else world * B
-        iters_total = pairs_total * NIT * args.steps
         enc_ms = float(np.mean([t.elapsed_ms() for row in enc_timers for t in row]))
         zoom_ms = float(np.mean([t.elapsed_ms() for row in zoom_timers for t in row]))
         flops = encoder_flops_per_pair(net.cin) * B
@@ -371,21 +445,18 @@ def main():
             tj = json.load(open(tpath)).get(("x3_B%d" if args.x3 else "B%d") % B)
             if tj:
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
-        out = {
-            "metric": "pose-refinement iters/sec (%d-iter loop, 480x640, bs%d)" % (NIT, args.global_batch or B),
-            "value": iters_total / dt,
-            "unit": "pose-refinement iters/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
-            "dtype": "f16" if args.fp16 else ("f16x3" if args.x3 else "f32"), "data": "synthetic",
-            "config": {"workload": "LINEMOD-ape-like synthetic pairs, %s, %d refinement iters, 480x640, "
-                                   "%s (" + ("RGB-D, 10-ch input incl. ZoomDepth" if args.depth else "8-ch input") + "), %s" % ("global batch %d sharded %d per GPU" % (args.global_batch, Bmax) if args.global_batch else "batch %d per GPU" % B, NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph", "pre-staged rendered frames (render excluded)"
-                                   if args.prestaged else "closed loop: on-device re-render + mask update between iterations"),
+        out = headline(args, world, B, Bmax, NIT, dt, pairs_total)
+        out.update({
+            "config": {"workload": "LINEMOD-ape-like synthetic pairs, %s, %d refinement iters, 480x640, %s (%s), %s" % (
+                           "global batch %d sharded %d per GPU" % (args.global_batch, Bmax) if args.global_batch else "batch %d per GPU" % B,
+                           NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph",
+                           "RGB-D, 10-ch input incl. ZoomDepth" if args.depth else "8-ch input",
+                           "pre-staged rendered frames (render excluded)" if args.prestaged else
+                           "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT,
                        "parallelism": "pairs sharded across %d GPU(s), one process per GPU, one ncclAllGather (RCCL) of the "
                                       "refined poses per iteration on the compute stream, no torch" % world},
-            "roofline": {"bound": "mfma", "kernel": ("conv_f16_kernel" if args.fp16 else "conv_f16_dma_kernel<X3> (conv2-conv6_1: 3 fp16 "
+            "roofline": {"bound": "mfma", "kernel": ("conv_f16_dma_kernel / conv1 patch kernel (fp16 MFMA 32x32x16)" if args.fp16 else "conv_f16_dma_kernel<X3> (conv2-conv6_1: 3 fp16 "
                                                       "MFMAs per product; peak = 2.5 PF / 3) + conv_direct_kernel (conv1, fp32)"
                                                       if args.x3 else "conv_nc8_kernel / conv_direct_kernel") +
                          " (10 encoder launches per iteration incl. split-K reduces)",
@@ -398,7 +469,7 @@ def main():
                               "note": "algorithmic bytes = read + write of every zoomed channel once (SURVEY 8d); the fused "
                                       "front end keeps BilinearSampler's float/double blend bit for bit (VALU work ~ the "
                                       "HBM time), see DESIGN.md section 3"},
-        }
+        })
         if not args.prestaged and NIT > 1:
             out["render_ms"] = float(np.mean([t.elapsed_ms() for row in render_timers for t in row]))
         # ---- everything below is OUTSIDE the timed region and bounded by --extras-budget; the headline above is

@@ -191,3 +191,29 @@ def test_rendezvous_needs_a_token_on_a_routable_address(monkeypatch):
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     with pytest.raises(RuntimeError, match="DEEPIM_RDZV_TOKEN"):
         parallel.Rendezvous(1, 2, "10.1.2.3", 29999, timeout=1.0)
+
+
+@pytest.mark.parametrize("global_batch,counts", [(32, [4] * 8), (13, [2, 2, 2, 2, 2, 1, 1, 1])])
+def test_eight_rank_launch_rehearsal(global_batch, counts):
+    """The driver's 8-GPU command line, without GPUs: `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8
+    --global-batch G --dry-run` — bench.py's own rank/env handling, rendezvous, RCCL-id broadcast, shard bounds, padded
+    per-iteration pose gather (order checked inside on every rank), barrier-bracketed max-over-ranks timing, and exactly ONE
+    JSON line, from rank 0 only.  (No RCCL run with N > 1 ranks exists yet: gpurun boxes have one GPU.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 36000 + os.getpid() % 2000 + global_batch
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--global-batch", str(global_batch), "--dry-run"], cwd=root, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 2
+    assert d["config"]["shard_counts"] == counts and d["config"]["global_batch"] == global_batch
+    assert d["config"]["pairs_per_gpu"] == counts[0]
+    assert abs(d["value"] - global_batch * 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert ("bs%d" % global_batch) in d["metric"]
