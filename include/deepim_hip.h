@@ -291,6 +291,13 @@ int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const float* in 
  * packed_w = the first half (hi parts) of deepim_conv1_x3_pack_weights(..., w_scale = 1) */
 int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in /*B,8,H,W*/, const void* packed_w,
                              const float* bias, int B, int H, int W, float slope);
+/* conv1 of the fp16 path for BASELINE config 5's RGB-D net input (INPUT_DEPTH: Cin = 10, deepIM_flownet.py:33-62): channels
+ * 0-7 as above, channels 8-9 as 14 pseudo taps of 4 consecutive columns x 2 channels (7 extra k-steps instead of the 24 of a
+ * 16-channel padding).  w (64,10,7,7) fp32 → packed (deepim_conv1_f16_c10_packed_size bytes). */
+size_t deepim_conv1_f16_c10_packed_size(void);
+int deepim_conv1_f16_c10_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*64,10,7,7*/);
+int deepim_conv1_f16_c10_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in /*B,10,H,W*/, const void* packed_w,
+                                 const float* bias, int B, int H, int W, float slope);
 int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
                              int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                              float acc_scale, float out_scale);

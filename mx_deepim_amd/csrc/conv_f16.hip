@@ -854,8 +854,13 @@ constexpr int C1_PH = C1_ROWS * 2 * C1_RW;     // h8 entries of a_hi (and of a_l
 constexpr int C1_LDS = (2 * C1_WH + 2 * C1_PH) * 16;
 constexpr int C1_LDS_F16 = (C1_WH + C1_PH) * 16;   // plain fp16 variant: hi parts only (73.7 KB → two blocks per CU)
 
+constexpr int C1_DSTAGE = C1_ROWS * 72 * 4;        // DEP: the two extra channels of the patch as [row][72 quad columns][2 halves]
+constexpr int C1_LDS_DEP = C1_LDS_F16 + C1_DSTAGE + 256;  // 81 024 B (+ the 64 biases): still two blocks per CU
+constexpr int C1_DEP_TAPS = 14;                     // pseudo taps (ky, kx0 in {0, 4}): 4 consecutive columns x 2 channels each
+
 struct Conv1Params {
-  const float* in;      // (B,8,H,W) fp32
+  const float* in;      // (B,8,H,W) fp32 — (B,10,H,W) for the DEP kernel
+  const h8* wdep;       // DEP: [16 pseudo taps][64 co] h8, read from global memory (L1-resident, 14 KB)
   const h8* wp;         // packed [hi|lo][50 taps][64 co] h8 (tap 49 = zeros)
   const float* bias;
   _Float16* out;        // split16 NHWC (B,Ho,Wo,128 halves)
@@ -866,13 +871,24 @@ struct Conv1Params {
 
 // X3 = false: the same kernel with plain fp16 operands (BASELINE config 5): one MFMA per tile pair and k-step, NHWC fp16
 // output (128 B per pixel), half the LDS — two blocks share a CU and cover each other's load / epilogue phases.
-template <bool X3>
+//
+// DEP (plain fp16 only): BASELINE config 5's RGB-D input, Cin = 10 (deepIM_flownet.py:33-62 with INPUT_DEPTH). Channels 0-7 run
+// exactly as above (25 k-steps); channels 8, 9 ride as 14 PSEUDO TAPS: for (ky, kx0 in {0, 4}) the 8 halves of a k-lane group
+// are {ch8, ch9} of the 4 consecutive input columns kx0 … kx0+3 (kx = 7 has zero weights). After the 25 main steps the two
+// extra channels — kept aside in LDS as [row][column][2 halves] — are regrouped into the parity-0 slots of the same patch
+// array as 16-byte entries E[row][even column c] = columns c … c+3, so the pseudo tap (ky, kx0) is addressed exactly like the
+// real tap (ky, kx0): 7 more k-steps instead of the 24 a 16-channel padding would cost. Their weight fragments come from
+// global memory (14 KB, L1-resident; the 80 KB per block that keep two blocks on a CU are spent on the patch).
+template <bool X3, bool DEP = false>
 __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p) {
+  static_assert(!(X3 && DEP), "the two-channel extension exists for the plain fp16 path only");
+  constexpr int CIN = DEP ? 10 : 8;
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   h8* w_hi = smem;
   h8* w_lo = smem + C1_WH;                         // X3 only
   h8* a_hi = smem + (X3 ? 2 : 1) * C1_WH;
   h8* a_lo = a_hi + C1_PH;                         // X3 only
+  unsigned* dstage = reinterpret_cast<unsigned*>(a_hi + C1_PH);   // DEP only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 5, lcol = lane & 31;
@@ -891,10 +907,10 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
     qc[k] = (q - qr[k] * 18) * 4;
   }
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 v[2][8];
+  f32x4 v[2][CIN];
   float amax = 0.f;
   const long plane = (long)p.H * p.W;
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((long)p.B * 8 * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((long)p.B * CIN * plane * 4), 0x00020000);
   auto load_patch = [&](int tile) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
     const int gy0 = 2 * (ty * 8) - 3, gx0 = 2 * (tx * 32) - 4;   // quads start one pixel left of the patch: 16-byte aligned
@@ -906,10 +922,10 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
       const bool row_ok = (k * 256 + tid) < C1_QUADS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       // one select per quad, not per load (the compiler turned per-load selects into branches with a vmcnt(0) between the
       // loads); an invalid quad stays invalid for every channel: 0x80000000 + c·cstep < 2^32
-      const unsigned b0 = row_ok ? (unsigned)((((long)n * 8 * p.H + gy) * p.W + gx) * 4) : 0x80000000u;
+      const unsigned b0 = row_ok ? (unsigned)((((long)n * CIN * p.H + gy) * p.W + gx) * 4) : 0x80000000u;
       const unsigned cstep = (unsigned)(plane * 4);
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+      for (int c = 0; c < CIN; ++c)
         v[k][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(b0 + (unsigned)c * cstep), 0, 0));
     }
   };
@@ -917,6 +933,18 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (k * 256 + tid >= C1_QUADS) continue;
+      if constexpr (DEP) {                         // channels 8, 9 of the quad's 4 columns: one (ch8, ch9) pair per column
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        i32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h2 pr;
+          pr[0] = (_Float16)(e == 0 ? v[k][8].x : e == 1 ? v[k][8].y : e == 2 ? v[k][8].z : v[k][8].w);
+          pr[1] = (_Float16)(e == 0 ? v[k][9].x : e == 1 ? v[k][9].y : e == 2 ? v[k][9].z : v[k][9].w);
+          d[e] = __builtin_bit_cast(int, pr);
+        }
+        *reinterpret_cast<i32x4*>(dstage + qr[k] * 72 + qc[k]) = d;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int pc = qc[k] + e - 1;             // patch column of this element
@@ -942,13 +970,19 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
 
   // bias of this lane's 8 channel runs (i, g), kept in registers: a load inside the epilogue would wait behind the prefetch
   // loads and the previous tile's stores (vmcnt counts in order)
-  float bias_r[2][4][4];
+  // (the DEP kernel has no registers to spare for them and keeps the 64 biases in LDS instead)
+  float bias_r[DEP ? 1 : 2][DEP ? 1 : 4][DEP ? 1 : 4];
+  float* bias_s = reinterpret_cast<float*>(dstage + C1_DSTAGE / 4);
+  if constexpr (DEP) {
+    if (tid < 64) bias_s[tid] = p.bias ? p.bias[tid] : 0.f;
+  } else {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bias_r[i][g][r] = p.bias ? p.bias[i * 32 + 8 * g + 4 * lrow + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bias_r[i][g][r] = p.bias ? p.bias[i * 32 + 8 * g + 4 * lrow + r] : 0.f;
+  }
   int tile = blockIdx.x;
   if (tile < p.ntiles) load_patch(tile);
   // fragment bases: A rows = output channels (lane%32, + 32 for the second tile), the half-wave picks tap t or t+1;
@@ -1012,6 +1046,37 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
         }
       }
     }
+    if constexpr (DEP) {
+      __syncthreads();                     // every wave is past the 8-channel patch: its parity-0 slots take the E entries
+      for (int i = tid; i < C1_ROWS * C1_RW; i += 256) {
+        const int row = i / C1_RW, j = i - row * C1_RW;
+        const unsigned* src = dstage + row * 72 + 2 * j + 1;     // patch column 2j sits in quad column 2j + 1
+        i32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = (int)src[min(e, 70 - 2 * j)];   // column 72 does not exist: only ever multiplied by the zero weights of kx = 7
+        a_hi[(row * 2) * C1_RW + j] = __builtin_bit_cast(h8, d);
+      }
+      __syncthreads();
+      auto read_dep = [&](int set, int pp) {    // into the main loop's fragment registers (dead by now)
+        const int s0 = 2 * pp, s1 = 2 * pp + 1;                // pseudo tap s: ky = s / 2, kx0 = 4 (s % 2)
+        const int o0 = ((s0 >> 1) * 2) * C1_RW + (s0 & 1) * 2, o1 = ((s1 >> 1) * 2) * C1_RW + (s1 & 1) * 2;
+        const int bo = lrow ? o1 : o0;
+        fr[set][0] = p.wdep[s0 * 64 + a_base];
+        fr[set][1] = p.wdep[s0 * 64 + a_base + 32];
+        fr[set][4] = a_hi[b_base0 + bo];
+        fr[set][5] = a_hi[b_base1 + bo];
+      };
+      read_dep(0, 0);
+#pragma unroll
+      for (int pp = 0; pp < C1_DEP_TAPS / 2; ++pp) {
+        const int cur = pp & 1;
+        if (pp + 1 < C1_DEP_TAPS / 2) read_dep(cur ^ 1, pp + 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[cur][i], fr[cur][4 + j], acc[i][j], 0, 0, 0);
+      }
+    }
     __syncthreads();                       // all waves are past their last patch read: the region becomes the staging area
     // epilogue: real units, bias, LeakyReLU, split → LDS record → 16 B per lane, 1 KB (4 pixel records) per wave store
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
@@ -1028,7 +1093,7 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
           h4 vh, vl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float x = (X3 ? acc[i][j][4 * g + r] * p.acc_scale : acc[i][j][4 * g + r]) + bias_r[i][g][r];
+            float x = (X3 ? acc[i][j][4 * g + r] * p.acc_scale : acc[i][j][4 * g + r]) + (DEP ? bias_s[co0 + r] : bias_r[DEP ? 0 : i][DEP ? 0 : g][DEP ? 0 : r]);
             x = x > 0.f ? x : x * p.slope;
             if constexpr (X3) {
               const X3Pair s2 = x3_split(x, p.out_scale, amax);
@@ -1070,6 +1135,24 @@ __global__ void pack_conv1_x3_kernel(_Float16* __restrict__ packed, const float*
   X3Pair s2 = {(_Float16)0.f, (_Float16)0.f};
   if (t < C1_TAPS) s2 = x3_split(w[((co * 8 + c) * 7 + t / 7) * 7 + t % 7], w_scale);
   packed[i] = part ? s2.lo : s2.hi;
+}
+
+// conv1 weights of the RGB-D input (64,10,7,7) fp32 → [50 taps][64 co][8 halves] for channels 0-7 (tap 49 zero), then
+// [16 pseudo taps][64 co][8 halves]: pseudo tap s = 2 ky + (kx0 / 4) holds {w(8,ky,kx0+e), w(9,ky,kx0+e)} for e = 0 … 3, zero
+// where kx0 + e = 7 and for s >= 14
+__global__ void pack_conv1_c10_kernel(_Float16* __restrict__ packed, const float* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (C1_WH + 16 * 64) * 8) return;
+  float v = 0.f;
+  if (i < C1_WH * 8) {
+    const int c = i & 7, co = (i >> 3) & 63, t = i >> 9;
+    if (t < C1_TAPS) v = w[((co * 10 + c) * 7 + t / 7) * 7 + t % 7];
+  } else {
+    const int k = i - C1_WH * 8, h = k & 7, co = (k >> 3) & 63, s_ = k >> 9;
+    const int ky = s_ >> 1, kx = (s_ & 1) * 4 + (h >> 1), c = 8 + (h & 1);
+    if (s_ < C1_DEP_TAPS && kx < 7) v = w[((co * 10 + c) * 7 + ky) * 7 + kx];
+  }
+  packed[i] = (_Float16)v;
 }
 
 inline int f16_chunks(int Cin_pad, int kh, int kw) { return di_div_up(kh * kw * (Cin_pad / 8), HOCT); }
@@ -1443,25 +1526,50 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   return 0;
 }
 
+extern "C" size_t deepim_conv1_f16_c10_packed_size(void) { return (size_t)(C1_WH + 16 * 64) * 16; }
+
+extern "C" int deepim_conv1_f16_c10_pack_weights(deepim_ctx* ctx, void* packed, const float* w) {
+  DI_DEVICE(ctx);
+  hipLaunchKernelGGL(pack_conv1_c10_kernel, dim3(di_div_up((C1_WH + 16 * 64) * 8, 256)), dim3(256), 0, ctx->stream,
+                     (_Float16*)packed, w);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w, const float* bias, int B,
+                            int H, int W, float slope, int Cin);
+
 // conv1 of the plain fp16 path on the same patch kernel: NCHW fp32 net input → NHWC fp16 (B,Ho,Wo,64); the packed weights are
 // the hi half of deepim_conv1_x3_pack_weights(..., w_scale = 1)
 extern "C" int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w,
                                         const float* bias, int B, int H, int W, float slope) {
+  return conv1_f16_launch(ctx, out_nhwc_f16, in, packed_w, bias, B, H, W, slope, 8);
+}
+
+// the same for the 10-channel RGB-D net input (BASELINE config 5); packed_w from deepim_conv1_f16_c10_pack_weights
+extern "C" int deepim_conv1_f16_c10_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w,
+                                            const float* bias, int B, int H, int W, float slope) {
+  return conv1_f16_launch(ctx, out_nhwc_f16, in, packed_w, bias, B, H, W, slope, 10);
+}
+
+static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w, const float* bias, int B,
+                            int H, int W, float slope, int Cin) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   Conv1Params p;
   p.in = in; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_nhwc_f16;
+  p.wdep = (const h8*)packed_w + C1_WH;
   p.B = B; p.H = H; p.W = W;
   p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
   p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
   const long nt = (long)p.tiles_x * p.tiles_y * B;
   DI_REQUIRE((W & 3) == 0, "conv1_f16: W must be a multiple of 4 (aligned quad loads)");
-  if ((long)B * 8 * H * W * 4 >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
-    const int Bc = (int)(0x7ffffffeL / ((long)8 * H * W * 4));
+  if ((long)B * Cin * H * W * 4 >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
+    const int Bc = (int)(0x7ffffffeL / ((long)Cin * H * W * 4));
     DI_REQUIRE(Bc >= 1, "conv1_f16: one sample exceeds 2 GiB");
     for (int b0 = 0; b0 < B; b0 += Bc) {
-      const int rc = deepim_conv1_f16_forward(ctx, (_Float16*)out_nhwc_f16 + (size_t)b0 * p.Ho * p.Wo * 64, in + (size_t)b0 * 8 * H * W,
-                                              packed_w, bias, min(Bc, B - b0), H, W, slope);
+      const int rc = conv1_f16_launch(ctx, (_Float16*)out_nhwc_f16 + (size_t)b0 * p.Ho * p.Wo * 64, in + (size_t)b0 * Cin * H * W,
+                                      packed_w, bias, min(Bc, B - b0), H, W, slope, Cin);
       if (rc) return rc;
     }
     return 0;
@@ -1472,9 +1580,12 @@ extern "C" int deepim_conv1_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, con
   static const char attr_tag = 0;   // function attributes are per DEVICE: remember them per context
   if (di_attr_needed(ctx, &attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_F16));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_DEP));
   }
   const int grid = (int)min(512L, nt);   // persistent: two blocks per CU
-  hipLaunchKernelGGL(conv1_x3_kernel<false>, dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);
+  DI_REQUIRE(Cin == 8 || Cin == 10, "conv1_f16: 8 (RGB pair + masks) or 10 (RGB-D pair + masks) input channels");
+  if (Cin == 10) hipLaunchKernelGGL((conv1_x3_kernel<false, true>), dim3(grid), dim3(256), C1_LDS_DEP, ctx->stream, p);
+  else hipLaunchKernelGGL(conv1_x3_kernel<false>, dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -234,6 +234,10 @@ class deepIM_flownet(object):
                 pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
                 lib.deepim_conv1_x3_pack_weights(h, pk, self.params[ENCODER[0][0] + "_weight"], ctypes.c_float(1.0))
                 self.packed_f16["conv1_patch"] = pk
+            elif self.cin == 10 and self.W % 4 == 0:   # RGB-D input (config 5): the 8 + 2 channel form of the same kernel
+                pk = DeviceArray(ctx, (lib.load().deepim_conv1_f16_c10_packed_size() // 2,), dtype=np.float16)
+                lib.deepim_conv1_f16_c10_pack_weights(h, pk, self.params[ENCODER[0][0] + "_weight"])
+                self.packed_f16["conv1_patch"] = pk
         if self.x3_conv:     # split-fp16 weights [hi 16 | lo 16] in MFMA octet order, scaled by a power of two into fp16's range
             self.packed_x3, self.x3_wscale = {}, {}
             if self.cin == 8 and self.W % 4 == 0:    # conv1 on the split-fp16 patch kernel (8-channel input; otherwise fp32 conv1)
@@ -314,8 +318,9 @@ class deepIM_flownet(object):
         geom = self.enc_geom
         if "conv1_patch" in self.packed_f16:
             name = geom[0][0]
-            lib.deepim_conv1_f16_forward(h, A[name + "_h"], A["net_input"], self.packed_f16["conv1_patch"],
-                                         self.params[name + "_bias"], B, self.H, self.W, ctypes.c_float(SLOPE))
+            conv1 = lib.deepim_conv1_f16_c10_forward if self.cin == 10 else lib.deepim_conv1_f16_forward
+            conv1(h, A[name + "_h"], A["net_input"], self.packed_f16["conv1_patch"], self.params[name + "_bias"], B, self.H,
+                  self.W, ctypes.c_float(SLOPE))
             src, geom = A[name + "_h"], geom[1:]
         else:
             lib.deepim_nchw_f32_to_nhwc_f16(h, A["net_input_h"], A["net_input"], B, self.cin, self.H, self.W, self.cin_pad)

@@ -109,3 +109,34 @@ def test_conv1_f16_patch_kernel(ctx, shape):
     got = out.asnumpy()
     assert np.abs(got - ref).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
     assert np.mean(got != ref) < 0.02
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 50, 68), (1, 480, 640)])
+def test_conv1_f16_rgbd_patch_kernel(ctx, shape):
+    """conv1 for BASELINE config 5's 10-channel RGB-D net input on the 8 + 2 channel form of the patch kernel (channels 8, 9
+    as 14 pseudo taps of 4 columns x 2 channels) vs the fp16 emulation, and vs the generic fp16 conv on a 16-channel padding.
+    The extra channels carry depth-like values (0 background, 0.5…1.2 m) next to image-like ones; frame borders (zero
+    padding of the 7x7 window, also for the 4-column groups) are part of every shape."""
+    B, H, W = shape
+    rng = np.random.default_rng(H + 1)
+    x = rng.uniform(-1, 1, (B, 10, H, W)).astype(np.float32)
+    x[:, 8:] = np.where(rng.random((B, 2, H, W)) < 0.6, rng.uniform(0.5, 1.2, (B, 2, H, W)), 0).astype(np.float32)
+    w = (rng.standard_normal((64, 10, 7, 7)) / np.sqrt(10 * 49)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    ref = opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w), b, 2, 3, 0.1))
+    ho, wo = ref.shape[2:]
+    pk = DeviceArray(ctx, (lib.load().deepim_conv1_f16_c10_packed_size() // 2,), dtype=np.float16)
+    lib.deepim_conv1_f16_c10_pack_weights(ctx.handle, pk, ctx.array(w))
+    oh = ctx.empty((B, ho, wo, 64), dtype=np.float16)
+    lib.deepim_conv1_f16_c10_forward(ctx.handle, oh, ctx.array(x), pk, ctx.array(b), B, H, W, cf(0.1))
+    out = ctx.empty((B, 64, ho, wo))
+    lib.deepim_nhwc_f16_to_nchw_f32(ctx.handle, out, oh, B, 64, ho, wo)
+    got = out.asnumpy()
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
+    assert np.mean(got != ref) < 0.02
+    # the two extra channels really contribute: zeroing their weights changes the result
+    w0 = w.copy()
+    w0[:, 8:] = 0
+    assert np.abs(opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w0), b, 2, 3, 0.1)) - ref).max() > 0.05
+    gen = _conv_f16(ctx, x, w, b, 2, 3, 0.1)           # generic kernel, Cin padded 10 → 16
+    assert np.abs(got - gen).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
