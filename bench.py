@@ -271,9 +271,10 @@ def main():
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     ap.add_argument("--depth", action="store_true", help="BASELINE config 5 input as written: RGB-D pairs, network.INPUT_DEPTH "
                     "(ZoomDepth of observed + rendered depth inside the timed front end, C_in = 10)")
-    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto", help="replay the encoder's launches (10 convs + "
-                    "split-K second passes + layout passes) from one captured hipGraph instead of issuing them one by one: "
-                    "auto = when the batch per GPU is <= 8, where the kernels are short enough for launch gaps to show")
+    ap.add_argument("--graph", choices=("on", "off"), default="off", help="replay the encoder's launches (10 convs + split-K "
+                    "second passes + layout passes) from one captured hipGraph instead of issuing them one by one. Measured "
+                    "(profiles/r03_fp16_config5.md): no gain at B = 8 / B = 4 — the kernel trace shows no idle gaps between the "
+                    "encoder's launches, the queue stays ahead of the GPU — so direct launches stay the default")
     ap.add_argument("--dry-run", action="store_true", help="launch rehearsal without a GPU: the same rank / rendezvous / shard / "
                     "per-iteration pose all-gather (host backend) / max-over-ranks / one-JSON-line-from-rank-0 code path with a "
                     "host stand-in for the refinement step; the line carries \"dry_run\": true and no roofline")
@@ -357,7 +358,7 @@ def main():
     zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(args.steps)]
     render_timers = [[ctx.timer() for _ in range(NIT - 1)] for _ in range(args.steps)]
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 8)
+    use_graph = args.graph == "on"
     enc_graph = [None]
 
     def run_encoder():
