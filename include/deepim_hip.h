@@ -235,6 +235,10 @@ int deepim_zoom_status(deepim_ctx* ctx, int* status);
 size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw);
 int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,kh,kw dev*/,
                              int Cout, int Cin, int kh, int kw);
+/* the same with a choice of operand orders: bits 1 = LDS-kernel order, 2 = NCHW register-fed order, 4 = NC8 order. A caller
+ * that runs NCHW activations only (the training graph and its data gradients) passes 3 and saves a third of the re-pack
+ * after every SGD step; a left-out order must not be used by the forward call (NC8 input needs bit 4). */
+int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw, int orders);
 int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                           const float* bias, int B, int Cin, int H, int W, int Cout,
                           int kh, int kw, int stride, int pad, float slope,
@@ -426,6 +430,15 @@ int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, 
 /* wt (Cin,Cout,kh,kw) = w (Cout,Cin,kh,kw) transposed and flipped: the weights with which the data gradient of a
  * convolution is itself a stride-1 convolution (pad kh-1-p) — run on deepim_conv2d_forward after deepim_conv_pack_weights */
 int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw);
+/* Data gradient of a stride-2 convolution as four stride-1 convolutions of the UN-dilated gradient, one per output parity
+ * class (py, px): the class only meets the taps ky = ky0 + 2a, kx = kx0 + 2b with ky0 = (py + pad) % 2, kx0 = (px + pad) % 2.
+ * wt (Cin,Cout,nky,nkx) = that sub-kernel of w (Cout,Cin,kh,kw), transposed and flipped → deepim_conv_pack_weights →
+ * deepim_conv2d_forward(stride 1, pad P) → deepim_interleave2d puts the window [cy, cy + hq) x [cx, cx + wq) of the result on
+ * dx[.., 2i + py, 2j + px] (the training loop's module.backward, deepim/core/module.py:1131-1137, for conv2/3/4/5/6). */
+int deepim_conv_subkernel_flip(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw, int ky0, int kx0,
+                               int nky, int nkx);
+int deepim_interleave2d(deepim_ctx* ctx, float* dx /*BC,H,W*/, const float* src /*BC,Hs,Ws*/, int BC, int Hs, int Ws, int cy,
+                        int cx, int H, int W, int py, int px);
 /* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
 int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
 /* the same with an offset: out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x], zeros elsewhere — also the backward of

@@ -56,6 +56,35 @@ __global__ __launch_bounds__(256) void conv_flip_weights_kernel(float* __restric
   wt[i] = w[(((long)co * Cin + ci) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)];
 }
 
+// Data gradient of a STRIDE-2 convolution without the zero-dilated gradient: the output pixels of one parity class
+// (y % 2, x % 2) = (py, px) only ever meet the taps ky = ky0 + 2a, kx = kx0 + 2b (ky0 = (py + pad) % 2, …), so the class is a
+// stride-1 convolution of the un-dilated dz with this sub-kernel, transposed and flipped:
+//   wt (Cin,Cout,nky,nkx)[ci][co][a'][b'] = w (Cout,Cin,kh,kw)[co][ci][ky0 + 2(nky-1-a')][kx0 + 2(nkx-1-b')]
+__global__ __launch_bounds__(256) void conv_subkernel_flip_kernel(float* __restrict__ wt, const float* __restrict__ w, int Cout,
+                                                                  int Cin, int kh, int kw, int ky0, int kx0, int nky, int nkx,
+                                                                  long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i % nkx);
+  const int a = (int)((i / nkx) % nky);
+  const int co = (int)((i / ((long)nkx * nky)) % Cout);
+  const int ci = (int)(i / ((long)nkx * nky * Cout));
+  wt[i] = w[(((long)co * Cin + ci) * kh + ky0 + 2 * (nky - 1 - a)) * kw + kx0 + 2 * (nkx - 1 - b)];
+}
+
+// dx (BC,H,W)[bc][2i + py][2j + px] = src (BC,Hs,Ws)[bc][i + cy][j + cx] for i < hq, j < wq: the window of a class result put
+// on its parity positions (the four classes together write every element of dx exactly once)
+__global__ __launch_bounds__(256) void interleave2d_kernel(float* __restrict__ dx, const float* __restrict__ src, int Hs, int Ws,
+                                                           int cy, int cx, int H, int W, int py, int px, int hq, int wq,
+                                                           long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % wq);
+  const int r = (int)((i / wq) % hq);
+  const long bc = i / ((long)wq * hq);
+  dx[(bc * H + 2 * r + py) * W + 2 * j + px] = src[(bc * Hs + r + cy) * Ws + j + cx];
+}
+
 // out (BC,Hd,Wd) = zeros except out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x]  (dilation and/or un-crop)
 __global__ __launch_bounds__(256) void dilate2d_kernel(float* __restrict__ out, const float* __restrict__ in, int Ho, int Wo,
                                                        int Hd, int Wd, int stride, int off_y, int off_x, long total) {
@@ -184,6 +213,129 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        if (c < p.Cout) out[(long)c * p.K + k] = acc[i][q][r];
+      }
+    }
+}
+
+// The same GEMM with both operands staged through LDS (round 3). In the kernel above a lane owns a dZ row / an im2col column
+// and walks along the pixels, so every lane of a load touches a different cache line (64 lines per instruction; PMC: the
+// kernel is bound by the L1 / TA line rate at 24 % of the fp32 matrix peak). Here a 16-pixel chunk of the two operand tiles
+// is loaded with the pixels fastest across the lanes — dZ: one dwordx4 per lane, 16 rows x 64 B per wave-instruction; im2col:
+// one dword per lane, 4 columns x 16 consecutive output pixels — written to LDS pixel-major ([pixel][row], pitch 132: the
+// 64-lane writes and the 32+32-lane fragment reads are 2-way, the minimum) and read back as MFMA fragments. Zero padding and
+// ragged edges through the raw-buffer out-of-range offset; global loads of chunk c+1 fly while chunk c is multiplied.
+constexpr int WG_PIX = 16, WG_P = 132;
+__global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradParams p) {
+  __shared__ float As[2][WG_PIX * WG_P];
+  __shared__ float Bs[2][WG_PIX * WG_P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kt = blockIdx.x % p.ktiles, mt = (blockIdx.x / p.ktiles) % p.mtiles, sl = blockIdx.x / (p.ktiles * p.mtiles);
+  const int lcol = lane & 31, lrow = lane >> 5;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int HW = p.Ho * p.Wo, cps = (HW + WG_PIX - 1) / WG_PIX;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)((long)p.B * p.Cout * HW * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.B * p.Cin * p.H * p.W * 4), 0x00020000);
+  // dZ loader: rows rowA and rowA + 64 of the tile, pixels 4 qA … 4 qA + 3 of the chunk
+  const int rowA = tid >> 2, qA = tid & 3;
+  unsigned a_row[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int co = mt * 128 + rowA + 64 * r;
+    a_row[r] = co < p.Cout ? (unsigned)co : OOB;
+  }
+  // im2col loader: pixel pixB of the chunk, columns krow0 + 16 e of the tile
+  const int pixB = tid & 15, krow0 = tid >> 4;
+  unsigned b_plane[8];      // element offset of channel ci(k) inside a sample, or OOB for k >= K
+  int b_tap[8];             // (ky - pad) << 16 | (kx - pad) & 0xffff
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = kt * 128 + krow0 + 16 * e;
+    const int kc = k < p.K ? k : 0;
+    const int ci = kc / (p.kh * p.kw), t = kc - ci * (p.kh * p.kw);
+    b_plane[e] = k < p.K ? (unsigned)(ci * p.H * p.W) : OOB;
+    b_tap[e] = ((t / p.kw - p.pad) << 16) | ((t % p.kw - p.pad) & 0xffff);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[2];
+  float rb[8];
+  auto load_regs = [&](long c) {
+    const int n = (int)(c / cps);
+    const int pc = (int)(c - (long)n * cps) * WG_PIX;
+    const int pa = pc + qA * 4;                       // HW % 4 == 0: the quad is entirely inside or entirely outside the sample
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const unsigned off = (a_row[r] != OOB && pa < HW) ? (unsigned)((((long)n * p.Cout + a_row[r]) * HW + pa) * 4) : OOB;
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)off, 0, 0));
+    }
+    const int pb = pc + pixB;
+    const int ho = pb / p.Wo, wo = pb - ho * p.Wo;
+    const int hi0 = ho * p.stride, wi0 = wo * p.stride;
+    const unsigned nbase = (unsigned)(n * p.Cin * p.H * p.W);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
+      const bool ok = pb < HW && b_plane[e] != OOB && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const unsigned off = ok ? (nbase + b_plane[e] + (unsigned)(hi * p.W + wi)) * 4u : OOB;
+      rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+    }
+  };
+  auto store_regs = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      As[buf][(qA * 4 + 0) * WG_P + rowA + 64 * r] = ra[r].x;
+      As[buf][(qA * 4 + 1) * WG_P + rowA + 64 * r] = ra[r].y;
+      As[buf][(qA * 4 + 2) * WG_P + rowA + 64 * r] = ra[r].z;
+      As[buf][(qA * 4 + 3) * WG_P + rowA + 64 * r] = ra[r].w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bs[buf][pixB * WG_P + krow0 + 16 * e] = rb[e];
+  };
+
+  const long chunks = (long)p.B * cps;
+  const long c_begin = (long)sl * p.groups_per_slice, c_end = min(chunks, c_begin + p.groups_per_slice);
+  if (c_begin < c_end) {
+    load_regs(c_begin);
+    store_regs(0);
+  }
+  __syncthreads();
+  for (long c = c_begin; c < c_end; ++c) {
+    const int buf = (int)(c - c_begin) & 1;
+    const bool more = c + 1 < c_end;
+    if (more) load_regs(c + 1);
+    const float* as = As[buf] + lrow * WG_P + wm0 + lcol;
+    const float* bs = Bs[buf] + lrow * WG_P + wn0 + lcol;
+#pragma unroll
+    for (int ks = 0; ks < WG_PIX / 2; ++ks) {
+      const float a0 = as[2 * ks * WG_P], a1 = as[2 * ks * WG_P + 32];
+      const float b0 = bs[2 * ks * WG_P], b1 = bs[2 * ks * WG_P + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) store_regs(buf ^ 1);
+    __syncthreads();
+  }
+  float* out = p.partial + (long)sl * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = kt * 128 + wn0 + q * 32 + lcol;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = mt * 128 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
         if (c < p.Cout) out[(long)c * p.K + k] = acc[i][q][r];
       }
     }
@@ -336,6 +488,28 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   DI_REQUIRE((HW & 3) == 0, "conv2d_wgrad: Ho*Wo must be a multiple of 4");
   p.ktiles = di_div_up(p.K, 128);
   p.mtiles = di_div_up(Cout, 128);
+  const long n_dw = (long)Cout * p.K;
+  if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
+    // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)
+    const long chunks = (long)B * di_div_up(HW, WG_PIX);
+    long S = di_div_up(1024, p.ktiles * p.mtiles);
+    S = min(S, max(1L, chunks / 24));
+    p.groups_per_slice = (int)di_div_up(chunks, S);
+    p.S = (int)di_div_up(chunks, p.groups_per_slice);
+    if (p.S == 1) {
+      p.partial = dw;                                  // a single slice writes the gradient itself
+    } else {
+      void* scratch;
+      int rc = deepim_scratch(ctx, (size_t)p.S * n_dw * sizeof(float), &scratch);
+      if (rc) return rc;
+      p.partial = (float*)scratch;
+    }
+    hipLaunchKernelGGL(wgrad_lds_kernel, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
+    if (p.S > 1)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n_dw, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n_dw, p.S);
+    DI_LAUNCH_CHECK();
+    return 0;
+  }
   const long groups = (long)B * ((HW + 7) >> 3);
   // enough pixel slices to fill the chip (~1024 blocks), each at least 64 groups (512 pixels) long; fixed by the geometry
   long S = di_div_up(1024, p.ktiles * p.mtiles);
@@ -349,6 +523,32 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   p.partial = (float*)scratch;
   hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n, p.S);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_conv_subkernel_flip(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw, int ky0,
+                                          int kx0, int nky, int nkx) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(ky0 >= 0 && kx0 >= 0 && nky >= 1 && nkx >= 1 && ky0 + 2 * (nky - 1) < kh && kx0 + 2 * (nkx - 1) < kw,
+             "conv_subkernel_flip: taps outside the kernel");
+  const long total = (long)Cin * Cout * nky * nkx;
+  hipLaunchKernelGGL(conv_subkernel_flip_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, wt, w, Cout, Cin, kh, kw,
+                     ky0, kx0, nky, nkx, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_interleave2d(deepim_ctx* ctx, float* dx, const float* src, int BC, int Hs, int Ws, int cy, int cx, int H,
+                                   int W, int py, int px) {
+  DI_DEVICE(ctx);
+  const int hq = (H - py + 1) / 2, wq = (W - px + 1) / 2;
+  DI_REQUIRE(py >= 0 && py < 2 && px >= 0 && px < 2 && cy >= 0 && cx >= 0 && hq + cy <= Hs && wq + cx <= Ws,
+             "interleave2d: class window outside the source");
+  const long total = (long)BC * hq * wq;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(interleave2d_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dx, src, Hs, Ws, cy, cx, H, W,
+                     py, px, hq, wq, total);
   DI_LAUNCH_CHECK();
   return 0;
 }

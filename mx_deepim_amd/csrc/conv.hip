@@ -1354,15 +1354,26 @@ extern "C" size_t deepim_conv_packed_size(int Cout, int Cin, int kh, int kw) {
 
 extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh,
                                         int kw) {
+  return deepim_conv_pack_weights_ex(ctx, packed_w, w, Cout, Cin, kh, kw, 7);
+}
+
+extern "C" int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw,
+                                           int orders) {
   DI_DEVICE(ctx);
+  DI_REQUIRE(orders >= 1 && orders <= 7, "conv_pack_weights: orders = bits 1 (LDS kernel) | 2 (NCHW register-fed) | 4 (NC8)");
   const int K = Cin * kh * kw, nchunk = chunk_count(K);
   const long total = (long)gran_count(Cout) * nchunk * KT * GRAN;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
-                     nchunk, total);
-  hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
-                     Cin, kh * kw, nchunk * (KT / 2), total);
-  hipLaunchKernelGGL(pack_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + 2 * total, w, Cout,
-                     Cin, kh * kw, nchunk * 2, total);
+  // three operand orders back to back; a caller that never runs one of the kernel families (the training graph: NCHW only)
+  // leaves its order out — the slot stays allocated and unread
+  if (orders & 1)
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
+                       nchunk, total);
+  if (orders & 2)
+    hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
+                       Cin, kh * kw, nchunk * (KT / 2), total);
+  if (orders & 4)
+    hipLaunchKernelGGL(pack_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + 2 * total, w, Cout,
+                       Cin, kh * kw, nchunk * 2, total);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -71,6 +71,80 @@ def test_conv_backward_kernels_match_oracle(ctx, case):
     close(dx.asnumpy(), dx_ref)
 
 
+# (B, Cin, H, W, Cout, k, p): stride-2 layers incl. odd frame sizes (conv6: 15x20 -> 8x10) and a 7x7 kernel
+S2_CASES = [(2, 64, 24, 32, 128, 5, 2), (2, 40, 16, 24, 70, 3, 1), (1, 512, 15, 20, 1024, 3, 1), (2, 6, 13, 17, 10, 3, 1),
+            (1, 8, 20, 28, 16, 7, 3), (2, 128, 30, 40, 256, 3, 1)]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_stride2_dgrad_by_parity_classes_matches_oracle(ctx, case):
+    """The data gradient of a stride-2 convolution as four stride-1 convolutions of the un-dilated dz (sub-kernel of each
+    output parity class, full convolution, window interleaved into dx) — against the oracle's conv2d_backward and against
+    the round-2 zero-dilated formulation (same sums in another order)."""
+    B, cin, H, W, cout, k, p = case
+    rng = np.random.default_rng(sum(case) + 5)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    ho, wo = (H + 2 * p - k) // 2 + 1, (W + 2 * p - k) // 2 + 1
+    dz_h = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    dx_ref, _, _ = onet.conv2d_backward(x, w, dz_h, 2, p)
+    h = ctx.handle
+    dz, wd = ctx.array(dz_h), ctx.array(w)
+    dx = ctx.array(np.full(x.shape, 7.0, np.float32))          # every element must be written by exactly one class
+    wt = ctx.empty((cin * cout * k * k,))
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cin, cout, k, k) // 4,))
+    taps = 0
+    for py in range(2):
+        for px in range(2):
+            ky0, kx0 = (py + p) % 2, (px + p) % 2
+            nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
+            taps += nky * nkx
+            cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
+            P = max(nky, nkx) - 1
+            hf, wf = ho + 2 * P - nky + 1, wo + 2 * P - nkx + 1
+            lib.deepim_conv_subkernel_flip(h, wt, wd, cout, cin, k, k, ky0, kx0, nky, nkx)
+            sub = wt.asnumpy()[:cin * cout * nky * nkx].reshape(cin, cout, nky, nkx)
+            np.testing.assert_array_equal(sub, np.ascontiguousarray(w[:, :, ky0::2, kx0::2].transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]))
+            lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, nky, nkx, 3)
+            cls = ctx.empty((B, cin, hf, wf))
+            lib.deepim_conv2d_forward(h, cls, dz, pk, None, B, cout, ho, wo, cin, nky, nkx, 1, P, cf(1.0), 0, 0)
+            lib.deepim_interleave2d(h, dx, cls, B * cin, hf, wf, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), H, W, py, px)
+    assert taps == k * k                                       # the four classes partition the kernel: the ideal multiply-adds
+    got = dx.asnumpy()
+    close(got, dx_ref)
+    # rows / columns no output pixel reaches (odd frame, pad) get exact zeros, like the oracle
+    assert np.abs(got[dx_ref == 0]).max(initial=0.0) == 0.0
+
+
+@pytest.mark.parametrize("case", WG_CASES + [(4, 64, 60, 80, 128, 5, 2, 2), (2, 512, 15, 20, 1024, 3, 2, 1)])
+def test_wgrad_lds_kernel_vs_register_fed_kernel(ctx, case):
+    """The LDS-staged weight-gradient kernel (default) and the round-2 register-fed one: both within 1e-4 of the float64
+    oracle, and within fp32 re-association distance of each other; both deterministic."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case) + 9)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz_h = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    w0 = np.zeros((cout, cin, k, k), np.float32)
+    _, dw_ref, _ = onet.conv2d_backward(x, w0, dz_h, s, p)
+    h = ctx.handle
+    xd, dz = ctx.array(x), ctx.array(dz_h)
+    res = {}
+    try:
+        for mode in (1, 0):
+            lib.deepim_set_option(h, b"wgrad_lds", mode)
+            dw = ctx.empty(w0.shape)
+            lib.deepim_conv2d_wgrad(h, dw, xd, dz, B, cin, H, W, cout, k, k, s, p)
+            dw2 = ctx.empty(w0.shape)
+            lib.deepim_conv2d_wgrad(h, dw2, xd, dz, B, cin, H, W, cout, k, k, s, p)
+            res[mode] = dw.asnumpy()
+            np.testing.assert_array_equal(dw2.asnumpy(), res[mode])
+            close(res[mode], dw_ref)
+    finally:
+        lib.deepim_set_option(h, b"wgrad_lds", 1)
+    close(res[1], res[0].astype(np.float64), 1e-5)
+
+
 @pytest.mark.parametrize("shape", [(4, 81920, 256), (3, 256, 256), (5, 256, 7)])
 def test_fc_backward_and_sgd(ctx, shape):
     B, I, O = shape
