@@ -239,6 +239,8 @@ int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*
  * that runs NCHW activations only (the training graph and its data gradients) passes 3 and saves a third of the re-pack
  * after every SGD step; a left-out order must not be used by the forward call (NC8 input needs bit 4). */
 int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw, int orders);
+/* the one order (1 or 2) deepim_conv2d_forward will read for this geometry under the context's current options */
+int deepim_conv_weight_order(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad);
 int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                           const float* bias, int B, int Cin, int H, int W, int Cout,
                           int kh, int kw, int stride, int pad, float slope,

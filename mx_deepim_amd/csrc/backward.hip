@@ -26,14 +26,18 @@ __global__ __launch_bounds__(256) void lrelu_backward_kernel(float* dz, const fl
   if (i < n) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
 }
 
-// db[c] = Σ_n Σ_p dz[n][c][p]: one block per channel, thread t sums elements t, t+256, … in order, then a fixed LDS tree
-__global__ __launch_bounds__(256) void bias_grad_kernel(float* __restrict__ db, const float* __restrict__ dz, int B, int C,
-                                                        long HW) {
-  const int c = blockIdx.x, tid = threadIdx.x;
+// db[c] = Σ_n Σ_p dz[n][c][p] in two deterministic passes: block (c, s) sums slice s of every sample's plane (thread t takes
+// elements t, t+256, … of the slice in order, float64, fixed LDS tree) into partial[c][s]; the second pass adds the S slice
+// sums of a channel in order. One block per channel (round 2) left 64-128 blocks walking 300 k elements each on the first
+// layers: 0.32 ms for conv1's gradient alone.
+__global__ __launch_bounds__(256) void bias_grad_kernel(double* __restrict__ partial, const float* __restrict__ dz, int B, int C,
+                                                        long HW, int S, long per_slice) {
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const long lo = (long)sl * per_slice, hi = min(HW, lo + per_slice);
   double acc = 0.0;
   for (int n = 0; n < B; ++n) {
     const float* p = dz + ((long)n * C + c) * HW;
-    for (long i = tid; i < HW; i += 256) acc += (double)p[i];
+    for (long i = lo + tid; i < hi; i += 256) acc += (double)p[i];
   }
   __shared__ double red[256];
   red[tid] = acc;
@@ -42,7 +46,16 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(float* __restrict__ db, 
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
-  if (tid == 0) db[c] = (float)red[0];
+  if (tid == 0) partial[(long)c * S + sl] = red[0];
+}
+
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(float* __restrict__ db, const double* __restrict__ partial, int C,
+                                                              int S) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double acc = 0.0;
+  for (int s = 0; s < S; ++s) acc += partial[(long)c * S + s];
+  db[c] = (float)acc;
 }
 
 __global__ __launch_bounds__(256) void conv_flip_weights_kernel(float* __restrict__ wt, const float* __restrict__ w, int Cout,
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 // 64-lane writes and the 32+32-lane fragment reads are 2-way, the minimum) and read back as MFMA fragments. Zero padding and
 // ragged edges through the raw-buffer out-of-range offset; global loads of chunk c+1 fly while chunk c is multiplied.
 constexpr int WG_PIX = 16, WG_P = 132;
-__global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 4) void wgrad_lds_kernel(WgradParams p) {
   __shared__ float As[2][WG_PIX * WG_P];
   __shared__ float Bs[2][WG_PIX * WG_P];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,26 +281,36 @@ __global__ __launch_bounds__(256) void wgrad_lds_kernel(WgradParams p) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 ra[2];
   float rb[8];
+  // every byte offset first, then the ten loads back to back: left to itself the compiler interleaves address arithmetic
+  // with the loads, reuses a load's destination register for the next address and waits (vmcnt(0)) in between, and turns
+  // `valid ? offset : OOB` into branches — the selects below are plain bit operations (bit 31 set = out of range → 0.0)
   auto load_regs = [&](long c) {
     const int n = (int)(c / cps);
     const int pc = (int)(c - (long)n * cps) * WG_PIX;
     const int pa = pc + qA * 4;                       // HW % 4 == 0: the quad is entirely inside or entirely outside the sample
+    unsigned offa[2], offb[8];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const unsigned off = (a_row[r] != OOB && pa < HW) ? (unsigned)((((long)n * p.Cout + a_row[r]) * HW + pa) * 4) : OOB;
-      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)off, 0, 0));
+      const unsigned inv = (a_row[r] >> 31) | (unsigned)(pa >= HW);
+      offa[r] = ((unsigned)(((n * p.Cout + (int)(a_row[r] & 0x7fffffffu)) * HW + pa) * 4) & 0x7fffffffu) | (inv << 31);
     }
     const int pb = pc + pixB;
     const int ho = pb / p.Wo, wo = pb - ho * p.Wo;
     const int hi0 = ho * p.stride, wi0 = wo * p.stride;
     const unsigned nbase = (unsigned)(n * p.Cin * p.H * p.W);
+    const unsigned pinv = (unsigned)(pb >= HW);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
-      const bool ok = pb < HW && b_plane[e] != OOB && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const unsigned off = ok ? (nbase + b_plane[e] + (unsigned)(hi * p.W + wi)) * 4u : OOB;
-      rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+      const unsigned inv = pinv | (b_plane[e] >> 31) | (unsigned)((unsigned)hi >= (unsigned)p.H) | (unsigned)((unsigned)wi >= (unsigned)p.W);
+      offb[e] = (((nbase + (b_plane[e] & 0x7fffffffu) + (unsigned)(hi * p.W + wi)) * 4u) & 0x7fffffffu) | (inv << 31);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)offa[r], 0, 0));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto store_regs = [&](int buf) {
 #pragma unroll
@@ -421,7 +444,15 @@ extern "C" int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy
 extern "C" int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, size_t hw) {
   DI_DEVICE(ctx);
   if (C == 0) return 0;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, ctx->stream, db, dz, B, C, (long)hw);
+  // slices of whole 1024-element runs, enough blocks for ~4 per CU; fixed by the geometry (deterministic)
+  int S = (int)max(1L, min((long)di_div_up(1024, C), (long)di_div_up((long)hw, 4096)));
+  const long per_slice = (long)di_div_up(di_div_up((long)hw, S), 1024) * 1024;
+  S = di_div_up((long)hw, per_slice);
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)C * S * sizeof(double), &scratch);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, B, C, (long)hw, S, per_slice);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
   DI_LAUNCH_CHECK();
   return 0;
 }

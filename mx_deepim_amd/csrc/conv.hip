@@ -1378,6 +1378,20 @@ extern "C" int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, con
   return 0;
 }
 
+// Which ONE of the packed operand orders deepim_conv2d_forward (NCHW in, NCHW out) reads for this geometry under the context's
+// current options — the selection of conv2d_forward_impl / choose_tile / launch_one restated, so that a caller that re-packs
+// weights it uses once (the data gradients of the training graph) packs only that order. Returns 1 (LDS kernel / few-output
+// kernel) or 2 (NCHW register-fed kernel).
+extern "C" int deepim_conv_weight_order(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                                        int pad) {
+  const long npix = (long)B * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
+  if (Cout <= 4 && ctx->conv_max_split != 1) return 1;
+  const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
+  if (!(direct && (Cin & 1) == 0 && (Cout > 64 || npix >= 256L * 1024))) return 1;
+  if (Cout <= 64) return 2;                                   // 64x256 tiles of the register-fed kernel
+  return (ctx->conv_tile256 && Cout % 256 == 0) ? 1 : 2;      // 256-row tiles exist in the LDS kernel only
+}
+
 extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                      const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                      int stride, int pad, float slope, int out_ctotal, int out_coff) {

@@ -602,7 +602,8 @@ def _train_methods():
         h = self.ctx.handle
         if s_ == 1:
             lib.deepim_conv_flip_weights(h, self.ws["wt"], w_raw, cout, cin, k, k)
-            lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k, 3)
+            order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_)   # packed for one use
+            lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k, order)
             lib.deepim_conv2d_forward(h, dx, dz, self.ws["wt_packed"], None, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_,
                                       ctypes.c_float(1.0), 0, 0)
             return
@@ -617,7 +618,8 @@ def _train_methods():
                 cls = self.ws["cls"]
                 assert B * cin * hf * wf <= cls.size
                 lib.deepim_conv_subkernel_flip(h, self.ws["wt"], w_raw, cout, cin, k, k, ky0, kx0, nky, nkx)
-                lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, nky, nkx, 3)
+                order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
+                lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, nky, nkx, order)
                 lib.deepim_conv2d_forward(h, cls, dz, self.ws["wt_packed"], None, B, cout, ho, wo, cin, nky, nkx, 1, P,
                                           ctypes.c_float(1.0), 0, 0)
                 lib.deepim_interleave2d(h, dx, cls, B * cin, hf, wf, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
