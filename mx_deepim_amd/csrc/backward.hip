@@ -232,30 +232,35 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 }
 
 // The same GEMM with both operands staged through LDS (round 3). In the kernel above a lane owns a dZ row / an im2col column
-// and walks along the pixels, so every lane of a load touches a different cache line (64 lines per instruction; PMC: the
-// kernel is bound by the L1 / TA line rate at 24 % of the fp32 matrix peak). Here a 16-pixel chunk of the two operand tiles
-// is loaded with the pixels fastest across the lanes — dZ: one dwordx4 per lane, 16 rows x 64 B per wave-instruction; im2col:
-// one dword per lane, 4 columns x 16 consecutive output pixels — written to LDS pixel-major ([pixel][row], pitch 132: the
-// 64-lane writes and the 32+32-lane fragment reads are 2-way, the minimum) and read back as MFMA fragments. Zero padding and
-// ragged edges through the raw-buffer out-of-range offset; global loads of chunk c+1 fly while chunk c is multiplied.
-constexpr int WG_PIX = 16, WG_P = 132;
-__global__ __launch_bounds__(256, 4) void wgrad_lds_kernel(WgradParams p) {
-  __shared__ float As[2][WG_PIX * WG_P];
-  __shared__ float Bs[2][WG_PIX * WG_P];
+// and walks along the pixels, so every lane of a load touches a different cache line (64 lines per instruction): it runs at the
+// L1 / TA line rate, 45-50 TFLOP/s. Here a 16-pixel chunk of the two operand tiles is loaded with the pixels fastest across the
+// lanes — dZ: one dwordx4 per lane, 16 rows x 64 B per wave-instruction; im2col: one dword per lane, 4 columns x 16 consecutive
+// output pixels — and kept in LDS ROW-major ([row][16 pixels], pitch 20 floats: 16-byte aligned, and 16 lanes of a
+// ds_read_b128 cover the 64 banks once). A lane's MFMA k index is the pixel: lanes 0-31 take pixels 0-7 of the chunk, lanes
+// 32-63 pixels 8-15, k-step j multiplies pixels (j, 8 + j) — so one fragment is 8 consecutive floats of one row = two
+// ds_read_b128, all 8 reads of a chunk are issued up front and the 32 MFMAs run back to back; dZ goes global → LDS as whole
+// dwordx4. Zero padding and ragged edges through the raw-buffer out-of-range offset; the global loads of chunk c+1 fly while
+// chunk c is multiplied. BM = 64 (conv1: Cout 64): 32x64 wave tiles instead of a half-empty 128-row tile.
+constexpr int WG_PIX = 16, WG_P = 20;
+template <int BM>
+__global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   // 41 KB of LDS per block: three blocks per CU
+  constexpr int TM = BM / 64, NA = BM / 64;          // MFMA row tiles per wave; dZ dwordx4 loads per thread and chunk
+  __shared__ __attribute__((aligned(16))) float As[2][BM * WG_P];
+  __shared__ __attribute__((aligned(16))) float Bs[2][128 * WG_P];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kt = blockIdx.x % p.ktiles, mt = (blockIdx.x / p.ktiles) % p.mtiles, sl = blockIdx.x / (p.ktiles * p.mtiles);
   const int lcol = lane & 31, lrow = lane >> 5;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * 64;
   const int HW = p.Ho * p.Wo, cps = (HW + WG_PIX - 1) / WG_PIX;
   const unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, (int)((long)p.B * p.Cout * HW * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.B * p.Cin * p.H * p.W * 4), 0x00020000);
-  // dZ loader: rows rowA and rowA + 64 of the tile, pixels 4 qA … 4 qA + 3 of the chunk
+  // dZ loader: rows rowA (+ 64) of the tile, pixels 4 qA … 4 qA + 3 of the chunk
   const int rowA = tid >> 2, qA = tid & 3;
-  unsigned a_row[2];
+  unsigned a_row[NA];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int co = mt * 128 + rowA + 64 * r;
+  for (int r = 0; r < NA; ++r) {
+    const int co = mt * BM + rowA + 64 * r;
     a_row[r] = co < p.Cout ? (unsigned)co : OOB;
   }
   // im2col loader: pixel pixB of the chunk, columns krow0 + 16 e of the tile
@@ -270,27 +275,27 @@ __global__ __launch_bounds__(256, 4) void wgrad_lds_kernel(WgradParams p) {
     b_plane[e] = k < p.K ? (unsigned)(ci * p.H * p.W) : OOB;
     b_tap[e] = ((t / p.kw - p.pad) << 16) | ((t % p.kw - p.pad) & 0xffff);
   }
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 ra[2];
+  f32x4 ra[NA];
   float rb[8];
-  // every byte offset first, then the ten loads back to back: left to itself the compiler interleaves address arithmetic
-  // with the loads, reuses a load's destination register for the next address and waits (vmcnt(0)) in between, and turns
+  // every byte offset first, then the loads back to back: left to itself the compiler interleaves address arithmetic with
+  // the loads, reuses a load's destination register for the next address and waits (vmcnt(0)) in between, and turns
   // `valid ? offset : OOB` into branches — the selects below are plain bit operations (bit 31 set = out of range → 0.0)
   auto load_regs = [&](long c) {
     const int n = (int)(c / cps);
     const int pc = (int)(c - (long)n * cps) * WG_PIX;
     const int pa = pc + qA * 4;                       // HW % 4 == 0: the quad is entirely inside or entirely outside the sample
-    unsigned offa[2], offb[8];
+    unsigned offa[NA], offb[8];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NA; ++r) {
       const unsigned inv = (a_row[r] >> 31) | (unsigned)(pa >= HW);
       offa[r] = ((unsigned)(((n * p.Cout + (int)(a_row[r] & 0x7fffffffu)) * HW + pa) * 4) & 0x7fffffffu) | (inv << 31);
     }
@@ -307,21 +312,16 @@ __global__ __launch_bounds__(256, 4) void wgrad_lds_kernel(WgradParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)offa[r], 0, 0));
+    for (int r = 0; r < NA; ++r) ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)offa[r], 0, 0));
 #pragma unroll
     for (int e = 0; e < 8; ++e) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
     __builtin_amdgcn_sched_barrier(0);
   };
   auto store_regs = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      As[buf][(qA * 4 + 0) * WG_P + rowA + 64 * r] = ra[r].x;
-      As[buf][(qA * 4 + 1) * WG_P + rowA + 64 * r] = ra[r].y;
-      As[buf][(qA * 4 + 2) * WG_P + rowA + 64 * r] = ra[r].z;
-      As[buf][(qA * 4 + 3) * WG_P + rowA + 64 * r] = ra[r].w;
-    }
+    for (int r = 0; r < NA; ++r) *reinterpret_cast<f32x4*>(&As[buf][(rowA + 64 * r) * WG_P + qA * 4]) = ra[r];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Bs[buf][pixB * WG_P + krow0 + 16 * e] = rb[e];
+    for (int e = 0; e < 8; ++e) Bs[buf][(krow0 + 16 * e) * WG_P + pixB] = rb[e];
   };
 
   const long chunks = (long)p.B * cps;
@@ -335,30 +335,37 @@ __global__ __launch_bounds__(256, 4) void wgrad_lds_kernel(WgradParams p) {
     const int buf = (int)(c - c_begin) & 1;
     const bool more = c + 1 < c_end;
     if (more) load_regs(c + 1);
-    const float* as = As[buf] + lrow * WG_P + wm0 + lcol;
-    const float* bs = Bs[buf] + lrow * WG_P + wn0 + lcol;
+    f32x4 af[TM][2], bf[2][2];
 #pragma unroll
-    for (int ks = 0; ks < WG_PIX / 2; ++ks) {
-      const float a0 = as[2 * ks * WG_P], a1 = as[2 * ks * WG_P + 32];
-      const float b0 = bs[2 * ks * WG_P], b1 = bs[2 * ks * WG_P + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        af[i][v] = *reinterpret_cast<const f32x4*>(&As[buf][(wm0 + i * 32 + lcol) * WG_P + lrow * 8 + v * 4]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        bf[q][v] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn0 + q * 32 + lcol) * WG_P + lrow * 8 + v * 4]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j >> 2][j & 3], bf[q][j >> 2][j & 3], acc[i][q], 0, 0, 0);
     if (more) store_regs(buf ^ 1);
     __syncthreads();
   }
   float* out = p.partial + (long)sl * p.Cout * p.K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = kt * 128 + wn0 + q * 32 + lcol;
       if (k >= p.K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = mt * 128 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        const int c = mt * BM + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
         if (c < p.Cout) out[(long)c * p.K + k] = acc[i][q][r];
       }
     }
@@ -518,7 +525,8 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   const int HW = p.Ho * p.Wo;
   DI_REQUIRE((HW & 3) == 0, "conv2d_wgrad: Ho*Wo must be a multiple of 4");
   p.ktiles = di_div_up(p.K, 128);
-  p.mtiles = di_div_up(Cout, 128);
+  const int bm = (ctx->wgrad_lds && Cout <= 64) ? 64 : 128;
+  p.mtiles = di_div_up(Cout, bm);
   const long n_dw = (long)Cout * p.K;
   if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
     // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)
@@ -535,7 +543,8 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
       if (rc) return rc;
       p.partial = (float*)scratch;
     }
-    hipLaunchKernelGGL(wgrad_lds_kernel, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
+    if (bm == 64) hipLaunchKernelGGL(wgrad_lds_kernel<64>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(wgrad_lds_kernel<128>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
     if (p.S > 1)
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n_dw, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n_dw, p.S);
     DI_LAUNCH_CHECK();
