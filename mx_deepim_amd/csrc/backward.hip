@@ -531,8 +531,17 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
     // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)
     const long chunks = (long)B * di_div_up(HW, WG_PIX);
-    long S = di_div_up(1024, p.ktiles * p.mtiles);
-    S = min(S, max(1L, chunks / 24));
+    // slice count: the blocks of a launch run in rounds of `slots` (256 CUs x 3 resident blocks, 4 for the 64-row tile); a
+    // count just above a multiple of that leaves a nearly empty last round (1024 blocks on 768 slots: a third of the chip
+    // idle for half the kernel). Pick S minimising rounds x chunks-per-slice (+ the reduce pass), slices >= 16 chunks.
+    const long tiles = (long)p.ktiles * p.mtiles, slots = bm == 64 ? 1024 : 768;
+    long S = 1;
+    float best = 1e30f;
+    for (long cand = 1; cand <= max(1L, min(chunks / 16, 4 * slots / tiles)); ++cand) {
+      const long cps_ = di_div_up(chunks, cand), s_eff = di_div_up(chunks, cps_);
+      const float cost = (float)di_div_up(tiles * s_eff, slots) * (float)cps_ + (s_eff > 1 ? 4.f + 0.02f * (float)s_eff : 0.f);
+      if (cost < best * 0.99f) { best = cost; S = cand; }
+    }
     p.groups_per_slice = (int)di_div_up(chunks, S);
     p.S = (int)di_div_up(chunks, p.groups_per_slice);
     if (p.S == 1) {
