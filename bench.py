@@ -590,7 +590,7 @@ def other_configs(left=lambda: 1e9):
 
 def layer_timings(ctx, net, reps=5):
     res = []
-    src = net.act["net_input"]
+    src = net.conv1_input()
     for li, (name, cin, h, w, cout, k, s, p) in enumerate(net.enc_geom):
         t = ctx.timer()
         net.encoder_layer(li, src)

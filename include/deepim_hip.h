@@ -199,6 +199,13 @@ int deepim_zoom_concat_forward(deepim_ctx* ctx,
                                const float* pixel_means_host,
                                float* net_input, float* zoom_factor,
                                int B, int H, int W);
+/* the same front end for the shipped 8-channel input (masks, no depth) writing channel-blocked records: net_input_nc8 is
+ * (B,H,W,8) = the "NC8" layout [n][C/8][h][w][8] with C = 8, which deepim_conv2d_forward_ex(in_nc8 = 1) reads for conv1;
+ * element values identical to deepim_zoom_concat_forward's (B,8,H,W) */
+int deepim_zoom_concat_forward_nc8(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                   const float* mask_observed, const float* mask_rendered, const float* src_pose,
+                                   const float* K_host, const float* pixel_means_host, float* net_input_nc8,
+                                   float* zoom_factor, int B, int H, int W);
 /* the same front end in the TRAINING graph (deepIM_flownet.py:392-412): the zoom region comes from mask_gt_observed
  * (B,1,H,W; NULL = mask_observed, i.e. the test graph) */
 int deepim_zoom_concat_train_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,

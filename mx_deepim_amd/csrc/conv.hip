@@ -687,13 +687,15 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 // (Tried: 64x128 tiles on 128-thread blocks for layers whose 128x128 tile count divides badly over 256 CUs, e.g. 2400 =
 // 9.375 per CU — identical throughput, so per-CU tile quantisation is not what separates conv3 (139 TF) from conv2 (144).
 // Note the 2nd __launch_bounds__ argument is waves per SIMD in HIP, not blocks per CU.)
-template <int OUT_NC8>
+// WIDE: 64 x 256 block tile (the four waves side by side along the pixels, all on the same 64 rows) for Cout = 64 — conv1 on
+// the channel-blocked net input the zoom front end writes (round 3).
+template <int OUT_NC8, int WIDE = 0>
 __global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NG = NC8_RING, NPD = NG - 1;   // NG: groups per loop body = ring size
+  constexpr int BM = WIDE ? 64 : 128, BN = WIDE ? 256 : 128, TM = 2, TN = 2, NG = NC8_RING, NPD = NG - 1;   // NG: groups per loop body = ring size
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = WIDE ? 0 : (wave >> 1) * 64, wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
   int vid;
   {
     const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
   const int ngroup = p.nchunk * 2;
   int wvo[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * 4 + (wm0 >> 5) + i) * ngroup) * 64 + lane) * 16;
+  for (int i = 0; i < TM; ++i) wvo[i] = (((mb * (BM / 32) + (wm0 >> 5) + i) * ngroup) * 64 + lane) * 16;
 
   // chunks_per_split is even on this path, so a block always owns whole bodies of NG = 4 groups
   const int g_begin = __builtin_amdgcn_readfirstlane(split * p.chunks_per_split * 2);
@@ -1203,7 +1205,10 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   DI_REQUIRE((long)p.gx * p.gy * p.gz < (1L << 31) && p.gx > 0, "conv: grid too large");
   dim3 grid(p.gx * p.gy * p.gz);
   if (MODE == MODE_CONV && p.in_nc8) {
-    if (p.out_nc8) hipLaunchKernelGGL(conv_nc8_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
+    if (t.bm == 64) {
+      DI_REQUIRE(t.bn == 256 && p.out_nc8 == 1, "conv: the 64-row NC8 kernel writes NC8 output on 64x256 tiles");
+      hipLaunchKernelGGL((conv_nc8_kernel<1, 1>), grid, dim3(256), 0, ctx->stream, p);
+    } else if (p.out_nc8) hipLaunchKernelGGL(conv_nc8_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL(conv_nc8_kernel<0>, grid, dim3(256), 0, ctx->stream, p);
   } else if (direct_ok)
     hipLaunchKernelGGL(conv_direct_kernel<2>, grid, dim3(256), 0, ctx->stream, p);
@@ -1471,7 +1476,8 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   if (out_nc8 == 2) DI_REQUIRE(!in_nc8, "conv2d: split16 output is built for the NCHW-input LDS-free kernel (conv1)");
   if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
   if (in_nc8) {
-    DI_REQUIRE((Cin & 7) == 0 && Cout > 64, "conv2d: NC8 input needs Cin % 8 == 0 and Cout > 64");
+    DI_REQUIRE((Cin & 7) == 0 && (Cout > 64 || (Cout == 64 && out_nc8 == 1)),
+               "conv2d: NC8 input needs Cin % 8 == 0 and Cout > 64 (or Cout == 64 with NC8 output: the 64x256-tile kernel)");
     const size_t half = packed_half(Cout, Cin * kh * kw);
     int2* tab8;
     rc = get_tab(ctx, MODE_NC8_TAB, Cin, kh, kw, H, W, &tab8);

@@ -296,8 +296,8 @@ __device__ __forceinline__ Quad make_quad(const Affine& a, int h, int w0, int H,
 // One channel of a quad. FLS >= 0: the channel's flags are a compile-time constant (the fused front end: every flag test
 // folds away); FLS < 0: flags come from the plan at run time (the generic Z ops).
 template <int FLS>
-__device__ __forceinline__ void resample_channel4(const float* __restrict__ s, float* __restrict__ d, float mean, int fl_dyn,
-                                                  const Quad& q, const Affine& a, int H, int W) {
+__device__ __forceinline__ void resample_channel4_vals(const float* __restrict__ s, float (&o)[4], float mean, int fl_dyn,
+                                                       const Quad& q, const Affine& a, int H, int W) {
   const int fl = FLS >= 0 ? FLS : fl_dyn;
   float tl[4], tr[4], bl[4], br[4];
 #pragma unroll
@@ -307,7 +307,6 @@ __device__ __forceinline__ void resample_channel4(const float* __restrict__ s, f
     bl[i] = s[q.row1 + q.xc0[i]];
     br[i] = s[q.row1 + q.xc1[i]];
   }
-  float o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const Taps& t = q.t[i];
@@ -330,6 +329,13 @@ __device__ __forceinline__ void resample_channel4(const float* __restrict__ s, f
     if (fl & CF_POST_ROUND_M045) v = roundf(v - 0.45f);
     o[i] = v;
   }
+}
+
+template <int FLS>
+__device__ __forceinline__ void resample_channel4(const float* __restrict__ s, float* __restrict__ d, float mean, int fl_dyn,
+                                                  const Quad& q, const Affine& a, int H, int W) {
+  float o[4];
+  resample_channel4_vals<FLS>(s, o, mean, fl_dyn, q, a, H, W);
   *reinterpret_cast<float4*>(d + q.opix) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
@@ -387,6 +393,37 @@ __global__ __launch_bounds__(256) void zoom_concat4_kernel(ConcatArgs g, const f
   if (MASK) {
     resample_channel4<CF_POST_ROUND>(g.mask_observed + (long)b * p, out + (long)n * p, 0.f, 0, q, a, H, W);
     resample_channel4<CF_PRE_BIN02 | CF_POST_ROUND>(g.mask_rendered + (long)b * p, out + (long)(n + 1) * p, 0.f, 0, q, a, H, W);
+  }
+}
+
+// The same front end for the shipped 8-channel input (RGB pair + masks) writing CHANNEL-BLOCKED records — [n][h][w][8], the
+// "NC8" layout with C = 8 — so that conv1 runs on the 16-byte-load kernel of the other encoder layers instead of gathering
+// dwords from eight NCHW planes. A thread owns 4 consecutive pixels of all 8 channels: 128 contiguous bytes, eight dwordx4
+// stores; values identical to the NCHW kernel's (same resample_channel4_vals calls).
+__global__ __launch_bounds__(256) void zoom_concat4_nc8_kernel(ConcatArgs g, const float* __restrict__ zoom_factor, int H, int W,
+                                                               float gx_step, float gy_step) {
+  const int qpr = W >> 2;
+  const int qid = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (qid >= qpr * H) return;
+  const int h = qid / qpr, w0 = (qid - h * qpr) << 2;
+  const Affine a = load_affine(zoom_factor, b, 0, H, W);
+  const Quad q = make_quad(a, h, w0, H, W, gx_step, gy_step);
+  const long p = (long)H * W;
+  float o[8][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4_vals<CF_POST_DIV255>(g.image_observed + ((long)b * 3 + c) * p, o[c], g.means.v[c], 0, q, a, H, W);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4_vals<CF_POST_DIV255>(g.image_rendered + ((long)b * 3 + c) * p, o[3 + c], g.means.v[c], 0, q, a, H, W);
+  resample_channel4_vals<CF_POST_ROUND>(g.mask_observed + (long)b * p, o[6], 0.f, 0, q, a, H, W);
+  resample_channel4_vals<CF_PRE_BIN02 | CF_POST_ROUND>(g.mask_rendered + (long)b * p, o[7], 0.f, 0, q, a, H, W);
+  float4* rec = reinterpret_cast<float4*>(g.net_input + ((long)b * p + q.opix) * 8);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rec[2 * i] = make_float4(o[0][i], o[1][i], o[2][i], o[3][i]);
+    rec[2 * i + 1] = make_float4(o[4][i], o[5][i], o[6][i], o[7][i]);
   }
 }
 
@@ -610,6 +647,31 @@ extern "C" int deepim_zoom_concat_forward(deepim_ctx* ctx, const float* image_ob
   return deepim_zoom_concat_train_forward(ctx, image_observed, image_rendered, mask_observed, nullptr, mask_rendered,
                                           depth_observed, depth_rendered, src_pose, K_host, pixel_means_host, net_input,
                                           zoom_factor, B, H, W);
+}
+
+// the shipped 8-channel front end (masks, no depth) writing channel-blocked records (B,H,W,8) for conv1's NC8 kernel
+extern "C" int deepim_zoom_concat_forward_nc8(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                              const float* mask_observed, const float* mask_rendered, const float* src_pose,
+                                              const float* K_host, const float* pixel_means_host, float* net_input_nc8,
+                                              float* zoom_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(mask_observed && mask_rendered, "zoom_concat_nc8: the 8-channel input needs both masks");
+  DI_REQUIRE((W & 3) == 0 && ((size_t)net_input_nc8 & 15) == 0, "zoom_concat_nc8: W % 4 == 0 and a 16-byte aligned output");
+  int rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr, src_pose,
+                               K_host, B, H, W);
+  if (rc) return rc;
+  ConcatArgs g;
+  g.image_observed = image_observed; g.image_rendered = image_rendered;
+  g.depth_observed = g.depth_rendered = nullptr;
+  g.mask_observed = mask_observed; g.mask_rendered = mask_rendered;
+  g.net_input = net_input_nc8; g.C = 8;
+  for (int i = 0; i < 3; ++i) g.means.v[i] = pixel_means_host ? pixel_means_host[i] : 0.f;
+  const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
+  dim3 grid(di_div_up((long)(W / 4) * H, 256), B);
+  hipLaunchKernelGGL(zoom_concat4_nc8_kernel, grid, dim3(256), 0, ctx->stream, g, zoom_factor, H, W, gx, gy);
+  DI_LAUNCH_CHECK();
+  return 0;
 }
 
 // training graph (deepIM_flownet.py:392-412): ZoomMask takes the zoom region from mask_GT_observed (NULL = the test graph,

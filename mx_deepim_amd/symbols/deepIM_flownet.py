@@ -43,6 +43,22 @@ def _out_hw(h, w, k, s, p):
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
+class _Activations(dict):
+    """The activation buffers of a bound network. `act["net_input"]` is always the (B,C,H,W) tensor of the reference graph:
+    when the zoom front end wrote the channel-blocked form for conv1 (8-channel input, NC8 encoder) it is converted into the
+    NCHW buffer on demand — tests and the bench's parity taps read it, the hot path does not."""
+
+    def __init__(self, net):
+        dict.__init__(self)
+        self._net = net
+
+    def __getitem__(self, key):
+        if key == "net_input" and getattr(self._net, "_input_live_nc8", False):
+            out, src = dict.__getitem__(self, "net_input"), dict.__getitem__(self, "net_input_nc8")
+            lib.deepim_relayout_nc8(self._net.ctx.handle, out, src, self._net.B, 8, self._net.H * self._net.W, 0)
+        return dict.__getitem__(self, key)
+
+
 class deepIM_flownet(object):
     def __init__(self):
         self.cfg = None
@@ -50,7 +66,7 @@ class deepIM_flownet(object):
         self.B = 0
         self.params = {}    # name -> DeviceArray (raw MXNet-layout parameters)
         self.packed = {}    # conv/deconv name -> packed weights
-        self.act = {}
+        self.act = _Activations(self)
 
     # ------------------------------------------------------------------ graph description
     def get_symbol(self, cfg=None, is_train=False):
@@ -260,6 +276,9 @@ class deepIM_flownet(object):
         # activations
         A = self.act
         A["net_input"] = ctx.empty((B, self.cin, H, W))
+        if self.cin == 8 and W % 4 == 0:   # channel-blocked twin for conv1's NC8 kernel (what zoom() writes in the default fp32 mode)
+            A["net_input_nc8"] = ctx.empty((B, H, W, 8))
+        self._input_live_nc8 = False
         A["zoom_factor"] = ctx.empty((B, 4))
         hh, ww, cin = H, W, self.cin
         self.enc_geom = []
@@ -302,8 +321,21 @@ class deepIM_flownet(object):
         lib.deepim_deconv4x4s2_crop_forward(self.ctx.handle, dst, src, self.packed[name], self.params[name + "_bias"],
                                             B, cin, h, w, cout, ho, wo, 1, 1, ctypes.c_float(slope), ctotal, coff)
 
+    def _conv1_from_nc8(self):
+        """conv1 reads a channel-blocked net input: the shipped 8-channel graph on the NC8 fp32 encoder (not the fp16 / x3
+        modes, which convert the NCHW input themselves, and not the training graph, whose backward reads NCHW)."""
+        return (self.nc8 and self.cin == 8 and self.input_mask and not self.input_depth and not self.fp16_conv
+                and not self.x3_conv and not getattr(self, "is_train", False) and self.W % 4 == 0)
+
     def zoom(self, data):
         A, h = self.act, self.ctx.handle
+        if self._conv1_from_nc8():
+            lib.deepim_zoom_concat_forward_nc8(h, data["image_observed"], data["image_rendered"], data["mask_observed"],
+                                               data["mask_rendered"], data["src_pose"], self.K, self.pixel_means,
+                                               dict.__getitem__(A, "net_input_nc8"), A["zoom_factor"], self.B, self.H, self.W)
+            self._input_live_nc8 = True
+            return
+        self._input_live_nc8 = False
         lib.deepim_zoom_concat_forward(
             h, data["image_observed"], data["image_rendered"],
             data["mask_observed"] if self.input_mask else None, data["mask_rendered"] if self.input_mask else None,
@@ -364,19 +396,26 @@ class deepIM_flownet(object):
         if self.x3_conv:
             return self.encoder_x3()
         A = self.act
-        src = A["net_input"]
+        src = self.conv1_input()
         for li in range(len(self.enc_geom)):
             self.encoder_layer(li, src)
             src = A[self.enc_geom[li][0]]
         self.act_layout = "nc8" if self.nc8 else "nchw"
 
+    def conv1_input(self):
+        """What conv1 reads: the channel-blocked (B,H,W,8) records when the last zoom() wrote them, else the NCHW net input."""
+        if getattr(self, "_input_live_nc8", False):
+            return dict.__getitem__(self.act, "net_input_nc8")
+        return dict.__getitem__(self.act, "net_input")
+
     def encoder_layer(self, li, src):
         """One encoder conv (index into enc_geom) from `src` into its activation buffer, in the configured layout."""
         name, cin, h, w, cout, k, s, p = self.enc_geom[li]
         if self.nc8:
+            in8 = 1 if (li > 0 or src.shape == (self.B, self.H, self.W, 8)) else 0     # conv1: NC8 records from the zoom front end
             lib.deepim_conv2d_forward_ex(self.ctx.handle, self.act[name], src, self.packed[name], self.params[name + "_bias"],
                                          self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,
-                                         1 if li > 0 else 0, 1 if li < len(self.enc_geom) - 1 else 0)
+                                         in8, 1 if li < len(self.enc_geom) - 1 else 0)
         else:
             self._conv(name, src, self.act[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
 

@@ -14,11 +14,12 @@ ENCODER = [("flow_conv1", 2, 3), ("conv2", 2, 2), ("conv3", 2, 2), ("conv3_1", 1
 
 
 def encoder(params, x, nc8=False):
-    """nc8: accumulate every layer in the order the channel-blocked MI355X configuration uses (conv1: channel pairs on
-    the NCHW net input, order 1; the rest: order 2 of net.c) instead of the canonical (ci,ky,kx)."""
+    """nc8: accumulate every layer in the order the channel-blocked MI355X configuration uses (order 2 of net.c; conv1 too
+    when the net input has 8 channels and is written channel-blocked by the zoom front end — with 6 or 10 input channels
+    conv1 reads the NCHW net input in channel pairs, order 1) instead of the canonical (ci,ky,kx)."""
     acts = {}
     for li, (name, s, p) in enumerate(ENCODER):
-        order = (1 if li == 0 else 2) if nc8 else 0
+        order = (2 if (li > 0 or x.shape[1] == 8) else 1) if nc8 else 0
         x = net.conv2d(x, params[name + "_weight"], params[name + "_bias"], s, p, SLOPE, pair_order=order)
         acts[name] = x
     return acts

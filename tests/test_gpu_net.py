@@ -195,6 +195,50 @@ def test_conv_nc8_kernel(ctx, case):
             lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 96, 128, 64, 7, 2, 3), (1, 8, 37, 52, 64, 7, 2, 3), (3, 16, 20, 28, 64, 3, 1, 1),
+                                  (1, 8, 480, 640, 64, 7, 2, 3)])
+def test_conv_nc8_wide_kernel_for_64_output_channels(ctx, case):
+    """conv1 on the channel-blocked net input: 64x256 tiles of the NC8 kernel (Cout = 64, NC8 output). Bit-identical to the
+    oracle accumulating over (c/8, ky, kx, s, h); NCHW output is refused for this tile shape."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ref2 = onet.conv2d(x, w, b, s, p, 0.1, pair_order=2)
+    xin, pk, bias = ctx.array(_to_nc8(x)), _pack_conv(ctx, w), ctx.array(b)
+    out = ctx.zeros((B, cout, Ho, Wo))
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    try:
+        lib.deepim_conv2d_forward_ex(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, 1, 1)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    np.testing.assert_array_equal(_from_nc8(out.asnumpy(), (B, cout, Ho, Wo)), ref2)
+    out2 = ctx.zeros((B, cout, Ho, Wo))                      # default plan (split-K allowed): same sums re-associated
+    lib.deepim_conv2d_forward_ex(ctx.handle, out2, xin, pk, bias, B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, 1, 1)
+    assert np.abs(_from_nc8(out2.asnumpy(), (B, cout, Ho, Wo)) - ref2).max() <= 1e-5 * max(1.0, np.abs(ref2).max())
+    with pytest.raises(RuntimeError):
+        lib.deepim_conv2d_forward_ex(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, 1, 0)
+
+
+def test_zoom_front_end_nc8_records_equal_the_nchw_tensor(ctx, small_batch):
+    """deepim_zoom_concat_forward_nc8 writes (B,H,W,8) records whose elements are bit-identical to the (B,8,H,W) tensor of
+    deepim_zoom_concat_forward, and the same zoom factor."""
+    d = small_batch
+    from mx_deepim_amd import synthetic
+    B, H, W = 2, 480, 640
+    args = [ctx.array(d["image_observed"]), ctx.array(d["image_rendered"][0]), ctx.array(d["mask_observed"]),
+            ctx.array(d["mask_rendered"][0])]
+    pose, K, means = ctx.array(d["src_pose"][0]), np.ascontiguousarray(d["K"]), np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
+    a, za = ctx.empty((B, 8, H, W)), ctx.empty((B, 4))
+    lib.deepim_zoom_concat_forward(ctx.handle, args[0], args[1], args[2], args[3], None, None, pose, K, means, a, za, B, H, W)
+    r, zr = ctx.empty((B, H, W, 8)), ctx.empty((B, 4))
+    lib.deepim_zoom_concat_forward_nc8(ctx.handle, args[0], args[1], args[2], args[3], pose, K, means, r, zr, B, H, W)
+    np.testing.assert_array_equal(zr.asnumpy(), za.asnumpy())
+    np.testing.assert_array_equal(r.asnumpy().transpose(0, 3, 1, 2), a.asnumpy())
+
+
 def test_conv_nc8_kernel_random_geometries(ctx):
     """Random geometries through the NC8 kernel (odd sizes, every kernel size / stride / pad the net uses, channel counts off
     the chunk grid so the K padding and the even-chunk rule of split-K are exercised, forced split factors)."""
