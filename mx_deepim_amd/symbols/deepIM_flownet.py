@@ -276,8 +276,6 @@ class deepIM_flownet(object):
         # activations
         A = self.act
         A["net_input"] = ctx.empty((B, self.cin, H, W))
-        if self.cin == 8 and W % 4 == 0:   # channel-blocked twin for conv1's NC8 kernel (what zoom() writes in the default fp32 mode)
-            A["net_input_nc8"] = ctx.empty((B, H, W, 8))
         self._input_live_nc8 = False
         A["zoom_factor"] = ctx.empty((B, 4))
         hh, ww, cin = H, W, self.cin
@@ -322,14 +320,19 @@ class deepIM_flownet(object):
                                             B, cin, h, w, cout, ho, wo, 1, 1, ctypes.c_float(slope), ctotal, coff)
 
     def _conv1_from_nc8(self):
-        """conv1 reads a channel-blocked net input: the shipped 8-channel graph on the NC8 fp32 encoder (not the fp16 / x3
-        modes, which convert the NCHW input themselves, and not the training graph, whose backward reads NCHW)."""
-        return (self.nc8 and self.cin == 8 and self.input_mask and not self.input_depth and not self.fp16_conv
-                and not self.x3_conv and not getattr(self, "is_train", False) and self.W % 4 == 0)
+        """OPT-IN (`net.conv1_nc8 = True` after bind; default off): conv1 reads a channel-blocked net input written by the
+        zoom front end — the shipped 8-channel graph on the NC8 fp32 encoder (not the fp16 / x3 modes, which convert the NCHW
+        input themselves, and not the training graph, whose backward reads NCHW). Measured in round 3 (profiles/r03_conv1_nc8.md):
+        conv1 1.016 ms vs 1.006 ms on the NCHW register-fed kernel and the front end 0.179 vs 0.149 ms — conv1 is bound by its
+        short K loop (49 tap groups per tile), not by the gather shape, so the default stays NCHW."""
+        return (getattr(self, "conv1_nc8", False) and self.nc8 and self.cin == 8 and self.input_mask and not self.input_depth
+                and not self.fp16_conv and not self.x3_conv and not getattr(self, "is_train", False) and self.W % 4 == 0)
 
     def zoom(self, data):
         A, h = self.act, self.ctx.handle
         if self._conv1_from_nc8():
+            if "net_input_nc8" not in A:       # opt-in path: allocated on first use (run once eagerly before a graph capture)
+                A["net_input_nc8"] = self.ctx.empty((self.B, self.H, self.W, 8))
             lib.deepim_zoom_concat_forward_nc8(h, data["image_observed"], data["image_rendered"], data["mask_observed"],
                                                data["mask_rendered"], data["src_pose"], self.K, self.pixel_means,
                                                dict.__getitem__(A, "net_input_nc8"), A["zoom_factor"], self.B, self.H, self.W)

@@ -13,13 +13,13 @@ ENCODER = [("flow_conv1", 2, 3), ("conv2", 2, 2), ("conv3", 2, 2), ("conv3_1", 1
            ("conv5", 2, 1), ("conv5_1", 1, 1), ("conv6", 2, 1), ("conv6_1", 1, 1)]
 
 
-def encoder(params, x, nc8=False):
-    """nc8: accumulate every layer in the order the channel-blocked MI355X configuration uses (order 2 of net.c; conv1 too
-    when the net input has 8 channels and is written channel-blocked by the zoom front end — with 6 or 10 input channels
-    conv1 reads the NCHW net input in channel pairs, order 1) instead of the canonical (ci,ky,kx)."""
+def encoder(params, x, nc8=False, conv1_nc8=False):
+    """nc8: accumulate every layer in the order the channel-blocked MI355X configuration uses (conv1: channel pairs on
+    the NCHW net input, order 1; the rest: order 2 of net.c) instead of the canonical (ci,ky,kx). conv1_nc8: conv1 in order
+    2 as well (the opt-in configuration where the zoom front end writes channel-blocked records)."""
     acts = {}
     for li, (name, s, p) in enumerate(ENCODER):
-        order = (2 if (li > 0 or x.shape[1] == 8) else 1) if nc8 else 0
+        order = (2 if (li > 0 or conv1_nc8) else 1) if nc8 else 0
         x = net.conv2d(x, params[name + "_weight"], params[name + "_bias"], s, p, SLOPE, pair_order=order)
         acts[name] = x
     return acts
@@ -84,12 +84,12 @@ def flow_head(params, concat3, zoom_factor, H, W, normalize_flow):
 
 
 def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", heads=False,
-                     normalize_flow=20.0, fp16_conv=False, nc8=False):
+                     normalize_flow=20.0, fp16_conv=False, nc8=False, conv1_nc8=False):
     """-> dict with net_input, zoom_factor, encoder activations, se3 (B,7), pose_est (B,3,4 float64)."""
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"))
     out = {"net_input": x, "zoom_factor": zf}
-    acts = encoder_fp16(params, x) if fp16_conv else encoder(params, x, nc8=nc8)
+    acts = encoder_fp16(params, x) if fp16_conv else encoder(params, x, nc8=nc8, conv1_nc8=conv1_nc8)
     out.update(acts)
     if heads:
         dec = decoder(params, acts)

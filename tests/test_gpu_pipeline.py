@@ -134,3 +134,37 @@ def test_hipgraph_replay_matches_eager(ctx, small_batch):
     eager1 = net.refine_iteration(data).asnumpy()
     np.testing.assert_array_equal(got, eager1)
     assert not np.array_equal(eager0, eager1)
+
+
+def test_opt_in_conv1_from_channel_blocked_net_input(ctx, small_batch):
+    """`net.conv1_nc8 = True`: the zoom front end writes (B,H,W,8) records and conv1 runs on the 64x256-tile NC8 kernel.
+    Net input bit-exact (through the lazily converted NCHW view), every encoder layer bit-exact against the oracle in that
+    summation order, pose within 1e-4. (Measured slower than the default — see deepIM_flownet._conv1_from_nc8 — hence opt-in.)"""
+    from oracle import pipeline as opipe
+    from mx_deepim_amd import synthetic
+    from mx_deepim_amd.config import default_config
+    from mx_deepim_amd.runtime import lib
+    from mx_deepim_amd.symbols import deepIM_flownet
+    d = small_batch
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    params = net.init_weights(cfg, seed=5)
+    net.bind(ctx, 2, params)
+    net.conv1_nc8 = True
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    data = {k: ctx.array(d[k]) for k in ("image_observed", "mask_observed")}
+    data.update({k: ctx.array(d[k][0]) for k in ("image_rendered", "mask_rendered", "src_pose")})
+    lib.deepim_set_option(ctx.handle, b"conv_force_plan", 1)       # one chain per output: bit-exact against the oracle order
+    try:
+        pose = net.refine_iteration(data).asnumpy()
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_force_plan", 0)
+    assert net._input_live_nc8
+    host = {"image_observed": d["image_observed"], "image_rendered": d["image_rendered"][0], "mask_observed": d["mask_observed"],
+            "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0]}
+    ref = opipe.refine_iteration(params, host, d["K"], np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1]), cfg.dataset.trans_means,
+                                 cfg.dataset.trans_stds, cfg.network.ROT_COORD, nc8=True, conv1_nc8=True)
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), ref["net_input"])
+    np.testing.assert_array_equal(net.activation_nchw("flow_conv1").asnumpy(), ref["flow_conv1"])
+    np.testing.assert_array_equal(net.act["conv6_1"].asnumpy(), ref["conv6_1"])
+    assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
