@@ -511,6 +511,9 @@ def main():
         for sg in (signal.SIGTERM, signal.SIGINT):
             signal.signal(sg, emit)
         deadline = time.time() + args.extras_budget
+        sys.stderr.write("[bench] timed region complete; extras (parity, CPU baseline, other configs) run under a %.0f s budget\n"
+                         % args.extras_budget)
+        sys.stderr.flush()
 
         def left():
             return deadline - time.time()

@@ -73,6 +73,32 @@ def test_bench_parity_heads_and_config5_modes():
             assert p["flow_max_rel"] <= 1e-4 and p["mask_flip_frac"] <= 1e-4
 
 
+def test_headline_survives_a_sigterm_during_the_extras():
+    """the measured line must not be lost if the process is stopped while the secondary figures run. bench.py
+    announces the end of the timed region on stderr; SIGTERM after that → exactly one JSON line on stdout, exit code 0."""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "2", "--verify", "2",
+                          "--no-other-configs"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    seen = False
+    while time.time() - t0 < 600:
+        line = p.stderr.readline()
+        if not line:
+            break
+        if "timed region complete" in line:
+            seen = True
+            break
+    assert seen, "bench.py never announced the end of the timed region"
+    time.sleep(1.0)                      # inside verify_parity / cpu_baseline now (both take >= 10 s)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=120)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, out[-500:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d
+
+
 def _run_two_ranks(port, extra):
     env = dict(os.environ, DEEPIM_BENCH_BACKEND="host", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
