@@ -206,6 +206,14 @@ int deepim_zoom_concat_forward_nc8(deepim_ctx* ctx, const float* image_observed,
                                    const float* mask_observed, const float* mask_rendered, const float* src_pose,
                                    const float* K_host, const float* pixel_means_host, float* net_input_nc8,
                                    float* zoom_factor, int B, int H, int W);
+/* the front end of the fp16 conv path (config 5): the same values rounded once to fp16 and written as the pixel records
+ * deepim_conv1_f16_h16_forward reads — main8 (B,H,W,8 halves) = net-input channels 0-7; with depth_* set (INPUT_DEPTH, C = 10)
+ * extra2 (B,H,W,2 halves) = channels 8-9 (the masks). depth_observed, depth_rendered and extra2 are all NULL or all set. */
+int deepim_zoom_concat_forward_h16(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                   const float* mask_observed, const float* mask_rendered, const float* depth_observed,
+                                   const float* depth_rendered, const float* src_pose, const float* K_host,
+                                   const float* pixel_means_host, void* main8, void* extra2, float* zoom_factor, int B,
+                                   int H, int W);
 /* the same front end in the TRAINING graph (deepIM_flownet.py:392-412): the zoom region comes from mask_gt_observed
  * (B,1,H,W; NULL = mask_observed, i.e. the test graph) */
 int deepim_zoom_concat_train_forward(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
@@ -311,6 +319,10 @@ size_t deepim_conv1_f16_c10_packed_size(void);
 int deepim_conv1_f16_c10_pack_weights(deepim_ctx* ctx, void* packed, const float* w /*64,10,7,7*/);
 int deepim_conv1_f16_c10_forward(deepim_ctx* ctx, void* out_nhwc_f16, const float* in /*B,10,H,W*/, const void* packed_w,
                                  const float* bias, int B, int H, int W, float slope);
+/* conv1 of the fp16 path from fp16 pixel records (deepim_zoom_concat_forward_h16): extra2 == NULL → 8-channel input, packed_w as
+ * for deepim_conv1_f16_forward; extra2 set → the 10-channel RGB-D input, packed_w from deepim_conv1_f16_c10_pack_weights */
+int deepim_conv1_f16_h16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* main8, const void* extra2,
+                                 const void* packed_w, const float* bias, int B, int H, int W, float slope);
 int deepim_conv2d_x3_forward(deepim_ctx* ctx, void* out_split16, const void* in_split16, const void* packed_w, const float* bias,
                              int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                              float acc_scale, float out_scale);

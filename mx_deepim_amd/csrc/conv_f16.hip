@@ -859,6 +859,8 @@ constexpr int C1_LDS_DEP = C1_LDS_F16 + C1_DSTAGE + 256;  // 81 024 B (+ the 64 
 constexpr int C1_DEP_TAPS = 14;                     // pseudo taps (ky, kx0 in {0, 4}): 4 consecutive columns x 2 channels each
 
 struct Conv1Params {
+  const void* in16;     // IN16: (B,H,W,8) fp16 pixel records (the first eight net-input channels)
+  const void* in16x;    // IN16 + DEP: (B,H,W,2) fp16, channels 8-9
   const float* in;      // (B,8,H,W) fp32 — (B,10,H,W) for the DEP kernel
   const h8* wdep;       // DEP: [16 pseudo taps][64 co] h8, read from global memory (L1-resident, 14 KB)
   const h8* wp;         // packed [hi|lo][50 taps][64 co] h8 (tap 49 = zeros)
@@ -879,10 +881,13 @@ struct Conv1Params {
 // array as 16-byte entries E[row][even column c] = columns c … c+3, so the pseudo tap (ky, kx0) is addressed exactly like the
 // real tap (ky, kx0): 7 more k-steps instead of the 24 a 16-channel padding would cost. Their weight fragments come from
 // global memory (14 KB, L1-resident; the 80 KB per block that keep two blocks on a CU are spent on the patch).
-template <bool X3, bool DEP = false>
+// IN16 (plain fp16 only): the net input arrives as fp16 pixel records from the zoom front end (deepim_zoom_concat_forward_h16)
+// instead of NCHW fp32 planes: the patch is 1449 sixteen-byte records, six loads per thread, stored to LDS as they are — no
+// conversion pass, a quarter of the input bytes.
+template <bool X3, bool DEP = false, bool IN16 = false>
 __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p) {
-  static_assert(!(X3 && DEP), "the two-channel extension exists for the plain fp16 path only");
-  constexpr int CIN = DEP ? 10 : 8;
+  static_assert(!(X3 && DEP) && !(X3 && IN16), "the two-channel extension and the fp16-record input exist for the plain fp16 path only");
+  constexpr int CIN = IN16 ? 1 : (DEP ? 10 : 8);   // fp32 planes loaded per quad (IN16: none, one dummy)
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   h8* w_hi = smem;
   h8* w_lo = smem + C1_WH;                         // X3 only
@@ -910,10 +915,43 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
   f32x4 v[2][CIN];
   float amax = 0.f;
   const long plane = (long)p.H * p.W;
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((long)p.B * CIN * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, IN16 ? 0 : (int)((long)p.B * CIN * plane * 4), 0x00020000);
+  constexpr int C1_NREC = (C1_ROWS * 69 + 255) / 256;   // IN16: pixel records of the patch per thread
+  i32x4 vr[IN16 ? C1_NREC : 1];
+  i32x4 vx[IN16 && DEP ? 2 : 1];
+  int rrow[IN16 ? C1_NREC : 1], rpc[IN16 ? C1_NREC : 1];
+  if constexpr (IN16) {
+#pragma unroll
+    for (int k = 0; k < C1_NREC; ++k) {
+      const int rec = min(k * 256 + tid, C1_ROWS * 69 - 1);
+      rrow[k] = rec / 69;
+      rpc[k] = rec - rrow[k] * 69;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs_in16 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in16, 0, IN16 ? (int)((long)p.B * plane * 16) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in16x = __builtin_amdgcn_make_buffer_rsrc((void*)p.in16x, 0, IN16 && DEP ? (int)((long)p.B * plane * 4) : 0, 0x00020000);
   auto load_patch = [&](int tile) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
     const int gy0 = 2 * (ty * 8) - 3, gx0 = 2 * (tx * 32) - 4;   // quads start one pixel left of the patch: 16-byte aligned
+    if constexpr (IN16) {
+#pragma unroll
+      for (int k = 0; k < C1_NREC; ++k) {
+        const int gy = gy0 + rrow[k], gx = gx0 + 1 + rpc[k];
+        const bool ok = (k * 256 + tid) < C1_ROWS * 69 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const unsigned off = (((unsigned)((n * p.H + gy) * p.W + gx) * 16u) & 0x7fffffffu) | ((unsigned)(!ok) << 31);
+        vr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_in16, (int)off, 0, 0);
+      }
+      if constexpr (DEP) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int gy = gy0 + qr[k], gx = gx0 + qc[k];
+          const bool ok = (k * 256 + tid) < C1_QUADS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const unsigned off = (((unsigned)((n * p.H + gy) * p.W + gx) * 4u) & 0x7fffffffu) | ((unsigned)(!ok) << 31);
+          vx[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_in16x, (int)off, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int gy = gy0 + qr[k], gx = gx0 + qc[k];
@@ -930,17 +968,28 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
     }
   };
   auto store_patch = [&]() {
+    if constexpr (IN16) {
+#pragma unroll
+      for (int k = 0; k < C1_NREC; ++k)
+        if (k * 256 + tid < C1_ROWS * 69) a_hi[(rrow[k] * 2 + (rpc[k] & 1)) * C1_RW + (rpc[k] >> 1)] = __builtin_bit_cast(h8, vr[k]);
+      if constexpr (DEP) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k * 256 + tid < C1_QUADS) *reinterpret_cast<i32x4*>(dstage + qr[k] * 72 + qc[k]) = vx[k];
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (k * 256 + tid >= C1_QUADS) continue;
-      if constexpr (DEP) {                         // channels 8, 9 of the quad's 4 columns: one (ch8, ch9) pair per column
+      if constexpr (DEP && !IN16) {                // channels 8, 9 of the quad's 4 columns: one (ch8, ch9) pair per column
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         i32x4 d;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           h2 pr;
-          pr[0] = (_Float16)(e == 0 ? v[k][8].x : e == 1 ? v[k][8].y : e == 2 ? v[k][8].z : v[k][8].w);
-          pr[1] = (_Float16)(e == 0 ? v[k][9].x : e == 1 ? v[k][9].y : e == 2 ? v[k][9].z : v[k][9].w);
+          pr[0] = (_Float16)(e == 0 ? v[k][8 % CIN].x : e == 1 ? v[k][8 % CIN].y : e == 2 ? v[k][8 % CIN].z : v[k][8 % CIN].w);
+          pr[1] = (_Float16)(e == 0 ? v[k][9 % CIN].x : e == 1 ? v[k][9 % CIN].y : e == 2 ? v[k][9 % CIN].z : v[k][9 % CIN].w);
           d[e] = __builtin_bit_cast(int, pr);
         }
         *reinterpret_cast<i32x4*>(dstage + qr[k] * 72 + qc[k]) = d;
@@ -952,7 +1001,7 @@ __global__ __launch_bounds__(256, X3 ? 1 : 2) void conv1_x3_kernel(Conv1Params p
         h8 hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float x = e == 0 ? v[k][c].x : e == 1 ? v[k][c].y : e == 2 ? v[k][c].z : v[k][c].w;
+          const float x = e == 0 ? v[k][c % CIN].x : e == 1 ? v[k][c % CIN].y : e == 2 ? v[k][c % CIN].z : v[k][c % CIN].w;
           if constexpr (X3) {
             const X3Pair s2 = x3_split(x, p.in_scale, amax);
             hi[c] = s2.hi;
@@ -1497,6 +1546,7 @@ extern "C" int deepim_conv1_x3_forward(deepim_ctx* ctx, void* out_split16, const
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   Conv1Params p;
+  p.in16 = p.in16x = nullptr; p.wdep = nullptr;
   p.in = in; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_split16;
   p.B = B; p.H = H; p.W = W;
   p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
@@ -1537,7 +1587,15 @@ extern "C" int deepim_conv1_f16_c10_pack_weights(deepim_ctx* ctx, void* packed, 
 }
 
 static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w, const float* bias, int B,
-                            int H, int W, float slope, int Cin);
+                            int H, int W, float slope, int Cin, const void* in16 = nullptr, const void* in16x = nullptr);
+
+// conv1 of the fp16 path from the fp16 pixel records of deepim_zoom_concat_forward_h16: main8 (B,H,W,8) and, for the 10-channel
+// RGB-D input, extra2 (B,H,W,2); packed_w as for deepim_conv1_f16_forward (extra2 == NULL) / deepim_conv1_f16_c10_forward
+extern "C" int deepim_conv1_f16_h16_forward(deepim_ctx* ctx, void* out_nhwc_f16, const void* main8, const void* extra2,
+                                            const void* packed_w, const float* bias, int B, int H, int W, float slope) {
+  DI_REQUIRE(main8 != nullptr, "conv1_f16_h16: no input");
+  return conv1_f16_launch(ctx, out_nhwc_f16, nullptr, packed_w, bias, B, H, W, slope, extra2 ? 10 : 8, main8, extra2);
+}
 
 // conv1 of the plain fp16 path on the same patch kernel: NCHW fp32 net input → NHWC fp16 (B,Ho,Wo,64); the packed weights are
 // the hi half of deepim_conv1_x3_pack_weights(..., w_scale = 1)
@@ -1553,10 +1611,11 @@ extern "C" int deepim_conv1_f16_c10_forward(deepim_ctx* ctx, void* out_nhwc_f16,
 }
 
 static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in, const void* packed_w, const float* bias, int B,
-                            int H, int W, float slope, int Cin) {
+                            int H, int W, float slope, int Cin, const void* in16, const void* in16x) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   Conv1Params p;
+  p.in16 = in16; p.in16x = in16x;
   p.in = in; p.wp = (const h8*)packed_w; p.bias = bias; p.out = (_Float16*)out_nhwc_f16;
   p.wdep = (const h8*)packed_w + C1_WH;
   p.B = B; p.H = H; p.W = W;
@@ -1564,12 +1623,15 @@ static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in
   p.tiles_x = di_div_up(p.Wo, 32); p.tiles_y = di_div_up(p.Ho, 8);
   const long nt = (long)p.tiles_x * p.tiles_y * B;
   DI_REQUIRE((W & 3) == 0, "conv1_f16: W must be a multiple of 4 (aligned quad loads)");
-  if ((long)B * Cin * H * W * 4 >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
-    const int Bc = (int)(0x7ffffffeL / ((long)Cin * H * W * 4));
+  const long per_sample = in16 ? (long)H * W * 16 : (long)Cin * H * W * 4;      // bytes behind the (largest) buffer descriptor
+  if ((long)B * per_sample >= 0x7fffffffL) {   // < 2 GiB of input per launch: consecutive sub-batches
+    const int Bc = (int)(0x7ffffffeL / per_sample);
     DI_REQUIRE(Bc >= 1, "conv1_f16: one sample exceeds 2 GiB");
     for (int b0 = 0; b0 < B; b0 += Bc) {
-      const int rc = conv1_f16_launch(ctx, (_Float16*)out_nhwc_f16 + (size_t)b0 * p.Ho * p.Wo * 64, in + (size_t)b0 * Cin * H * W,
-                                      packed_w, bias, min(Bc, B - b0), H, W, slope, Cin);
+      const int rc = conv1_f16_launch(ctx, (_Float16*)out_nhwc_f16 + (size_t)b0 * p.Ho * p.Wo * 64,
+                                      in ? in + (size_t)b0 * Cin * H * W : nullptr, packed_w, bias, min(Bc, B - b0), H, W, slope, Cin,
+                                      in16 ? (const char*)in16 + (size_t)b0 * H * W * 16 : nullptr,
+                                      in16x ? (const char*)in16x + (size_t)b0 * H * W * 4 : nullptr);
       if (rc) return rc;
     }
     return 0;
@@ -1581,10 +1643,14 @@ static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in
   if (di_attr_needed(ctx, &attr_tag)) {
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_F16));
     DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_DEP));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_F16));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv1_x3_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_DEP));
   }
   const int grid = (int)min(512L, nt);   // persistent: two blocks per CU
   DI_REQUIRE(Cin == 8 || Cin == 10, "conv1_f16: 8 (RGB pair + masks) or 10 (RGB-D pair + masks) input channels");
-  if (Cin == 10) hipLaunchKernelGGL((conv1_x3_kernel<false, true>), dim3(grid), dim3(256), C1_LDS_DEP, ctx->stream, p);
+  if (in16 && Cin == 10) hipLaunchKernelGGL((conv1_x3_kernel<false, true, true>), dim3(grid), dim3(256), C1_LDS_DEP, ctx->stream, p);
+  else if (in16) hipLaunchKernelGGL((conv1_x3_kernel<false, false, true>), dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);
+  else if (Cin == 10) hipLaunchKernelGGL((conv1_x3_kernel<false, true>), dim3(grid), dim3(256), C1_LDS_DEP, ctx->stream, p);
   else hipLaunchKernelGGL(conv1_x3_kernel<false>, dim3(grid), dim3(256), C1_LDS_F16, ctx->stream, p);
   DI_LAUNCH_CHECK();
   return 0;

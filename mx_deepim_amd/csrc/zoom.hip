@@ -427,6 +427,54 @@ __global__ __launch_bounds__(256) void zoom_concat4_nc8_kernel(ConcatArgs g, con
   }
 }
 
+// The front end of the fp16 conv path (BASELINE config 5): the same values rounded once to fp16 (RNE, what the separate
+// NCHW fp32 → NHWC fp16 pass did) and written as the pixel records conv1's patch kernel reads — main (B,H,W,8 halves) = the
+// first eight net-input channels, and with DEPTH the two remaining ones (the masks) as (B,H,W,2 halves). Half the bytes of
+// the fp32 net input on the way out, a quarter on conv1's way in.
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void zoom_concat4_h16_kernel(ConcatArgs g, _Float16* __restrict__ main8,
+                                                               _Float16* __restrict__ extra2,
+                                                               const float* __restrict__ zoom_factor, int H, int W,
+                                                               float gx_step, float gy_step) {
+  constexpr int C = DEPTH ? 10 : 8;
+  const int qpr = W >> 2;
+  const int qid = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (qid >= qpr * H) return;
+  const int h = qid / qpr, w0 = (qid - h * qpr) << 2;
+  const Affine a = load_affine(zoom_factor, b, 0, H, W);
+  const Quad q = make_quad(a, h, w0, H, W, gx_step, gy_step);
+  const long p = (long)H * W;
+  float o[C][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4_vals<CF_POST_DIV255>(g.image_observed + ((long)b * 3 + c) * p, o[c], g.means.v[c], 0, q, a, H, W);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    resample_channel4_vals<CF_POST_DIV255>(g.image_rendered + ((long)b * 3 + c) * p, o[3 + c], g.means.v[c], 0, q, a, H, W);
+  if (DEPTH) {
+    resample_channel4_vals<CF_POST_DIV255>(g.depth_observed + (long)b * p, o[6], 0.f, 0, q, a, H, W);
+    resample_channel4_vals<CF_POST_DIV255>(g.depth_rendered + (long)b * p, o[7], 0.f, 0, q, a, H, W);
+  }
+  resample_channel4_vals<CF_POST_ROUND>(g.mask_observed + (long)b * p, o[C - 2], 0.f, 0, q, a, H, W);
+  resample_channel4_vals<CF_PRE_BIN02 | CF_POST_ROUND>(g.mask_rendered + (long)b * p, o[C - 1], 0.f, 0, q, a, H, W);
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  h8v* rec = reinterpret_cast<h8v*>(main8 + ((long)b * p + q.opix) * 8);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h8v r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = (_Float16)o[c][i];
+    rec[i] = r;
+  }
+  if (DEPTH) {
+    h8v r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = (_Float16)o[8][i]; r[2 * i + 1] = (_Float16)o[9][i]; }
+    *reinterpret_cast<h8v*>(extra2 + ((long)b * p + q.opix) * 2) = r;
+  }
+}
+
 // every float bit pattern through div255 against the IEEE division (parity hook)
 __global__ __launch_bounds__(256) void selfcheck_div255_kernel(unsigned long long* __restrict__ bad) {
   const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
@@ -670,6 +718,35 @@ extern "C" int deepim_zoom_concat_forward_nc8(deepim_ctx* ctx, const float* imag
   const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
   dim3 grid(di_div_up((long)(W / 4) * H, 256), B);
   hipLaunchKernelGGL(zoom_concat4_nc8_kernel, grid, dim3(256), 0, ctx->stream, g, zoom_factor, H, W, gx, gy);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// front end of the fp16 conv path: fp16 pixel records for deepim_conv1_f16_h16_forward (depth_* and extra2 both NULL or both set)
+extern "C" int deepim_zoom_concat_forward_h16(deepim_ctx* ctx, const float* image_observed, const float* image_rendered,
+                                              const float* mask_observed, const float* mask_rendered,
+                                              const float* depth_observed, const float* depth_rendered, const float* src_pose,
+                                              const float* K_host, const float* pixel_means_host, void* main8, void* extra2,
+                                              float* zoom_factor, int B, int H, int W) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(mask_observed && mask_rendered, "zoom_concat_h16: needs both masks (8- or 10-channel input)");
+  const bool dep = depth_observed != nullptr;
+  DI_REQUIRE(dep == (depth_rendered != nullptr) && dep == (extra2 != nullptr), "zoom_concat_h16: depth pair and extra2 go together");
+  DI_REQUIRE((W & 3) == 0 && ((size_t)main8 & 15) == 0 && ((size_t)extra2 & 15) == 0, "zoom_concat_h16: W % 4 == 0, 16-byte aligned outputs");
+  int rc = compute_zoom_factor(ctx, zoom_factor, mask_observed, mask_rendered, BB_MASK_GT, BB_MASK_RENDERED, nullptr, src_pose,
+                               K_host, B, H, W);
+  if (rc) return rc;
+  ConcatArgs g;
+  g.image_observed = image_observed; g.image_rendered = image_rendered;
+  g.depth_observed = depth_observed; g.depth_rendered = depth_rendered;
+  g.mask_observed = mask_observed; g.mask_rendered = mask_rendered;
+  g.net_input = nullptr; g.C = dep ? 10 : 8;
+  for (int i = 0; i < 3; ++i) g.means.v[i] = pixel_means_host ? pixel_means_host[i] : 0.f;
+  const float gx = (float)(2.0 / (W - 1)), gy = (float)(2.0 / (H - 1));
+  dim3 grid(di_div_up((long)(W / 4) * H, 256), B);
+  if (dep) hipLaunchKernelGGL(zoom_concat4_h16_kernel<true>, grid, dim3(256), 0, ctx->stream, g, (_Float16*)main8, (_Float16*)extra2, zoom_factor, H, W, gx, gy);
+  else hipLaunchKernelGGL(zoom_concat4_h16_kernel<false>, grid, dim3(256), 0, ctx->stream, g, (_Float16*)main8, (_Float16*)nullptr, zoom_factor, H, W, gx, gy);
   DI_LAUNCH_CHECK();
   return 0;
 }

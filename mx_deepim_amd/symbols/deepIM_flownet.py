@@ -53,6 +53,20 @@ class _Activations(dict):
         self._net = net
 
     def __getitem__(self, key):
+        if key == "net_input" and getattr(self._net, "_input_live_h16", False):
+            # fp16 mode: the front end wrote fp16 pixel records; their float values (exactly what conv1 multiplies) as NCHW
+            n, h = self._net, self._net.ctx.handle
+            out = dict.__getitem__(self, "net_input")
+            if n.cin == 8:
+                lib.deepim_nhwc_f16_to_nchw_f32(h, out, dict.__getitem__(self, "net_input_h8"), n.B, 8, n.H, n.W)
+            else:
+                if "net_input_tmp" not in self:
+                    self["net_input_tmp"] = n.ctx.empty((n.B, 8, n.H, n.W))
+                tmp = dict.__getitem__(self, "net_input_tmp")
+                lib.deepim_nhwc_f16_to_nchw_f32(h, tmp, dict.__getitem__(self, "net_input_h8"), n.B, 8, n.H, n.W)
+                lib.deepim_copy_channels(h, out, 10, 0, tmp, 8, n.B, n.H * n.W)
+                lib.deepim_nhwc_f16_to_nchw_f32(h, tmp, dict.__getitem__(self, "net_input_x2"), n.B, 2, n.H, n.W)
+                lib.deepim_copy_channels(h, out, 10, 8, tmp, 2, n.B, n.H * n.W)
         if key == "net_input" and getattr(self._net, "_input_live_nc8", False):
             out, src = dict.__getitem__(self, "net_input"), dict.__getitem__(self, "net_input_nc8")
             lib.deepim_relayout_nc8(self._net.ctx.handle, out, src, self._net.B, 8, self._net.H * self._net.W, 0)
@@ -292,6 +306,14 @@ class deepIM_flownet(object):
         if self.fp16_conv:
             self.cin_pad = (self.cin + 7) // 8 * 8
             A["net_input_h"] = ctx.empty((B, H, W, self.cin_pad), dtype=np.float16)
+            if "conv1_patch" in self.packed_f16 and self.input_mask:
+                # the zoom front end writes conv1's fp16 pixel records itself (no fp32 net input, no conversion pass);
+                # `net.fp16_fused_input = False` restores the two-step form for A/B measurements
+                A["net_input_h8"] = ctx.empty((B, H, W, 8), dtype=np.float16)
+                if self.cin == 10:
+                    A["net_input_x2"] = ctx.empty((B, H, W, 2), dtype=np.float16)
+                self.fp16_fused_input = True
+        self._input_live_h16 = False
         A["fc6"], A["fc7"], A["se3"] = ctx.empty((B, 256)), ctx.empty((B, 256)), ctx.empty((B, 7))
         A["pose_est"] = ctx.empty((B, 3, 4))
         if self.with_decoder:
@@ -330,6 +352,16 @@ class deepIM_flownet(object):
 
     def zoom(self, data):
         A, h = self.act, self.ctx.handle
+        if self.fp16_conv and getattr(self, "fp16_fused_input", False) and "net_input_h8" in A:
+            x2 = dict.__getitem__(A, "net_input_x2") if self.cin == 10 else None
+            lib.deepim_zoom_concat_forward_h16(h, data["image_observed"], data["image_rendered"], data["mask_observed"],
+                                               data["mask_rendered"], data.get("depth_observed") if self.input_depth else None,
+                                               data.get("depth_rendered") if self.input_depth else None, data["src_pose"],
+                                               self.K, self.pixel_means, dict.__getitem__(A, "net_input_h8"), x2,
+                                               A["zoom_factor"], self.B, self.H, self.W)
+            self._input_live_h16, self._input_live_nc8 = True, False
+            return
+        self._input_live_h16 = False
         if self._conv1_from_nc8():
             if "net_input_nc8" not in A:       # opt-in path: allocated on first use (run once eagerly before a graph capture)
                 A["net_input_nc8"] = self.ctx.empty((self.B, self.H, self.W, 8))
@@ -353,9 +385,15 @@ class deepIM_flownet(object):
         geom = self.enc_geom
         if "conv1_patch" in self.packed_f16:
             name = geom[0][0]
-            conv1 = lib.deepim_conv1_f16_c10_forward if self.cin == 10 else lib.deepim_conv1_f16_forward
-            conv1(h, A[name + "_h"], A["net_input"], self.packed_f16["conv1_patch"], self.params[name + "_bias"], B, self.H,
-                  self.W, ctypes.c_float(SLOPE))
+            if getattr(self, "_input_live_h16", False):
+                lib.deepim_conv1_f16_h16_forward(h, A[name + "_h"], dict.__getitem__(A, "net_input_h8"),
+                                                 dict.__getitem__(A, "net_input_x2") if self.cin == 10 else None,
+                                                 self.packed_f16["conv1_patch"], self.params[name + "_bias"], B, self.H, self.W,
+                                                 ctypes.c_float(SLOPE))
+            else:
+                conv1 = lib.deepim_conv1_f16_c10_forward if self.cin == 10 else lib.deepim_conv1_f16_forward
+                conv1(h, A[name + "_h"], A["net_input"], self.packed_f16["conv1_patch"], self.params[name + "_bias"], B, self.H,
+                      self.W, ctypes.c_float(SLOPE))
             src, geom = A[name + "_h"], geom[1:]
         else:
             lib.deepim_nchw_f32_to_nhwc_f16(h, A["net_input_h"], A["net_input"], B, self.cin, self.H, self.W, self.cin_pad)

@@ -178,7 +178,10 @@ def test_config5_rgbd_input_fp16_conv_path(ctx):
     emu = opipe.refine_iteration(params, npd, d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds,
                                  cfg.network.ROT_COORD, fp16_conv=True)
     assert emu["net_input"].shape[1] == 10
-    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), emu["net_input"])     # the zoom front end stays fp32, bit-exact
+    # the front end writes conv1's fp16 pixel records directly: their values are the fp32 net input rounded once (RNE), bit for bit
+    assert net._input_live_h16
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), opipe.q16(emu["net_input"]))
+    np.testing.assert_array_equal(net.act["zoom_factor"].asnumpy(), emu["zoom_factor"])
     assert np.abs(emu["net_input"][:, 6:8]).max() > 0                                   # the depth channels carry data
     c = net.act["conv6_1"].asnumpy()
     assert np.abs(c - emu["conv6_1"]).max() <= 5e-3 * np.abs(emu["conv6_1"]).max()

@@ -84,6 +84,18 @@ def test_fp16_iteration_vs_emulation_and_fp32(ctx, small_batch):
     assert np.abs(c - emu["conv6_1"]).max() <= 5e-3 * np.abs(emu["conv6_1"]).max()
     assert np.abs(net.act["se3"].asnumpy() - emu["se3"]).max() / np.abs(emu["se3"]).max() < 5e-3
     assert np.abs(pose - emu["pose_est"]).max() / np.abs(emu["pose_est"]).max() < 2e-3
+    # fused front end (default): fp16 pixel records = the fp32 net input rounded once; the two-step form (fp32 net input, then
+    # conv1 converts) gives the SAME conv1 output bit for bit
+    assert net._input_live_h16
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), opipe.q16(emu["net_input"]))
+    h1 = net.act["flow_conv1_h"].asnumpy().copy()
+    net.fp16_fused_input = False
+    pose_b = net.refine_iteration(data).asnumpy()
+    net.fp16_fused_input = True
+    assert not net._input_live_h16
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), emu["net_input"])
+    np.testing.assert_array_equal(net.act["flow_conv1_h"].asnumpy(), h1)
+    np.testing.assert_array_equal(pose_b, pose)
     ref32 = opipe.refine_iteration(*args)   # how far fp16 is from the fp32 reference path (documented, not 1e-4)
     dev = np.abs(pose - ref32["pose_est"]).max() / np.abs(ref32["pose_est"]).max()
     assert dev < 2e-2, dev
@@ -140,3 +152,30 @@ def test_conv1_f16_rgbd_patch_kernel(ctx, shape):
     assert np.abs(opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w0), b, 2, 3, 0.1)) - ref).max() > 0.05
     gen = _conv_f16(ctx, x, w, b, 2, 3, 0.1)           # generic kernel, Cin padded 10 → 16
     assert np.abs(got - gen).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
+
+
+@pytest.mark.parametrize("depth", [False, True], ids=["8ch", "rgbd_10ch"])
+def test_conv1_f16_from_fp16_pixel_records(ctx, depth):
+    """deepim_conv1_f16_h16_forward (input: (B,H,W,8) [+ (B,H,W,2)] fp16 records) equals deepim_conv1_f16[_c10]_forward on the
+    NCHW fp32 tensor holding the same (fp16-representable) values — bit for bit, three frame sizes incl. ragged tiles."""
+    for B, H, W in ((2, 64, 128), (1, 52, 68), (1, 480, 640)):
+        C = 10 if depth else 8
+        rng = np.random.default_rng(H + C)
+        x = opipe.q16(rng.uniform(-1, 1, (B, C, H, W)).astype(np.float32))
+        w = (rng.standard_normal((64, C, 7, 7)) / np.sqrt(C * 49)).astype(np.float32)
+        b = rng.standard_normal(64).astype(np.float32)
+        ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if depth:
+            pk = DeviceArray(ctx, (lib.load().deepim_conv1_f16_c10_packed_size() // 2,), dtype=np.float16)
+            lib.deepim_conv1_f16_c10_pack_weights(ctx.handle, pk, ctx.array(w))
+        else:
+            pk = DeviceArray(ctx, (lib.load().deepim_conv1_x3_packed_size() // 2,), dtype=np.float16)
+            lib.deepim_conv1_x3_pack_weights(ctx.handle, pk, ctx.array(w), cf(1.0))
+        ref_h = ctx.empty((B, ho, wo, 64), dtype=np.float16)
+        fwd = lib.deepim_conv1_f16_c10_forward if depth else lib.deepim_conv1_f16_forward
+        fwd(ctx.handle, ref_h, ctx.array(x), pk, ctx.array(b), B, H, W, cf(0.1))
+        main8 = ctx.array(np.ascontiguousarray(x[:, :8].transpose(0, 2, 3, 1)).astype(np.float16), dtype=np.float16)
+        extra2 = ctx.array(np.ascontiguousarray(x[:, 8:].transpose(0, 2, 3, 1)).astype(np.float16), dtype=np.float16) if depth else None
+        got_h = ctx.empty((B, ho, wo, 64), dtype=np.float16)
+        lib.deepim_conv1_f16_h16_forward(ctx.handle, got_h, main8, extra2, pk, ctx.array(b), B, H, W, cf(0.1))
+        np.testing.assert_array_equal(got_h.asnumpy(), ref_h.asnumpy(), err_msg=str((B, H, W, depth)))
