@@ -689,20 +689,12 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 // Note the 2nd __launch_bounds__ argument is waves per SIMD in HIP, not blocks per CU.)
 // WIDE: 64 x 256 block tile (the four waves side by side along the pixels, all on the same 64 rows) for Cout = 64 — conv1 on
 // the channel-blocked net input the zoom front end writes (round 3).
-// KG = 2 (round 3): INTRA-BLOCK split-K for under-filled grids. The block has eight waves — two K groups of four, each group
-// the four 64x64 wave tiles of the same 128x128 block tile — group 0 runs the first half of the block's K range, group 1 the
-// second, with no barrier in between (the kernel is LDS-free, the groups never meet in the loop); at the end group 1 hands its
-// accumulators over through 64 KB of LDS and group 0 adds them (fixed order: deterministic) and runs the epilogue. Each
-// factor of two of a split-K plan taken this way is a partial tile that never goes to memory and a slice the second pass
-// does not read: partial bytes = blocks x 64 KB, and the blocks halve.
-template <int OUT_NC8, int WIDE = 0, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 2 ? 2 : NC8_OCC) void conv_nc8_kernel(ConvParams p) {
+template <int OUT_NC8, int WIDE = 0>
+__global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
   constexpr int BM = WIDE ? 64 : 128, BN = WIDE ? 256 : 128, TM = 2, TN = 2, NG = NC8_RING, NPD = NG - 1;   // NG: groups per loop body = ring size
-  static_assert(!(WIDE && KG == 2), "the K-group variant exists for the 128x128 tile");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kgrp = KG == 2 ? (wave8 >> 2) : 0, wave = wave8 & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = WIDE ? 0 : (wave >> 1) * 64, wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
   int vid;
   {
@@ -752,15 +744,8 @@ __global__ __launch_bounds__(256 * KG, KG == 2 ? 2 : NC8_OCC) void conv_nc8_kern
   for (int i = 0; i < TM; ++i) wvo[i] = (((mb * (BM / 32) + (wm0 >> 5) + i) * ngroup) * 64 + lane) * 16;
 
   // chunks_per_split is even on this path, so a block always owns whole bodies of NG = 4 groups
-  int g_begin = __builtin_amdgcn_readfirstlane(split * p.chunks_per_split * 2);
-  int g_end = __builtin_amdgcn_readfirstlane(min(p.nchunk, (split + 1) * p.chunks_per_split) * 2);
-  if constexpr (KG == 2) {   // the two K groups share the block's range, cut at a body boundary (group 0 takes the odd body)
-    const int nbody = (g_end - g_begin + NG - 1) / NG, half = (nbody + 1) / 2;
-    const int g_mid = min(g_end, g_begin + half * NG);
-    if (kgrp == 0) g_end = g_mid; else g_begin = g_mid;
-    g_begin = __builtin_amdgcn_readfirstlane(g_begin);
-    g_end = __builtin_amdgcn_readfirstlane(g_end);
-  }
+  const int g_begin = __builtin_amdgcn_readfirstlane(split * p.chunks_per_split * 2);
+  const int g_end = __builtin_amdgcn_readfirstlane(min(p.nchunk, (split + 1) * p.chunks_per_split) * 2);
   const int g_last = ngroup - 1;
 
   f32x16 acc[TM][TN];
@@ -830,28 +815,6 @@ __global__ __launch_bounds__(256 * KG, KG == 2 ? 2 : NC8_OCC) void conv_nc8_kern
 #undef NLOADB
 #undef NLOADA
 #undef QSEL
-
-  if constexpr (KG == 2) {
-    // group 1 → LDS → group 0: one accumulator register of all 64 lanes is a conflict-free 256-byte row
-    extern __shared__ float kg_red[];
-    float* mine = kg_red + (wave * 64) * 64 + lane;
-    if (kgrp == 1) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (kgrp == 1) return;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += mine[((i * TN + j) * 16 + r) * 64];
-  }
 
   const bool partial = p.ksplit > 1;
   float* outp = partial ? p.partial + (long)split * p.partial_stride : p.out;
@@ -1172,7 +1135,7 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
   out[((long)bc * Ho + yo) * Wo + xo] = acc * scale;
 }
 
-struct TileChoice { int bm, bn, ksplit, tail_s; int kg = 1; };
+struct TileChoice { int bm, bn, ksplit, tail_s; };
 // Tile/split plan, deterministic (the same geometry gets the same summation order in every run, process and rank):
 // 128x128 tiles (best MFMA density per gathered activation); 64x256 / 64x128 when Cout <= 64; when the grid leaves the
 // chip under-filled, split K across grid.z (fixed-order two-pass reduction). The split factor minimises a cost model
@@ -1204,12 +1167,6 @@ TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, i
 template <int MODE>
 int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   if (p.out_nc8 == 2) t.ksplit = 1, t.tail_s = 0;   // the split16 epilogue has no split-K second pass
-  // NC8 kernel, 128x128 tiles: take one factor of two of a split-K plan inside the block (conv_nc8_kernel<…, KG = 2>): the
-  // same K slices, pairs of them on one CU, half the partial tiles in memory — none at all when the plan was 2
-  if (MODE == MODE_CONV && p.in_nc8 && t.bm == 128 && t.ksplit >= 2 && t.tail_s == 0 && ctx->conv_kgroups) {
-    t.kg = 2;
-    t.ksplit = (t.ksplit + 1) / 2;
-  }
   p.ksplit = t.ksplit;
   p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
   if (p.in_nc8) p.chunks_per_split = (p.chunks_per_split + 1) & ~1;   // the NC8 kernel consumes whole pairs of chunks
@@ -1251,14 +1208,6 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     if (t.bm == 64) {
       DI_REQUIRE(t.bn == 256 && p.out_nc8 == 1, "conv: the 64-row NC8 kernel writes NC8 output on 64x256 tiles");
       hipLaunchKernelGGL((conv_nc8_kernel<1, 1>), grid, dim3(256), 0, ctx->stream, p);
-    } else if (t.kg == 2) {
-      static const char kg_tag = 0;
-      if (di_attr_needed(ctx, &kg_tag)) {
-        DI_CHECK(hipFuncSetAttribute((const void*)conv_nc8_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        DI_CHECK(hipFuncSetAttribute((const void*)conv_nc8_kernel<0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-      }
-      if (p.out_nc8) hipLaunchKernelGGL((conv_nc8_kernel<1, 0, 2>), grid, dim3(512), 65536, ctx->stream, p);
-      else hipLaunchKernelGGL((conv_nc8_kernel<0, 0, 2>), grid, dim3(512), 65536, ctx->stream, p);
     } else if (p.out_nc8) hipLaunchKernelGGL(conv_nc8_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL(conv_nc8_kernel<0>, grid, dim3(256), 0, ctx->stream, p);
   } else if (direct_ok)

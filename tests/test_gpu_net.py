@@ -239,41 +239,6 @@ def test_zoom_front_end_nc8_records_equal_the_nchw_tensor(ctx, small_batch):
     np.testing.assert_array_equal(r.asnumpy().transpose(0, 3, 1, 2), a.asnumpy())
 
 
-@pytest.mark.parametrize("case", [(4, 512, 30, 40, 512, 3, 2, 1), (4, 512, 15, 20, 1024, 3, 2, 1), (2, 1024, 8, 10, 1024, 3, 1, 1),
-                                  (3, 256, 17, 23, 136, 3, 1, 1)])
-def test_conv_nc8_intra_block_k_groups(ctx, case):
-    """Under-filled NC8 layers (conv5 … conv6_1 at the per-GPU share of config 3): one factor of two of the split-K plan is taken
-    inside the block (two K groups of four waves, LDS hand-over). Same K slices as the all-in-memory plan, another association:
-    within 1e-5 of the oracle and of the `conv_kgroups = 0` result, deterministic, for the default plan and forced plans 2 … 5."""
-    B, cin, H, W, cout, k, s, p = case
-    rng = np.random.default_rng(sum(case))
-    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
-    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
-    b = rng.standard_normal(cout).astype(np.float32)
-    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-    ref2 = onet.conv2d(x, w, b, s, p, 0.1, pair_order=2)
-    xin, pk, bias = ctx.array(_to_nc8(x)), _pack_conv(ctx, w), ctx.array(b)
-    scale = max(1.0, np.abs(ref2).max())
-
-    def run(kgroups, plan, out_nc8):
-        lib.deepim_set_option(ctx.handle, b"conv_kgroups", kgroups)
-        lib.deepim_set_option(ctx.handle, b"conv_force_plan", plan)
-        try:
-            out = ctx.zeros((B, cout, Ho, Wo))
-            lib.deepim_conv2d_forward_ex(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, 1, out_nc8)
-            return _from_nc8(out.asnumpy(), (B, cout, Ho, Wo)) if out_nc8 else out.asnumpy()
-        finally:
-            lib.deepim_set_option(ctx.handle, b"conv_force_plan", 0)
-            lib.deepim_set_option(ctx.handle, b"conv_kgroups", 1)
-
-    for plan in (0, 2, 3, 4, 5):
-        for out_nc8 in (1, 0):
-            a = run(1, plan, out_nc8)
-            assert np.abs(a - ref2).max() <= 1e-5 * scale, (plan, out_nc8)
-            np.testing.assert_array_equal(run(1, plan, out_nc8), a)              # deterministic
-            assert np.abs(a - run(0, plan, out_nc8)).max() <= 1e-5 * scale
-
-
 def test_conv_nc8_kernel_random_geometries(ctx):
     """Random geometries through the NC8 kernel (odd sizes, every kernel size / stride / pad the net uses, channel counts off
     the chunk grid so the K padding and the even-chunk rule of split-K are exercised, forced split factors)."""
