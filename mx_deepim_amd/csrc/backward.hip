@@ -397,27 +397,65 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(float* __restrict__ dw, c
   }
   *reinterpret_cast<float4*>(dw + (long)o * I + i4 * 4) = acc;
 }
-// dX[b][i] = Σ_o dy[b][o]·w[o][i]: thread = 4 consecutive i for a tile of 8 batch rows (w is read once per 8 rows)
+// dX[b][i] = Σ_o dy[b][o]·w[o][i] for a tile of 8 batch rows (w is read once per 8 rows). A block = 64 column quads x 4
+// output-row quarters: wave q walks rows [q·O/4, (q+1)·O/4) with its 64 lanes on 1 KB of consecutive columns, four rows in
+// flight; the four partial sums are added in wave order through LDS (deterministic). (Round 2: one thread per column quad
+// over ALL rows and 256 quads per block — 80 blocks for fc6's 84 MB of weights, one for fc7: 122 and 111 µs.)
 __global__ __launch_bounds__(256) void fc_dgrad_kernel(float* __restrict__ dx, const float* __restrict__ dy,
                                                        const float* __restrict__ w, int B, int I, int O) {
-  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float4 part[3][8][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i4 = blockIdx.x * 64 + lane;
   const int b0 = blockIdx.y * 8;
-  if (i4 >= I / 4) return;
+  const bool live = i4 < I / 4;
+  const int oq = (O + 3) / 4, o_lo = min(O, q * oq), o_hi = min(O, o_lo + oq);
   float4 acc[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) acc[b] = make_float4(0, 0, 0, 0);
-  for (int o = 0; o < O; ++o) {
-    const float4 v = *reinterpret_cast<const float4*>(w + (long)o * I + i4 * 4);
+  if (live) {
+    const float* wp = w + (long)i4 * 4;
+    int o = o_lo;
+    for (; o + 4 <= o_hi; o += 4) {
+      float4 v[4];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const float g = b0 + b < B ? dy[(long)(b0 + b) * O + o] : 0.f;
-      acc[b].x = fmaf(g, v.x, acc[b].x); acc[b].y = fmaf(g, v.y, acc[b].y);
-      acc[b].z = fmaf(g, v.z, acc[b].z); acc[b].w = fmaf(g, v.w, acc[b].w);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(wp + (long)(o + u) * I);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const float g = b0 + b < B ? dy[(long)(b0 + b) * O + o + u] : 0.f;
+          acc[b].x = fmaf(g, v[u].x, acc[b].x); acc[b].y = fmaf(g, v[u].y, acc[b].y);
+          acc[b].z = fmaf(g, v[u].z, acc[b].z); acc[b].w = fmaf(g, v[u].w, acc[b].w);
+        }
+    }
+    for (; o < o_hi; ++o) {
+      const float4 v = *reinterpret_cast<const float4*>(wp + (long)o * I);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const float g = b0 + b < B ? dy[(long)(b0 + b) * O + o] : 0.f;
+        acc[b].x = fmaf(g, v.x, acc[b].x); acc[b].y = fmaf(g, v.y, acc[b].y);
+        acc[b].z = fmaf(g, v.z, acc[b].z); acc[b].w = fmaf(g, v.w, acc[b].w);
+      }
     }
   }
+  if (q > 0) {
 #pragma unroll
-  for (int b = 0; b < 8; ++b)
-    if (b0 + b < B) *reinterpret_cast<float4*>(dx + (long)(b0 + b) * I + i4 * 4) = acc[b];
+    for (int b = 0; b < 8; ++b) part[q - 1][b][lane] = acc[b];
+  }
+  __syncthreads();
+  if (q == 0 && live) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b0 + b >= B) continue;
+      float4 r = acc[b];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 t = part[k][b][lane];
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      *reinterpret_cast<float4*>(dx + (long)(b0 + b) * I + i4 * 4) = r;
+    }
+  }
 }
 __global__ void fc_bgrad_kernel(float* __restrict__ db, const float* __restrict__ dy, int B, int O) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,7 +646,7 @@ extern "C" int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* 
   if (B == 0) return 0;
   DI_REQUIRE((I & 3) == 0, "fc_backward: input width must be a multiple of 4");
   if (dw) hipLaunchKernelGGL(fc_wgrad_kernel, dim3(di_div_up((long)O * (I / 4), 256)), dim3(256), 0, ctx->stream, dw, dy, x, B, I, O);
-  if (dx) hipLaunchKernelGGL(fc_dgrad_kernel, dim3(di_div_up(I / 4, 256), di_div_up(B, 8)), dim3(256), 0, ctx->stream, dx, dy, w, B, I, O);
+  if (dx) hipLaunchKernelGGL(fc_dgrad_kernel, dim3(di_div_up(I / 4, 64), di_div_up(B, 8)), dim3(256), 0, ctx->stream, dx, dy, w, B, I, O);
   if (db) hipLaunchKernelGGL(fc_bgrad_kernel, dim3(di_div_up(O, 64)), dim3(64), 0, ctx->stream, db, dy, B, O);
   DI_LAUNCH_CHECK();
   return 0;

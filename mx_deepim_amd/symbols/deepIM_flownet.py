@@ -743,7 +743,8 @@ def _train_methods():
         lib.deepim_bias_grad(h, self.grad[name + "_bias"], dy, B, cout, ho * wo)
         lib.deepim_scatter2d(h, self.ws["dil"], dy, B * cout, ho, wo, hf, wf, 1, 1, 1)
         lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
-        lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.params[name + "_weight"], cin, cout, 4, 4, 3)
+        order = lib.load().deepim_conv_weight_order(h, B, cout, hf, wf, cin, 4, 4, 2, 0)         # packed for this one use
+        lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.params[name + "_weight"], cin, cout, 4, 4, order)
         lib.deepim_conv2d_forward(h, dx, self.ws["dil"], self.ws["wt_packed"], None, B, cout, hf, wf, cin, 4, 4, 2, 0,
                                   ctypes.c_float(1.0), 0, 0)
 
