@@ -460,6 +460,10 @@ int deepim_conv_subkernel_flip(deepim_ctx* ctx, float* wt, const float* w, int C
                                int nky, int nkx);
 int deepim_interleave2d(deepim_ctx* ctx, float* dx /*BC,H,W*/, const float* src /*BC,Hs,Ws*/, int BC, int Hs, int Ws, int cy,
                         int cx, int H, int W, int py, int px);
+/* the class convolution and the interleave in one: the final stores of the conv kernels (and of their split-K second pass)
+ * put the window of the result on out (B,Cout,Hd,Wd)[.., 2i + py, 2j + px] — no class buffer */
+int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, int B, int Cin, int H, int W,
+                                int Cout, int kh, int kw, int pad, int cy, int cx, int Hd, int Wd, int py, int px);
 /* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
 int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
 /* the same with an offset: out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x], zeros elsewhere — also the backward of

@@ -93,9 +93,28 @@ struct ConvParams {
   int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW, 1 = NC8; output only: 2 = split16 fp16 pairs)
   float out_scale;          // split16 output: stored value = result · out_scale
   int* status;              // context status word (split16 output: saturation flag)
+  // Output remap of the final NCHW stores (not of split-K partials): the window [rm_cy, rm_cy + rm_hq) x [rm_cx, rm_cx + rm_wq) of
+  // the (Ho, Wo) result goes to out[.., 2i + rm_py, 2j + rm_px] of a (rm_H, rm_W) plane; pixels outside the window are dropped.
+  // This is how a parity class of a stride-2 data gradient lands in dx without a class buffer (deepim_conv2d_forward_remap).
+  int rm_on, rm_cy, rm_cx, rm_hq, rm_wq, rm_py, rm_px, rm_H, rm_W;
   const float* wd8;         // weights for NC8 inputs [Cout/32][group = (c8,ky,kx)][lane][4]
   const int2* tab8;         // per group: {byte offset (c8*H*W + ky*W + kx)*32, bit ky*8+kx}
 };
+
+struct Remap { int on, cy, cx, hq, wq, py, px, H, W, Wo; };
+__host__ __device__ inline Remap remap_of(const ConvParams& p) {
+  return {p.rm_on, p.rm_cy, p.rm_cx, p.rm_hq, p.rm_wq, p.rm_py, p.rm_px, p.rm_H, p.rm_W, p.Wo};
+}
+// pixel r of the (Ho, Wo) result → offset inside a channel plane of the destination and that plane's size; false = dropped
+__device__ __forceinline__ bool remap_pixel(const Remap& m, int r, int hw, long& poff, long& plane) {
+  if (!m.on) { poff = r; plane = hw; return true; }
+  const int ho = r / m.Wo, wo = r - ho * m.Wo;
+  const int i = ho - m.cy, j = wo - m.cx;
+  if ((unsigned)i >= (unsigned)m.hq || (unsigned)j >= (unsigned)m.wq) return false;
+  poff = (long)(2 * i + m.py) * m.W + 2 * j + m.px;
+  plane = (long)m.H * m.W;
+  return true;
+}
 
 template <int BM, int BN, int MODE, int NT = 256>
 __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
@@ -324,11 +343,14 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
     const long op = n0 + wn0 + j * 32 + lcol;
     if (op >= npix) continue;
     long obase;
+    long cstride = (long)p.Ho * p.Wo;
     if (MODE == MODE_CONV) {
       const int hw = p.Ho * p.Wo;
       const int n = (int)(op / hw);
       const int r = (int)(op - (long)n * hw);
-      obase = ((long)n * ctotal + coff) * hw + r;
+      long poff = r;
+      if (!partial && !remap_pixel(remap_of(p), r, hw, poff, cstride)) continue;
+      obase = ((long)n * ctotal + coff) * cstride + poff;
     } else {
       const int oy0 = (par_y - p.crop_y) & 1, ox0 = (par_x - p.crop_x) & 1;
       const int nqy = (p.Ho - oy0 + 1) >> 1, nqx = (p.Wo - ox0 + 1) >> 1;
@@ -338,7 +360,6 @@ __global__ __launch_bounds__(NT, 4) void conv_mfma_kernel(ConvParams p) {
       const int qy = r / nqx, qx = r - qy * nqx;
       obase = ((long)n * ctotal + coff) * p.Ho * p.Wo + (long)(2 * qy + oy0) * p.Wo + (2 * qx + ox0);
     }
-    const long cstride = (long)p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -651,7 +672,9 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
     const int hw = p.Ho * p.Wo;
     const int n = (int)(op / hw);
     const int r0 = (int)(op - (long)n * hw);
-    const long obase = ((long)n * ctotal + coff) * hw + r0;
+    long poff = r0, plane = hw;
+    if (!partial && !remap_pixel(remap_of(p), r0, hw, poff, plane)) continue;
+    const long obase = ((long)n * ctotal + coff) * plane + poff;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -663,7 +686,7 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
             v = v + (p.bias ? p.bias[co] : 0.f);
             v = v > 0.f ? v : v * p.slope;
           }
-          outp[obase + (long)co * hw] = v;
+          outp[obase + (long)co * plane] = v;
         }
       }
     }
@@ -947,24 +970,26 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                             const float* __restrict__ bias, long total, long stride,
                                                             int S, int Cout, int hw, int ctotal, int coff,
-                                                            float slope) {
+                                                            float slope, Remap rm) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  const int r = (int)(i % hw);
+  long poff, plane;
+  if (!remap_pixel(rm, r, hw, poff, plane)) return;
   float v = partial[i];
   for (int s = 1; s < S; ++s) v += partial[(long)s * stride + i];
-  const int r = (int)(i % hw);
   const int c = (int)((i / hw) % Cout);
   const long n = i / ((long)hw * Cout);
   v = v + (bias ? bias[c] : 0.f);
   v = v > 0.f ? v : v * slope;
-  out[(n * ctotal + coff + c) * hw + r] = v;
+  out[(n * ctotal + coff + c) * plane + poff] = v;
 }
 
 // tail-split second pass: one block per remainder tile; out = lrelu(Σ_slice partial + bias), slices in fixed order
 __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                           const float* __restrict__ bias, int n_full, int R, int S,
                                                           int gx, int Cout, long npix, int hw, int ctotal, int coff,
-                                                          float slope) {
+                                                          float slope, Remap rm) {
   const int rt = blockIdx.x, vid = n_full + rt;
   const int bx = vid % gx, mb = vid / gx;
   const float* pp = partial + (long)rt * 16384;
@@ -978,7 +1003,9 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ ou
     v = v > 0.f ? v : v * slope;
     const long n = pix / hw;
     const int r = (int)(pix - n * hw);
-    out[(n * ctotal + coff + co) * hw + r] = v;
+    long poff, plane;
+    if (!remap_pixel(rm, r, hw, poff, plane)) continue;
+    out[(n * ctotal + coff + co) * plane + poff] = v;
   }
 }
 
@@ -1197,7 +1224,7 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
       p.tail_partial = (float*)scratch;
       hipLaunchKernelGGL(conv_direct_kernel<2>, dim3(p.n_full + p.n_tail_pad), dim3(256), 0, ctx->stream, p);
       hipLaunchKernelGGL(tail_reduce_kernel, dim3(R), dim3(256), 0, ctx->stream, p.out, p.tail_partial, p.bias, n_full, R,
-                         p.tail_s, p.gx, p.Cout, p.npix, p.Ho * p.Wo, p.out_ctotal, p.out_coff, p.slope);
+                         p.tail_s, p.gx, p.Cout, p.npix, p.Ho * p.Wo, p.out_ctotal, p.out_coff, p.slope, remap_of(p));
       DI_LAUNCH_CHECK();
       return 0;
     }
@@ -1230,7 +1257,7 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
                          p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
-                         p.slope);
+                         p.slope, remap_of(p));
   }
   DI_LAUNCH_CHECK();
   return 0;
@@ -1407,7 +1434,8 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
 
 static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
                                int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
-                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale);
+                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale,
+                               const Remap* rm = nullptr);
 
 extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                         const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
@@ -1415,6 +1443,22 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
                                         int out_nc8) {
   return conv2d_forward_impl(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal, out_coff,
                              in_nc8, out_nc8 ? 1 : 0, 1.f);
+}
+
+// One output parity class of a stride-2 data gradient, straight into dx: a stride-1 convolution of the un-dilated gradient `in`
+// (B,Cin,H,W) with the class's flipped sub-kernel (kh x kw, symmetric pad), whose result window [cy, cy + hq) x [cx, cx + wq)
+// — hq = ⌈(Hd - py) / 2⌉, wq = ⌈(Wd - px) / 2⌉ — is written to out (B,Cout,Hd,Wd)[.., 2i + py, 2j + px]. No bias, no activation.
+extern "C" int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, int B, int Cin,
+                                           int H, int W, int Cout, int kh, int kw, int pad, int cy, int cx, int Hd, int Wd,
+                                           int py, int px) {
+  Remap rm;
+  rm.on = 1; rm.cy = cy; rm.cx = cx; rm.py = py; rm.px = px; rm.H = Hd; rm.W = Wd;
+  rm.hq = (Hd - py + 1) / 2; rm.wq = (Wd - px + 1) / 2;
+  rm.Wo = W + 2 * pad - kw + 1;
+  const int Ho = H + 2 * pad - kh + 1;
+  DI_REQUIRE(py >= 0 && py < 2 && px >= 0 && px < 2 && cy >= 0 && cx >= 0 && rm.hq + cy <= Ho && rm.wq + cx <= rm.Wo,
+             "conv2d_forward_remap: class window outside the convolution result");
+  return conv2d_forward_impl(ctx, out, in, packed_w, nullptr, B, Cin, H, W, Cout, kh, kw, 1, pad, 1.f, 0, 0, 0, 0, 1.f, &rm);
 }
 
 // NCHW fp32 in → split16 out (conv1 of the split-fp16 encoder): the fp32 MFMA convolution with the split folded into its
@@ -1429,7 +1473,7 @@ extern "C" int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16,
 
 static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
                                int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
-                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale) {
+                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale, const Remap* rm) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
@@ -1441,11 +1485,11 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
       const int Bc = (int)((limit - 1) / per_sample);
       DI_REQUIRE(Bc >= 1, "conv2d: one sample exceeds 2 GiB");
       const int Ho_ = (H + 2 * pad - kh) / stride + 1, Wo_ = (W + 2 * pad - kw) / stride + 1;
-      const size_t out_sample = (size_t)(out_ctotal > 0 ? out_ctotal : Cout) * Ho_ * Wo_;   // split16: 2·Cout halves = Cout floats
+      const size_t out_sample = (size_t)(out_ctotal > 0 ? out_ctotal : Cout) * (rm ? (size_t)rm->H * rm->W : (size_t)Ho_ * Wo_);   // split16: 2·Cout halves = Cout floats
       for (int b0 = 0; b0 < B; b0 += Bc) {
         const int rc = conv2d_forward_impl(ctx, out + (size_t)b0 * out_sample, in + (size_t)b0 * Cin * H * W, packed_w, bias,
                                            min(Bc, B - b0), Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal,
-                                           out_coff, in_nc8, out_nc8, out_scale);
+                                           out_coff, in_nc8, out_nc8, out_scale, rm);
         if (rc) return rc;
       }
       return 0;
@@ -1462,6 +1506,12 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.slope = slope; p.crop_y = p.crop_x = 0;
+  p.rm_on = 0; p.rm_cy = p.rm_cx = p.rm_hq = p.rm_wq = p.rm_py = p.rm_px = p.rm_H = p.rm_W = 0;
+  if (rm) {
+    DI_REQUIRE(!in_nc8 && !out_nc8 && Cout > 4, "conv2d remap: NCHW in / out on the MFMA kernels only");
+    p.rm_on = 1; p.rm_cy = rm->cy; p.rm_cx = rm->cx; p.rm_hq = rm->hq; p.rm_wq = rm->wq; p.rm_py = rm->py; p.rm_px = rm->px;
+    p.rm_H = rm->H; p.rm_W = rm->W;
+  }
   p.npix = (long)B * p.Ho * p.Wo;
   p.pad_bytes = (pad * W + pad) * 4;
   DI_REQUIRE((size_t)B * Cin * H * W * 4 + p.pad_bytes < 0x7fffffffUL, "conv2d: input tensor must be < 2 GiB per launch");
@@ -1548,6 +1598,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.slope = slope; p.crop_y = crop_y; p.crop_x = crop_x;
+  p.rm_on = 0; p.rm_cy = p.rm_cx = p.rm_hq = p.rm_wq = p.rm_py = p.rm_px = p.rm_H = p.rm_W = 0;
   // every parity class has at most ceil(Ho/2)*ceil(Wo/2) pixels; size the grid for the largest, the
   // kernel masks with its own per-class count
   p.npix = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);

@@ -607,12 +607,6 @@ def _train_methods():
             self.ws["zm_a"], self.ws["zm_b"], self.ws["zm_f"] = ctx.empty((B, 1, H, W)), ctx.empty((B, 1, H, W)), ctx.empty((B, 4))
             self.ws["d_mask_hi"] = ctx.empty((B, 1, H, W))
         self.ws["dil"], self.ws["wt"], self.ws["wt_packed"] = ctx.empty((dil,)), ctx.empty((wmax,)), ctx.empty((pmax,))
-        # class buffer of the stride-2 data gradients: one parity class of the largest dx plus the border of a full convolution
-        cls = 1
-        for name, cin_, hh_, ww_, cout_, k_, s__, p__ in self.enc_geom[1:]:
-            if s__ == 2:
-                cls = max(cls, B * cin_ * ((hh_ + 1) // 2 + k_) * ((ww_ + 1) // 2 + k_))
-        self.ws["cls"] = ctx.empty((cls,))
         self.ws["g256a"], self.ws["g256b"] = ctx.empty((B, 256)), ctx.empty((B, 256))
         self.ws["dy7"], self.ws["w7"], self.ws["dw7"], self.ws["db7"] = ctx.empty((B, 7)), ctx.empty((7, 256)), ctx.empty((7, 256)), ctx.empty((7,))
         self.ws["d_points"] = ctx.empty((B, 3, num_points))
@@ -677,8 +671,8 @@ def _train_methods():
         """dx (B,cin,hh,ww) of a Convolution (cout,cin,k,k; stride s_, pad p_) given dz (B,cout,ho,wo).
         stride 1: the forward MFMA conv kernel on dz with the transposed, flipped weights, pad k-1-p.
         stride 2: four stride-1 convolutions of the UN-dilated dz, one per output parity class (y % 2, x % 2) with the
-        sub-kernel of the taps that class meets (k = 3: 1, 2, 2 and 4 taps; k = 5: 4, 6, 6 and 9), each written to a class
-        buffer and interleaved into dx — exactly the ideal multiply-adds (round 2 convolved a zero-dilated dz: 4x those)."""
+        sub-kernel of the taps that class meets (k = 3: 1, 2, 2 and 4 taps; k = 5: 4, 6, 6 and 9), each storing its result
+        window on its parity positions of dx — exactly the ideal multiply-adds (round 2 convolved a zero-dilated dz: 4x those)."""
         h = self.ctx.handle
         if s_ == 1:
             lib.deepim_conv_flip_weights(h, self.ws["wt"], w_raw, cout, cin, k, k)
@@ -694,15 +688,12 @@ def _train_methods():
                 nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
                 cy0, cx0 = (py + p_ - ky0) // 2, (px + p_ - kx0) // 2
                 P = max(nky, nkx) - 1
-                hf, wf = ho + 2 * P - nky + 1, wo + 2 * P - nkx + 1
-                cls = self.ws["cls"]
-                assert B * cin * hf * wf <= cls.size
                 lib.deepim_conv_subkernel_flip(h, self.ws["wt"], w_raw, cout, cin, k, k, ky0, kx0, nky, nkx)
                 order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
                 lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, nky, nkx, order)
-                lib.deepim_conv2d_forward(h, cls, dz, self.ws["wt_packed"], None, B, cout, ho, wo, cin, nky, nkx, 1, P,
-                                          ctypes.c_float(1.0), 0, 0)
-                lib.deepim_interleave2d(h, dx, cls, B * cin, hf, wf, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
+                # the conv kernels' final stores (and their split-K second pass) put the class window straight onto dx
+                lib.deepim_conv2d_forward_remap(h, dx, dz, self.ws["wt_packed"], B, cout, ho, wo, cin, nky, nkx, P,
+                                                cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
 
     def _conv_backward(self, li, dz, dx):
         """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into

@@ -112,6 +112,20 @@ def test_stride2_dgrad_by_parity_classes_matches_oracle(ctx, case):
     assert taps == k * k                                       # the four classes partition the kernel: the ideal multiply-adds
     got = dx.asnumpy()
     close(got, dx_ref)
+    # the same four convolutions storing their window straight onto dx (what the training graph runs): identical values
+    dx2 = ctx.array(np.full(x.shape, 7.0, np.float32))
+    for py in range(2):
+        for px in range(2):
+            ky0, kx0 = (py + p) % 2, (px + p) % 2
+            nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
+            cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
+            P = max(nky, nkx) - 1
+            lib.deepim_conv_subkernel_flip(h, wt, wd, cout, cin, k, k, ky0, kx0, nky, nkx)
+            order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
+            lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, nky, nkx, order)
+            lib.deepim_conv2d_forward_remap(h, dx2, dz, pk, B, cout, ho, wo, cin, nky, nkx, P, cy0 + P - (nky - 1),
+                                            cx0 + P - (nkx - 1), H, W, py, px)
+    np.testing.assert_array_equal(dx2.asnumpy(), got)
     # rows / columns no output pixel reaches (odd frame, pad) get exact zeros, like the oracle
     assert np.abs(got[dx_ref == 0]).max(initial=0.0) == 0.0
 

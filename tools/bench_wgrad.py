@@ -57,11 +57,9 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
                     nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
                     cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
                     P = max(nky, nkx) - 1
-                    hf, wf = ho + 2 * P - nky + 1, wo + 2 * P - nkx + 1
                     lib.deepim_conv_subkernel_flip(h, wt, w, cout, cin, k, k, ky0, kx0, nky, nkx)
                     lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, nky, nkx, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P))
-                    lib.deepim_conv2d_forward(h, cls, dz, pk, None, B, cout, ho, wo, cin, nky, nkx, 1, P, cf(1.0), 0, 0)
-                    lib.deepim_interleave2d(h, dx, cls, B * cin, hf, wf, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
+                    lib.deepim_conv2d_forward_remap(h, dx, dz, pk, B, cout, ho, wo, cin, nky, nkx, P, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
         ms = timeit(dgrad)
         tot["dg"] += ms
         line += " | dgrad %.3f ms %5.1f TF" % (ms, fl / ms / 1e9)
