@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Dev: per-kernel PMC summary of a rocprofv3 --pmc run (counter_collection.csv). usage: pmc_summary.py <counter_collection.csv>
+Prints, per kernel name (last dispatch of each distinct (name, grid)): MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)
+… (same formula as profiles/r02_pmc_*.md), wait / active fractions of SQ_WAVE_CYCLES, LDS bank conflict share."""
+import csv, re, sys
+from collections import OrderedDict
+rows = list(csv.DictReader(open(sys.argv[1])))
+disp = OrderedDict()
+for r in rows:
+    key = r["Dispatch_Id"]
+    d = disp.setdefault(key, {"name": r["Kernel_Name"], "grid": r.get("Grid_Size", "?"), "vgpr": r.get("VGPR_Count", "?"), "agpr": r.get("Accum_VGPR_Count", "?")})
+    d[r["Counter_Name"]] = float(r["Counter_Value"])
+last = OrderedDict()
+for d in disp.values():
+    last[(d["name"], d["grid"])] = d
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*$", "", n)[:44]
+print("%-44s %9s %9s %6s %6s %6s %6s %6s" % ("kernel", "grid", "vgpr+a", "mfma", "w_any", "w_inst", "active", "ldsbc"))
+for (n, g), d in last.items():
+    if "wgrad" not in n and "conv" not in n: continue
+    wc = d.get("SQ_WAVE_CYCLES", 0) or 1
+    gui = d.get("GRBM_GUI_ACTIVE", 0) or 1
+    print("%-44s %9s %9s %6.3f %6.2f %6.2f %6.2f %6.3f" % (short(n), g, "%s+%s" % (d["vgpr"], d["agpr"]),
+          d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 128), d.get("SQ_WAIT_ANY", 0) / wc, d.get("SQ_WAIT_INST_ANY", 0) / wc,
+          d.get("SQ_ACTIVE_INST_ANY", 0) / wc, d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, d.get("SQ_ACTIVE_INST_LDS", 0))))
