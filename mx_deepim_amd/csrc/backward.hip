@@ -284,26 +284,34 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 ra[NA];
-  float rb[8];
+  // two register sets: the loads of a chunk are issued TWO chunks before its LDS store (one chunk of loads in flight, consumed
+  // at the end of the same chunk, left the waves waiting for memory behind their MFMAs)
+  f32x4 raA[NA], raB[NA];
+  float rbA[8], rbB[8];
+  const int chunks = p.B * cps;                      // < 2^31 (checked on the host)
+  const int c_begin = sl * p.groups_per_slice, c_end = min(chunks, c_begin + p.groups_per_slice);
   // every byte offset first, then the loads back to back: left to itself the compiler interleaves address arithmetic with
   // the loads, reuses a load's destination register for the next address and waits (vmcnt(0)) in between, and turns
   // `valid ? offset : OOB` into branches — the selects below are plain bit operations (bit 31 set = out of range → 0.0)
-  auto load_regs = [&](long c) {
-    const int n = (int)(c / cps);
-    const int pc = (int)(c - (long)n * cps) * WG_PIX;
+  // (chunks at or past c_end load zeros: the loop below is branch-free — with loads under `if` the compiler cannot count what is in
+  // flight and drains vmcnt(0) at every LDS store, i.e. the prefetch depth collapses to one chunk)
+  auto load_regs = [&](int c, f32x4 (&ra)[NA], float (&rb)[8]) {
+    const unsigned dead = (unsigned)(c >= c_end);
+    c = min(c, chunks - 1);
+    const int n = c / cps;                            // 32-bit: a 64-bit division is a software loop inside the pipeline
+    const int pc = (c - n * cps) * WG_PIX;
     const int pa = pc + qA * 4;                       // HW % 4 == 0: the quad is entirely inside or entirely outside the sample
     unsigned offa[NA], offb[8];
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const unsigned inv = (a_row[r] >> 31) | (unsigned)(pa >= HW);
+      const unsigned inv = dead | (a_row[r] >> 31) | (unsigned)(pa >= HW);
       offa[r] = ((unsigned)(((n * p.Cout + (int)(a_row[r] & 0x7fffffffu)) * HW + pa) * 4) & 0x7fffffffu) | (inv << 31);
     }
     const int pb = pc + pixB;
     const int ho = pb / p.Wo, wo = pb - ho * p.Wo;
     const int hi0 = ho * p.stride, wi0 = wo * p.stride;
     const unsigned nbase = (unsigned)(n * p.Cin * p.H * p.W);
-    const unsigned pinv = (unsigned)(pb >= HW);
+    const unsigned pinv = dead | (unsigned)(pb >= HW);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
@@ -317,24 +325,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
     for (int e = 0; e < 8; ++e) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_regs = [&](int buf) {
+  auto store_regs = [&](int buf, const f32x4 (&ra)[NA], const float (&rb)[8]) {
 #pragma unroll
     for (int r = 0; r < NA; ++r) *reinterpret_cast<f32x4*>(&As[buf][(rowA + 64 * r) * WG_P + qA * 4]) = ra[r];
 #pragma unroll
     for (int e = 0; e < 8; ++e) Bs[buf][(krow0 + 16 * e) * WG_P + pixB] = rb[e];
   };
 
-  const long chunks = (long)p.B * cps;
-  const long c_begin = (long)sl * p.groups_per_slice, c_end = min(chunks, c_begin + p.groups_per_slice);
-  if (c_begin < c_end) {
-    load_regs(c_begin);
-    store_regs(0);
-  }
-  __syncthreads();
-  for (long c = c_begin; c < c_end; ++c) {
-    const int buf = (int)(c - c_begin) & 1;
-    const bool more = c + 1 < c_end;
-    if (more) load_regs(c + 1);
+  auto compute = [&](int buf) {
     f32x4 af[TM][2], bf[2][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -353,8 +351,23 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j >> 2][j & 3], bf[q][j >> 2][j & 3], acc[i][q], 0, 0, 0);
-    if (more) store_regs(buf ^ 1);
+  };
+  // iteration c: the set holds chunk c+1 (loaded during iterations c-2 … c-1) → LDS[buf^1]; its registers then take chunk c+3;
+  // chunk c is multiplied out of LDS[buf]
+  auto iter = [&](int c, int buf, f32x4 (&ra)[NA], float (&rb)[8]) {
+    store_regs(buf ^ 1, ra, rb);
+    load_regs(c + 3, ra, rb);
+    compute(buf);
     __syncthreads();
+  };
+  load_regs(c_begin, raA, rbA);
+  store_regs(0, raA, rbA);
+  load_regs(c_begin + 1, raA, rbA);
+  load_regs(c_begin + 2, raB, rbB);
+  __syncthreads();
+  for (int c = c_begin; c < c_end; c += 2) {   // an odd count runs one phantom chunk of zeros
+    iter(c, 0, raA, rbA);
+    iter(c + 1, 1, raB, rbB);
   }
   float* out = p.partial + (long)sl * p.Cout * p.K;
 #pragma unroll
@@ -569,6 +582,7 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
     // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)
     const long chunks = (long)B * di_div_up(HW, WG_PIX);
+    DI_REQUIRE(chunks < (1L << 30), "conv2d_wgrad: too many pixel chunks");
     // slice count: the blocks of a launch run in rounds of `slots` (256 CUs x 3 resident blocks, 4 for the 64-row tile); a
     // count just above a multiple of that leaves a nearly empty last round (1024 blocks on 768 slots: a third of the chip
     // idle for half the kernel). Pick S minimising rounds x chunks-per-slice (+ the reduce pass), slices >= 16 chunks.
