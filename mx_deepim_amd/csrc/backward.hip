@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
 // dwordx4. Zero padding and ragged edges through the raw-buffer out-of-range offset; the global loads of chunk c+1 fly while
 // chunk c is multiplied. BM = 64 (conv1: Cout 64): 32x64 wave tiles instead of a half-empty 128-row tile.
 constexpr int WG_PIX = 16, WG_P = 20;
+#ifndef WG_INTERLEAVE
+#define WG_INTERLEAVE 1   // 1: one iteration is ONE scheduling region and the memory operations are spread over the MFMA slots
+#endif
 template <int BM>
 __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   // 41 KB of LDS per block: three blocks per CU
   constexpr int TM = BM / 64, NA = BM / 64;          // MFMA row tiles per wave; dZ dwordx4 loads per thread and chunk
@@ -318,12 +321,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
       const unsigned inv = pinv | (b_plane[e] >> 31) | (unsigned)((unsigned)hi >= (unsigned)p.H) | (unsigned)((unsigned)wi >= (unsigned)p.W);
       offb[e] = (((nbase + (b_plane[e] & 0x7fffffffu) + (unsigned)(hi * p.W + wi)) * 4u) & 0x7fffffffu) | (inv << 31);
     }
+#if !WG_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int r = 0; r < NA; ++r) ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)offa[r], 0, 0));
 #pragma unroll
     for (int e = 0; e < 8; ++e) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
+#if !WG_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   auto store_regs = [&](int buf, const f32x4 (&ra)[NA], const float (&rb)[8]) {
 #pragma unroll
@@ -358,6 +365,21 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
     store_regs(buf ^ 1, ra, rb);
     load_regs(c + 3, ra, rb);
     compute(buf);
+#if WG_INTERLEAVE
+    // issue order of the region (hipcc alone: all stores, all address arithmetic, all loads, then reads → wait → 16 MFMAs twice,
+    // so a wave's own memory operations never overlap its own MFMAs): the first fragments, then one MFMA per slot with the
+    // address arithmetic and ONE memory operation behind it — the LDS stores of chunk c+1, the second-half fragments, the ten
+    // global loads of chunk c+3
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + 2), 0);          // DS reads: first-half fragments
+#pragma unroll
+    for (int k = 0; k < 8 * TM * 2; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                   // a few VALU (byte offsets)
+      if (k < NA + 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write (NA b128 + 4 write2)
+      else if (k < NA + 4 + (TM + 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read: second-half fragments
+      else if (k < NA + 4 + (TM + 2) + NA + 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+    }
+#endif
     __syncthreads();
   };
   load_regs(c_begin, raA, rbA);
@@ -591,7 +613,9 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
     float best = 1e30f;
     for (long cand = 1; cand <= max(1L, min(chunks / 16, 4 * slots / tiles)); ++cand) {
       const long cps_ = di_div_up(chunks, cand), s_eff = di_div_up(chunks, cps_);
-      const float cost = (float)di_div_up(tiles * s_eff, slots) * (float)cps_ + (s_eff > 1 ? 4.f + 0.02f * (float)s_eff : 0.f);
+      // + the second pass: every slice writes and re-reads Cout·K floats (≈4.5e-7 chunk times per float at ≈4 TB/s)
+      const float cost = (float)di_div_up(tiles * s_eff, slots) * (float)cps_ +
+                         (s_eff > 1 ? 2.f + (float)s_eff * (0.02f + 4.5e-7f * (float)n_dw) : 0.f);
       if (cost < best * 0.99f) { best = cost; S = cand; }
     }
     p.groups_per_slice = (int)di_div_up(chunks, S);
