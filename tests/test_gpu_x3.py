@@ -265,3 +265,23 @@ def test_x3_closed_loop_tracks_the_fp32_loop(ctx):
     assert np.abs(ref - batch["src_pose"][0]).max() > 1e-3          # the loop moved the poses
     assert np.abs(run("default") - ref).max() < 1e-6
     assert np.abs(run("x3") - ref).max() < 1e-6
+
+
+def test_x3_and_fp16_plans_do_not_depend_on_the_process_environment():
+    """Round 2 read DEEPIM_F16_TN4 / _W8 / _NO_TAIL / _NO_DMA from the environment on the launch path: tiling, hence summation
+    order, could differ between two ranks of one job. They are context options now (`f16_dev_flags`): two processes with
+    different environments produce bit-identical x3 and fp16 outputs (tail-split, split-K and whole-tile layers)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for extra in ({}, {"DEEPIM_F16_TN4": "1", "DEEPIM_F16_W8": "1", "DEEPIM_F16_NO_TAIL": "1", "DEEPIM_F16_NO_DMA": "1"}):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DEEPIM_F16")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(here, "_x3_plan_worker.py")], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("sha256")][-1])
+    assert outs[0] == outs[1], outs
+    src = open(os.path.join(os.path.dirname(here), "mx_deepim_amd", "csrc", "conv_f16.hip")).read()
+    assert src.count("getenv(") == 1 and 'getenv("DEEPIM_CONV_VERBOSE")' in src        # only the verbose switch is left
