@@ -254,6 +254,12 @@ int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*
  * that runs NCHW activations only (the training graph and its data gradients) passes 3 and saves a third of the re-pack
  * after every SGD step; a left-out order must not be used by the forward call (NC8 input needs bit 4). */
 int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw, int orders);
+/* packed weights of a DATA GRADIENT straight from the layer's raw tensor w_layer (Co_l,Ci_l,kh_l,kw_l): the packed convolution has
+ * Cout = Ci_l, Cin = Co_l, an nky x nkx kernel with tap (a,b) = layer tap (ky0 + st·(nky-1-a), kx0 + st·(nkx-1-b)). st = 1 with
+ * the whole kernel = transposed + flipped weights (replaces deepim_conv_flip_weights + pack); st = 2 = one output parity class of
+ * a stride-2 layer (replaces deepim_conv_subkernel_flip + pack). orders: bits 1 | 2. */
+int deepim_conv_pack_dgrad(deepim_ctx* ctx, float* packed_w, const float* w_layer, int Co_l, int Ci_l, int kh_l, int kw_l, int ky0,
+                           int kx0, int st, int nky, int nkx, int orders);
 /* the one order (1 or 2) deepim_conv2d_forward will read for this geometry under the context's current options */
 int deepim_conv_weight_order(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad);
 int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,

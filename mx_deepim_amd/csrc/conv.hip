@@ -1045,9 +1045,20 @@ __global__ __launch_bounds__(256) void relayout_nc8_kernel(float* __restrict__ d
 }
 
 // ------------------------------------------------------------ packing ----
+// What the pack kernels read. on = 0: w is the convolution's own (Cout, Cin, kh·kw) tensor. on = 1: the weights of a DATA
+// GRADIENT read straight out of the layer's raw tensor wl (Co_l, Ci_l, kh_l, kw_l) — the convolution being packed has
+// Cout = Ci_l, Cin = Co_l and an (nky x nkx) kernel whose tap (a, b) is the layer's tap (ky0 + st·(nky-1-a), kx0 + st·(nkx-1-b)):
+// st = 1, ky0 = kx0 = 0 is the transposed + flipped kernel of a stride-1 layer, st = 2 the sub-kernel of one output parity
+// class of a stride-2 layer (csrc/backward.hip). Fusing the view into the pack saves the flip pass and its buffer.
+struct WView { int on, Ci_l, kh_l, kw_l, ky0, kx0, st, nky, nkx; };
+__device__ __forceinline__ float wview_at(const WView& v, const float* __restrict__ w, int co, int ci, int t, int Cin, int khw) {
+  if (!v.on) return w[((long)co * Cin + ci) * khw + t];
+  const int a = t / v.nkx, b = t - a * v.nkx;
+  return w[(((long)ci * v.Ci_l + co) * v.kh_l + v.ky0 + v.st * (v.nky - 1 - a)) * v.kw_l + v.kx0 + v.st * (v.nkx - 1 - b)];
+}
 // conv:   packed[g][kc][kk][mm] = w[(g*64+mm)][kc*16+kk]  (w as (Cout, K) row-major), zero padded
 __global__ void pack_conv_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int K, int nchunk,
-                                 long total) {
+                                 long total, WView v, int khw) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int mm = (int)(i % GRAN);
@@ -1055,7 +1066,7 @@ __global__ void pack_conv_kernel(float* __restrict__ packed, const float* __rest
   const int kc = (int)((i / (GRAN * KT)) % nchunk);
   const int g = (int)(i / ((long)GRAN * KT * nchunk));
   const int co = g * GRAN + mm, k = kc * KT + kk;
-  packed[i] = (co < Cout && k < K) ? w[(long)co * K + k] : 0.f;
+  packed[i] = (co < Cout && k < K) ? wview_at(v, w, co, k / khw, k % khw, K / khw, khw) : 0.f;
 }
 // deconv (w: Cin,Cout,4,4): 4 parity classes z = py*2+px; per class K = Cin*4, k = ci*4 + jy*2 + jx,
 // tap ky = py + 2*jy, kx = px + 2*jx:  packed[z][g][kc][kk][mm] = w[ci][g*64+mm][ky][kx]
@@ -1080,14 +1091,14 @@ __global__ void pack_deconv_kernel(float* __restrict__ packed, const float* __re
 
 // direct layout: packed[mt][g/4][lane = h*32 + r][g%4] = w[mt*32 + r][2*ci2 + h][ky][kx], g = (ci2*kh + ky)*kw + kx, zero padded
 __global__ void pack_direct_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, int khw,
-                                   int npair, long total) {
+                                   int npair, long total, WView v) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int q = (int)(i & 3), r = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1);
   const int g = (int)((i >> 8) % (npair / 4)) * 4 + q;
   const int mt = (int)(i / (64L * npair));
   const int co = mt * 32 + r, ci = 2 * (g / khw) + h, t = g % khw;
-  packed[i] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * khw + t] : 0.f;
+  packed[i] = (co < Cout && ci < Cin) ? wview_at(v, w, co, ci, t, Cin, khw) : 0.f;
 }
 __global__ void build_direct_tab_kernel(int2* __restrict__ tab, int npair_real, int n, int kh, int kw, int H, int W) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1389,8 +1400,8 @@ extern "C" int deepim_conv_pack_weights(deepim_ctx* ctx, float* packed_w, const 
   return deepim_conv_pack_weights_ex(ctx, packed_w, w, Cout, Cin, kh, kw, 7);
 }
 
-extern "C" int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw,
-                                           int orders) {
+static int conv_pack_impl(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw, int orders,
+                          const WView& v) {
   DI_DEVICE(ctx);
   DI_REQUIRE(orders >= 1 && orders <= 7, "conv_pack_weights: orders = bits 1 (LDS kernel) | 2 (NCHW register-fed) | 4 (NC8)");
   const int K = Cin * kh * kw, nchunk = chunk_count(K);
@@ -1399,15 +1410,36 @@ extern "C" int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, con
   // leaves its order out — the slot stays allocated and unread
   if (orders & 1)
     hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
-                       nchunk, total);
+                       nchunk, total, v, kh * kw);
   if (orders & 2)
     hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
-                       Cin, kh * kw, nchunk * (KT / 2), total);
-  if (orders & 4)
+                       Cin, kh * kw, nchunk * (KT / 2), total, v);
+  if (orders & 4) {
+    DI_REQUIRE(!v.on, "conv_pack: the NC8 order is not built for data-gradient views");
     hipLaunchKernelGGL(pack_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + 2 * total, w, Cout,
                        Cin, kh * kw, nchunk * 2, total);
+  }
   DI_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int deepim_conv_pack_weights_ex(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin, int kh, int kw,
+                                           int orders) {
+  const WView v = {0, 0, 0, 0, 0, 0, 1, kh, kw};
+  return conv_pack_impl(ctx, packed_w, w, Cout, Cin, kh, kw, orders, v);
+}
+
+// Packed weights of a DATA GRADIENT straight from the layer's raw tensor w_layer (Co_l, Ci_l, kh_l, kw_l): the convolution that is
+// packed has Cout = Ci_l, Cin = Co_l and an nky x nkx kernel, tap (a, b) = layer tap (ky0 + st (nky-1-a), kx0 + st (nkx-1-b)).
+// st = 1, ky0 = kx0 = 0, nky = kh_l, nkx = kw_l: the transposed + flipped kernel (what deepim_conv_flip_weights + pack gave);
+// st = 2: one output parity class of a stride-2 layer (what deepim_conv_subkernel_flip + pack gave). orders: 1 | 2.
+extern "C" int deepim_conv_pack_dgrad(deepim_ctx* ctx, float* packed_w, const float* w_layer, int Co_l, int Ci_l, int kh_l,
+                                      int kw_l, int ky0, int kx0, int st, int nky, int nkx, int orders) {
+  DI_REQUIRE((st == 1 || st == 2) && ky0 >= 0 && kx0 >= 0 && nky >= 1 && nkx >= 1 && ky0 + st * (nky - 1) < kh_l &&
+                 kx0 + st * (nkx - 1) < kw_l && (orders & 4) == 0,
+             "conv_pack_dgrad: taps outside the layer's kernel (or an NC8 order asked for)");
+  const WView v = {1, Ci_l, kh_l, kw_l, ky0, kx0, st, nky, nkx};
+  return conv_pack_impl(ctx, packed_w, w_layer, Ci_l, Co_l, nky, nkx, orders, v);
 }
 
 // Which ONE of the packed operand orders deepim_conv2d_forward (NCHW in, NCHW out) reads for this geometry under the context's

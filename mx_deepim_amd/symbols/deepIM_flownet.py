@@ -675,9 +675,8 @@ def _train_methods():
         window on its parity positions of dx — exactly the ideal multiply-adds (round 2 convolved a zero-dilated dz: 4x those)."""
         h = self.ctx.handle
         if s_ == 1:
-            lib.deepim_conv_flip_weights(h, self.ws["wt"], w_raw, cout, cin, k, k)
             order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_)   # packed for one use
-            lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, k, k, order)
+            lib.deepim_conv_pack_dgrad(h, self.ws["wt_packed"], w_raw, cout, cin, k, k, 0, 0, 1, k, k, order)   # transposed + flipped
             lib.deepim_conv2d_forward(h, dx, dz, self.ws["wt_packed"], None, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_,
                                       ctypes.c_float(1.0), 0, 0)
             return
@@ -688,9 +687,8 @@ def _train_methods():
                 nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
                 cy0, cx0 = (py + p_ - ky0) // 2, (px + p_ - kx0) // 2
                 P = max(nky, nkx) - 1
-                lib.deepim_conv_subkernel_flip(h, self.ws["wt"], w_raw, cout, cin, k, k, ky0, kx0, nky, nkx)
                 order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
-                lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.ws["wt"], cin, cout, nky, nkx, order)
+                lib.deepim_conv_pack_dgrad(h, self.ws["wt_packed"], w_raw, cout, cin, k, k, ky0, kx0, 2, nky, nkx, order)
                 # the conv kernels' final stores (and their split-K second pass) put the class window straight onto dx
                 lib.deepim_conv2d_forward_remap(h, dx, dz, self.ws["wt_packed"], B, cout, ho, wo, cin, nky, nkx, P,
                                                 cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)

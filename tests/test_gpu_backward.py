@@ -69,6 +69,12 @@ def test_conv_backward_kernels_match_oracle(ctx, case):
     dx = ctx.empty(x.shape)
     lib.deepim_conv2d_forward(h, dx, g, pk, None, B, cout, gh, gw, cin, k, k, 1, k - 1 - p, cf(1.0), 0, 0)
     close(dx.asnumpy(), dx_ref)
+    # the same packed weights without the flip pass: the transposed + flipped view read inside the pack kernels
+    pk2 = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cin, cout, k, k) // 4,))
+    lib.deepim_memset(h, pk2, 0, pk2.nbytes)
+    lib.deepim_conv_pack_dgrad(h, pk2, ctx.array(w), cout, cin, k, k, 0, 0, 1, k, k, 3)
+    half = lib.load().deepim_conv_packed_size(cin, cout, k, k) // 4 // 3
+    np.testing.assert_array_equal(pk2.asnumpy()[:2 * half], pk.asnumpy()[:2 * half])
 
 
 # (B, Cin, H, W, Cout, k, p): stride-2 layers incl. odd frame sizes (conv6: 15x20 -> 8x10) and a 7x7 kernel
@@ -120,9 +126,8 @@ def test_stride2_dgrad_by_parity_classes_matches_oracle(ctx, case):
             nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
             cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
             P = max(nky, nkx) - 1
-            lib.deepim_conv_subkernel_flip(h, wt, wd, cout, cin, k, k, ky0, kx0, nky, nkx)
             order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
-            lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, nky, nkx, order)
+            lib.deepim_conv_pack_dgrad(h, pk, wd, cout, cin, k, k, ky0, kx0, 2, nky, nkx, order)     # sub-kernel view inside the pack
             lib.deepim_conv2d_forward_remap(h, dx2, dz, pk, B, cout, ho, wo, cin, nky, nkx, P, cy0 + P - (nky - 1),
                                             cx0 + P - (nkx - 1), H, W, py, px)
     np.testing.assert_array_equal(dx2.asnumpy(), got)

@@ -47,8 +47,7 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
 
         def dgrad():
             if s == 1:
-                lib.deepim_conv_flip_weights(h, wt, w, cout, cin, k, k)
-                lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, k, k, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p))
+                lib.deepim_conv_pack_dgrad(h, pk, w, cout, cin, k, k, 0, 0, 1, k, k, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p))
                 lib.deepim_conv2d_forward(h, dx, dz, pk, None, B, cout, ho, wo, cin, k, k, 1, k - 1 - p, cf(1.0), 0, 0)
                 return
             for py in range(2):
@@ -57,8 +56,7 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
                     nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
                     cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
                     P = max(nky, nkx) - 1
-                    lib.deepim_conv_subkernel_flip(h, wt, w, cout, cin, k, k, ky0, kx0, nky, nkx)
-                    lib.deepim_conv_pack_weights_ex(h, pk, wt, cin, cout, nky, nkx, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P))
+                    lib.deepim_conv_pack_dgrad(h, pk, w, cout, cin, k, k, ky0, kx0, 2, nky, nkx, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P))
                     lib.deepim_conv2d_forward_remap(h, dx, dz, pk, B, cout, ho, wo, cin, nky, nkx, P, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
         ms = timeit(dgrad)
         tot["dg"] += ms
