@@ -60,7 +60,9 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * "conv_autotune": 0 (default) = the split-K factor of an under-filled conv grid comes from a deterministic cost
  * model (same geometry → same summation order in every run, process and rank); 1 = on the first call of a conv
  * geometry, time a few split-K factors and keep the fastest (plans then depend on timing noise). "conv_tile256": 1 = 256x128 tiles on 512-thread blocks when
- * Cout % 256 == 0 (default 0: measured no faster than 128x128). Unknown names fail. */
+ * Cout % 256 == 0 (default 0: measured no faster than 128x128). "wgrad_lds": 1 (default) = LDS-staged weight-gradient kernel
+ * (and the few-filter stream kernel for Cout <= 4), 0 = the round-2 register-fed kernel; "dgrad_group": 1 (default) = the four
+ * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);
@@ -454,6 +456,10 @@ int deepim_group_picker_backward(deepim_ctx* ctx, float* in_grad /*B,C*/, const 
 int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy, const float* y, float slope, size_t n);
 /* db[c] = sum over n, pixels of dz (B,C,hw) */
 int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, size_t hw);
+/* the two in one walk, with the gradient arriving over a skip connection folded in: dz = lrelu'(y)*(dy [+ add]) (B,C,hw; dz may
+ * be dy; add may be NULL), db[c] = sum of dz — what the training graph needs per encoder layer */
+int deepim_lrelu_bias_backward(deepim_ctx* ctx, float* dz, float* db, const float* dy, const float* add, const float* y,
+                               float slope, int B, int C, size_t hw);
 /* wt (Cin,Cout,kh,kw) = w (Cout,Cin,kh,kw) transposed and flipped: the weights with which the data gradient of a
  * convolution is itself a stride-1 convolution (pad kh-1-p) — run on deepim_conv2d_forward after deepim_conv_pack_weights */
 int deepim_conv_flip_weights(deepim_ctx* ctx, float* wt, const float* w, int Cout, int Cin, int kh, int kw);
@@ -470,6 +476,14 @@ int deepim_interleave2d(deepim_ctx* ctx, float* dx /*BC,H,W*/, const float* src 
  * put the window of the result on out (B,Cout,Hd,Wd)[.., 2i + py, 2j + px] — no class buffer */
 int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, int B, int Cin, int H, int W,
                                 int Cout, int kh, int kw, int pad, int cy, int cx, int Hd, int Wd, int py, int px);
+/* The whole data gradient of a stride-2 convolution (kernel k x k, pad): dx (B,Ci_l,Hd,Wd) from dz (B,Co_l,Ho,Wo), Ho = (Hd + 2 pad
+ * - k)/2 + 1, and the layer's RAW weights w_layer (Co_l,Ci_l,k,k). The four parity classes above are packed, convolved and
+ * reduced TOGETHER — one launch each, the blocks of the convolution launch shared out over the classes — when the register-fed
+ * 128x128 kernel takes the geometry (even Co_l, Ci_l > 64); class by class otherwise or with option "dgrad_group" = 0.
+ * packed_ws: device workspace of deepim_conv_dgrad_s2_packed_size bytes. */
+size_t deepim_conv_dgrad_s2_packed_size(int Co_l, int Ci_l, int k, int pad);
+int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B, int Ci_l,
+                           int Hd, int Wd, int Co_l, int k, int pad);
 /* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
 int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
 /* the same with an offset: out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x], zeros elsewhere — also the backward of
@@ -493,6 +507,12 @@ int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* db, const f
 /* MXNet sgd_mom_update (train.py:296-303): mom = momentum*mom - lr*(rescale*g [clipped to +-clip if clip > 0] + wd*w); w += mom */
 int deepim_sgd_mom_update(deepim_ctx* ctx, float* w, float* mom, const float* g, float lr, float wd, float momentum,
                           float rescale, float clip, size_t n);
+
+/* the same update of every parameter in one launch. table (device): `rows` rows of five 64-bit words {w, mom, g (device
+ * addresses), n, (bits of float wd) | (first block of the row << 32)}; a row owns ceil(n/256) blocks, rows in block order,
+ * total_blocks = their sum. Results are bit-identical to per-tensor deepim_sgd_mom_update calls. */
+int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long long* table, int rows, int total_blocks, float lr,
+                                float momentum, float rescale, float clip);
 
 /* ------------------------------------- R-group: re-render between iterations -- */
 /* Replaces Render_Py.render (lib/render_glumpy/render_py_multi.py:101-129: OpenGL draw + glReadPixels +

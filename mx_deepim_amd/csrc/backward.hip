@@ -49,6 +49,50 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(double* __restrict__ par
   if (tid == 0) partial[(long)c * S + sl] = red[0];
 }
 
+// The same walk with the LeakyReLU gradient folded in: dz = lrelu'(y)·(dy [+ add]) is written AND summed by block (c, slice) — one
+// read of dy / y instead of three passes (skip-gradient add, activation gradient, bias-gradient first pass). V4: float4 steps.
+template <bool V4>
+__global__ __launch_bounds__(256) void lrelu_bias_backward_kernel(double* __restrict__ partial, float* dz, const float* dy,
+                                                                  const float* add, const float* __restrict__ y, float slope,
+                                                                  int B, int C, long HW, int S, long per_slice) {
+  const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+  const long lo = (long)sl * per_slice, hi = min(HW, lo + per_slice);
+  double acc = 0.0;
+  for (int n = 0; n < B; ++n) {
+    const long base = ((long)n * C + c) * HW;
+    if (V4) {
+      for (long i = lo + 4 * tid; i < hi; i += 1024) {
+        float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+        const float4 yy = *reinterpret_cast<const float4*>(y + base + i);
+        if (add) {
+          const float4 a = *reinterpret_cast<const float4*>(add + base + i);
+          g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+        }
+        g.x = yy.x > 0.f ? g.x : g.x * slope; g.y = yy.y > 0.f ? g.y : g.y * slope;
+        g.z = yy.z > 0.f ? g.z : g.z * slope; g.w = yy.w > 0.f ? g.w : g.w * slope;
+        *reinterpret_cast<float4*>(dz + base + i) = g;
+        acc += (double)g.x; acc += (double)g.y; acc += (double)g.z; acc += (double)g.w;
+      }
+    } else {
+      for (long i = lo + tid; i < hi; i += 256) {
+        float g = dy[base + i];
+        if (add) g += add[base + i];
+        g = y[base + i] > 0.f ? g : g * slope;
+        dz[base + i] = g;
+        acc += (double)g;
+      }
+    }
+  }
+  __shared__ double red[256];
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) partial[(long)c * S + sl] = red[0];
+}
+
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(float* __restrict__ db, const double* __restrict__ partial, int C,
                                                               int S) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -406,6 +450,59 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
     }
 }
 
+// Weight gradient of a layer with very few filters (the 3x3 prediction heads, Cout 1-2; the 2 → 2 k4 flow upsamplers): per input
+// channel one dot product over the pixels for every (filter, tap) — a stream over x, not an MFMA problem (on the 64-row MFMA
+// tile 97 % of the rows were padding: 59 µs + a reduce pass for Convolution3). Block = one input channel; thread t takes pixels
+// t, t + 256, … of every sample in order, then a fixed shuffle + LDS tree: deterministic.
+template <int CO, int KS>
+__global__ __launch_bounds__(256) void wgrad_fewout_kernel(float* __restrict__ dw, const float* __restrict__ x,
+                                                           const float* __restrict__ dz, int B, int Cin, int H, int W, int Cout,
+                                                           int Ho, int Wo, int stride, int pad) {
+  constexpr int T = KS * KS;
+  const int ci = blockIdx.x, tid = threadIdx.x;
+  float acc[CO][T];
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[co][t] = 0.f;
+  const int HW = Ho * Wo;
+  for (int n = 0; n < B; ++n) {
+    const float* xp = x + ((long)n * Cin + ci) * H * W;
+    const float* zp = dz + (long)n * Cout * HW;
+    for (int r = tid; r < HW; r += 256) {
+      const int ho = r / Wo, wo = r - ho * Wo;
+      float g[CO];
+#pragma unroll
+      for (int co = 0; co < CO; ++co) g[co] = co < Cout ? zp[(long)co * HW + r] : 0.f;
+      const int hi0 = ho * stride - pad, wi0 = wo * stride - pad;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int hi = hi0 + ky, wi = wi0 + kx;
+          const float v = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? xp[hi * W + wi] : 0.f;
+#pragma unroll
+          for (int co = 0; co < CO; ++co) acc[co][ky * KS + kx] = fmaf(g[co], v, acc[co][ky * KS + kx]);
+        }
+    }
+  }
+  __shared__ float sh[4][CO * T];
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float v = acc[co][t];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) sh[wave][co * T + t] = v;
+    }
+  __syncthreads();
+  if (tid < CO * T) {
+    const int co = tid / T, t = tid - co * T;
+    if (co < Cout) dw[((long)co * Cin + ci) * T + t] = ((sh[0][tid] + sh[1][tid]) + sh[2][tid]) + sh[3][tid];
+  }
+}
+
 // dw[i] = Σ_s partial[s][i], slices in order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ partial, long n,
                                                            int S) {
@@ -414,6 +511,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   float v = partial[i];
   for (int s = 1; s < S; ++s) v += partial[(long)s * n + i];
   dw[i] = v;
+}
+
+// Many slices of a small dw (conv1: 25 k weights x 256 slices): one thread per element walks S dependent, 100 KB-strided loads
+// (60 µs). Here a block = 64 float4 columns x 4 slice quarters; each quarter keeps four independent partial sums (slices s, s+1,
+// s+2, s+3 of its range), the quarters are added in order through LDS. Fixed order, so still deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(float* __restrict__ dw, const float* __restrict__ partial, long n4,
+                                                            int S) {
+  const int tid = threadIdx.x, col = tid & 63, q = tid >> 6;
+  const long i = (long)blockIdx.x * 64 + col;
+  const int Sq = (S + 3) >> 2, s0 = q * Sq, s1 = min(S, s0 + Sq);
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + i;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = p[(long)(s + u) * n4];
+        a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+      }
+    }
+    for (; s < s1; ++s) {
+      const float4 v = p[(long)s * n4];
+      a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+  }
+  float4 r = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                         (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
+  __shared__ float4 sh[4][64];
+  sh[q][col] = r;
+  __syncthreads();
+  if (q == 0 && i < n4) {
+#pragma unroll
+    for (int u = 1; u < 4; ++u) { const float4 v = sh[u][col]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    reinterpret_cast<float4*>(dw)[i] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------- FC ----
@@ -511,7 +646,67 @@ __global__ __launch_bounds__(256) void sgd_mom_kernel(float* __restrict__ w, flo
   w[i] = w[i] + m;
 }
 
+// every parameter in one launch: row r of the table = {w, mom, g, n, wd bits | first block << 32}; a block finds its row by
+// walking the (scalar, cached) table
+__global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long long* __restrict__ table, int rows, float lr,
+                                                            float momentum, float rescale, float clip) {
+  const unsigned b = blockIdx.x;
+  int r = 0;
+  while (r + 1 < rows && (unsigned)(table[(r + 1) * 5 + 4] >> 32) <= b) ++r;
+  const unsigned long long* e = table + r * 5;
+  float* w = reinterpret_cast<float*>(e[0]);
+  float* mom = reinterpret_cast<float*>(e[1]);
+  const float* g = reinterpret_cast<const float*>(e[2]);
+  const size_t n = e[3];
+  const float wd = __uint_as_float((unsigned)e[4]);
+  const size_t i = (size_t)(b - (unsigned)(e[4] >> 32)) * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gg = g[i] * rescale;
+  if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+  const float m = momentum * mom[i] - lr * (gg + wd * w[i]);
+  mom[i] = m;
+  w[i] = w[i] + m;
+}
+
+void launch_wgrad_reduce(deepim_ctx* ctx, float* dw, const float* partial, long n, int S) {
+  if (S >= 8 && n % 4 == 0)
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(di_div_up(n / 4, 64)), dim3(256), 0, ctx->stream, dw, partial, n / 4, S);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n, 256)), dim3(256), 0, ctx->stream, dw, partial, n, S);
+}
+
 }  // namespace
+
+extern "C" int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long long* table, int rows, int total_blocks,
+                                           float lr, float momentum, float rescale, float clip) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(rows >= 0 && table != nullptr, "sgd_mom_update_multi: no table");
+  if (rows == 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(sgd_mom_multi_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, table, rows, lr, momentum, rescale, clip);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_lrelu_bias_backward(deepim_ctx* ctx, float* dz, float* db, const float* dy, const float* add, const float* y,
+                                          float slope, int B, int C, size_t hw) {
+  DI_DEVICE(ctx);
+  if (C == 0 || B == 0 || hw == 0) return 0;
+  int S = (int)max(1L, min((long)di_div_up(1024, C), (long)di_div_up((long)hw, 4096)));
+  const long per_slice = (long)di_div_up(di_div_up((long)hw, S), 1024) * 1024;
+  S = di_div_up((long)hw, per_slice);
+  void* scratch;
+  int rc = deepim_scratch(ctx, (size_t)C * S * sizeof(double), &scratch);
+  if (rc) return rc;
+  if (hw % 4 == 0)
+    hipLaunchKernelGGL(lrelu_bias_backward_kernel<true>, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, dy, add, y,
+                       slope, B, C, (long)hw, S, per_slice);
+  else
+    hipLaunchKernelGGL(lrelu_bias_backward_kernel<false>, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, dy, add, y,
+                       slope, B, C, (long)hw, S, per_slice);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy, const float* y, float slope, size_t n) {
   DI_DEVICE(ctx);
@@ -601,6 +796,14 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   const int bm = (ctx->wgrad_lds && Cout <= 64) ? 64 : 128;
   p.mtiles = di_div_up(Cout, bm);
   const long n_dw = (long)Cout * p.K;
+  if (ctx->wgrad_lds && Cout <= 4 && kh == kw && (kh == 3 || kh == 4)) {   // prediction heads, flow upsamplers
+#define DI_WG_FEW(CO, KS) hipLaunchKernelGGL((wgrad_fewout_kernel<CO, KS>), dim3(Cin), dim3(256), 0, ctx->stream, dw, x, dz, B, Cin, H, W, Cout, p.Ho, p.Wo, stride, pad)
+    if (kh == 3) { if (Cout == 1) DI_WG_FEW(1, 3); else if (Cout == 2) DI_WG_FEW(2, 3); else DI_WG_FEW(4, 3); }
+    else { if (Cout == 1) DI_WG_FEW(1, 4); else if (Cout == 2) DI_WG_FEW(2, 4); else DI_WG_FEW(4, 4); }
+#undef DI_WG_FEW
+    DI_LAUNCH_CHECK();
+    return 0;
+  }
   if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
     // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)
     const long chunks = (long)B * di_div_up(HW, WG_PIX);
@@ -630,8 +833,7 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
     }
     if (bm == 64) hipLaunchKernelGGL(wgrad_lds_kernel<64>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL(wgrad_lds_kernel<128>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
-    if (p.S > 1)
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n_dw, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n_dw, p.S);
+    if (p.S > 1) launch_wgrad_reduce(ctx, dw, p.partial, n_dw, p.S);
     DI_LAUNCH_CHECK();
     return 0;
   }
@@ -647,7 +849,7 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   if (rc) return rc;
   p.partial = (float*)scratch;
   hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(di_div_up(n, 256)), dim3(256), 0, ctx->stream, dw, p.partial, n, p.S);
+  launch_wgrad_reduce(ctx, dw, p.partial, n, p.S);
   DI_LAUNCH_CHECK();
   return 0;
 }

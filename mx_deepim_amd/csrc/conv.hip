@@ -480,7 +480,7 @@ static_assert(DK % DR == 0 && DPD < DK, "ring must divide the chunk");
 // (Tried: single-wave workgroups, one 64x64 quadrant each, for 4x finer tail granularity — 60 TF, half the rate.)
 // WMW = wave rows: 2 → waves 2x2 over a 128x128 tile; 1 → waves 1x4 over a 64x256 tile (Cout <= 64: conv1)
 template <int WMW>
-__global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_direct_body(const ConvParams& p, const int block_id) {
   constexpr int BM = 64 * WMW, BN = 64 * (4 / WMW), TM = 2, TN = 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
   if (p.tail_s > 0) {
     // every XCD (block b → XCD b % 8) first walks its eighth of the full tiles, then its eighth of the tail items,
     // so the short items are dispatched last on all XCDs and fill the round the full tiles leave under-used
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int bid = block_id, xcd = bid & 7, idx = bid >> 3;
     const int fq = p.n_full >> 3, tq8 = p.n_tail_pad >> 3;
     if (idx < fq) {
       vid = xcd * fq + idx;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
       split = tail_item % p.tail_s;
     }
   } else {
-    const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
+    const int total = p.gx * p.gy * p.gz, bid = block_id;
     const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
     vid = p.swizzle ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
     split = vid / (p.gx * p.gy);
@@ -695,6 +695,33 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams
 
 
 // ---------------------------------------------------------------------------------------------------------------
+
+template <int WMW>
+__global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
+  conv_direct_body<WMW>(p, blockIdx.x);
+}
+
+// Several independent convolutions in ONE launch (the four output parity classes of a stride-2 data gradient: same input, own
+// sub-kernel, own K, own remap): block b belongs to the last convolution whose first block is <= b. Small layers fill the chip
+// together instead of one under-filled launch (+ split-K pass) per class.
+constexpr int CONV_GROUP_MAX = 4;
+struct ConvGroup {
+  ConvParams p[CONV_GROUP_MAX];
+  int start[CONV_GROUP_MAX + 1];   // first block of each member (multiples of 8: the XCD round-robin stays aligned); start[n] = grid
+  int n;
+};
+__global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_group_kernel(ConvGroup g) {
+  const int b = blockIdx.x;
+  int c = 0;
+#pragma unroll
+  for (int i = 1; i < CONV_GROUP_MAX; ++i)
+    if (i < g.n && b >= g.start[i]) c = i;
+  c = __builtin_amdgcn_readfirstlane(c);
+  const int local = b - g.start[c];
+  if (local >= g.p[c].gx * g.p[c].gy * g.p[c].gz) return;   // the padding up to the next multiple of 8
+  conv_direct_body<2>(g.p[c], local);
+}
+
 // The same LDS-free design on channel-blocked ("NC8") activations [n][C/8][h][w][8] — the layout the encoder layers
 // hand to each other (conv1 writes it, conv6_1 returns to NCHW for fc6). K runs (c8, ky, kx, s, h) with channel
 // c8*8 + s + 4h: the four k-steps s of one (c8, tap) group pair channels (s, s+4), so lanes 0-31 read channels 0-3 and
@@ -985,6 +1012,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
   out[(n * ctotal + coff + c) * plane + poff] = v;
 }
 
+// the second passes of a ConvGroup launch in one: member m sums its own slices onto its own remap window of `out`
+struct ReduceGroup {
+  float* out;
+  const float* partial[CONV_GROUP_MAX];
+  long total[CONV_GROUP_MAX], stride[CONV_GROUP_MAX];
+  int S[CONV_GROUP_MAX], hw[CONV_GROUP_MAX];
+  Remap rm[CONV_GROUP_MAX];
+  int start[CONV_GROUP_MAX + 1];
+  int n, Cout;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup g) {
+  const int b = blockIdx.x;
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < CONV_GROUP_MAX; ++i)
+    if (i < g.n && b >= g.start[i]) m = i;
+  m = __builtin_amdgcn_readfirstlane(m);
+  const long i = (long)(b - g.start[m]) * 256 + threadIdx.x;
+  if (i >= g.total[m]) return;
+  const int hw = g.hw[m];
+  const int r = (int)(i % hw);
+  long poff, plane;
+  if (!remap_pixel(g.rm[m], r, hw, poff, plane)) return;
+  const float* partial = g.partial[m];
+  const long stride = g.stride[m];
+  float v = partial[i];
+  for (int s = 1; s < g.S[m]; ++s) v += partial[(long)s * stride + i];
+  const int c = (int)((i / hw) % g.Cout);
+  const long n = i / ((long)hw * g.Cout);
+  g.out[(n * g.Cout + c) * plane + poff] = v;
+}
+
 // tail-split second pass: one block per remainder tile; out = lrelu(Σ_slice partial + bias), slices in fixed order
 __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                           const float* __restrict__ bias, int n_full, int R, int S,
@@ -1099,6 +1158,31 @@ __global__ void pack_direct_kernel(float* __restrict__ packed, const float* __re
   const int mt = (int)(i / (64L * npair));
   const int co = mt * 32 + r, ci = 2 * (g / khw) + h, t = g % khw;
   packed[i] = (co < Cout && ci < Cin) ? wview_at(v, w, co, ci, t, Cin, khw) : 0.f;
+}
+// the register-fed order of the four parity-class sub-kernels of a stride-2 data gradient in one launch
+struct PackGroup {
+  float* dst[CONV_GROUP_MAX];
+  long total[CONV_GROUP_MAX];
+  int khw[CONV_GROUP_MAX], npair[CONV_GROUP_MAX];
+  WView v[CONV_GROUP_MAX];
+  int start[CONV_GROUP_MAX + 1];
+  int n, Cout, Cin;
+};
+__global__ __launch_bounds__(256) void pack_direct_group_kernel(const float* __restrict__ w, PackGroup g) {
+  const int b = blockIdx.x;
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < CONV_GROUP_MAX; ++i)
+    if (i < g.n && b >= g.start[i]) m = i;
+  m = __builtin_amdgcn_readfirstlane(m);
+  const long i = (long)(b - g.start[m]) * 256 + threadIdx.x;
+  if (i >= g.total[m]) return;
+  const int khw = g.khw[m], npair = g.npair[m];
+  const int q = (int)(i & 3), r = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1);
+  const int gq = (int)((i >> 8) % (npair / 4)) * 4 + q;
+  const int mt = (int)(i / (64L * npair));
+  const int co = mt * 32 + r, ci = 2 * (gq / khw) + h, t = gq % khw;
+  g.dst[m][i] = (co < g.Cout && ci < g.Cin) ? wview_at(g.v[m], w, co, ci, t, g.Cin, khw) : 0.f;
 }
 __global__ void build_direct_tab_kernel(int2* __restrict__ tab, int npair_real, int n, int kh, int kw, int H, int W) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1491,6 +1575,177 @@ extern "C" int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const fl
   DI_REQUIRE(py >= 0 && py < 2 && px >= 0 && px < 2 && cy >= 0 && cx >= 0 && rm.hq + cy <= Ho && rm.wq + cx <= rm.Wo,
              "conv2d_forward_remap: class window outside the convolution result");
   return conv2d_forward_impl(ctx, out, in, packed_w, nullptr, B, Cin, H, W, Cout, kh, kw, 1, pad, 1.f, 0, 0, 0, 0, 1.f, &rm);
+}
+
+// ---- the whole data gradient of a stride-2 convolution ----------------------------------------------------------------------
+// dx (B,Ci_l,Hd,Wd) from dz (B,Co_l,Ho,Wo) and the layer's raw weights (Co_l,Ci_l,k,k): the four output parity classes
+// (deepim_conv_pack_dgrad / deepim_conv2d_forward_remap above), planned and launched TOGETHER when the register-fed 128x128
+// kernel takes them — one pack launch, one convolution launch whose blocks are shared out over the four classes (split-K per
+// class so that every block runs about the same number of K chunks), one second pass. On conv4 … conv6 of the training graph a
+// class alone fills a fraction of the chip (12-48 tiles); four launches + four second passes were launch-bound (19-49 TF).
+namespace {
+struct S2Class { int py, px, ky0, kx0, nky, nkx, cy, cx, P; };
+inline S2Class s2_class(int z, int k, int pad) {
+  S2Class c;
+  c.py = z >> 1; c.px = z & 1;
+  c.ky0 = (c.py + pad) % 2; c.kx0 = (c.px + pad) % 2;
+  c.nky = (k - c.ky0 + 1) / 2; c.nkx = (k - c.kx0 + 1) / 2;
+  c.P = max(c.nky, c.nkx) - 1;
+  c.cy = (c.py + pad - c.ky0) / 2 + c.P - (c.nky - 1);
+  c.cx = (c.px + pad - c.kx0) / 2 + c.P - (c.nkx - 1);
+  return c;
+}
+}  // namespace
+
+extern "C" size_t deepim_conv_dgrad_s2_packed_size(int Co_l, int Ci_l, int k, int pad) {
+  size_t total = 0;
+  for (int z = 0; z < 4; ++z) {
+    const S2Class c = s2_class(z, k, pad);
+    total += 3 * packed_half(Ci_l, Co_l * c.nky * c.nkx);
+  }
+  return total * sizeof(float);
+}
+
+extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
+                                      int Ci_l, int Hd, int Wd, int Co_l, int k, int pad) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(k >= 2 && k <= 7 && pad >= 0 && pad < k, "conv2d_dgrad_s2: kernel 2 … 7, pad < k");
+  const int Ho = (Hd + 2 * pad - k) / 2 + 1, Wo = (Wd + 2 * pad - k) / 2 + 1;
+  S2Class cls[4];
+  size_t slot[4], off = 0;
+  for (int z = 0; z < 4; ++z) {
+    cls[z] = s2_class(z, k, pad);
+    slot[z] = off;
+    off += 3 * packed_half(Ci_l, Co_l * cls[z].nky * cls[z].nkx);
+  }
+  const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
+  const size_t in_bytes = (size_t)B * Co_l * Ho * Wo * 4;
+  const bool grouped = ctx->dgrad_group && direct && (Co_l & 1) == 0 && Ci_l > 64 &&
+                       !(ctx->conv_tile256 && Ci_l % 256 == 0) && in_bytes + (size_t)(4 * Wo + 4) * 4 < 0x7fffffffUL;
+  if (!grouped) {   // class by class: whatever kernel family deepim_conv2d_forward picks for the geometry
+    for (int z = 0; z < 4; ++z) {
+      const S2Class& c = cls[z];
+      const int order = deepim_conv_weight_order(ctx, B, Co_l, Ho, Wo, Ci_l, c.nky, c.nkx, 1, c.P);
+      int rc = deepim_conv_pack_dgrad(ctx, packed_ws + slot[z], w_layer, Co_l, Ci_l, k, k, c.ky0, c.kx0, 2, c.nky, c.nkx, order);
+      if (rc) return rc;
+      rc = deepim_conv2d_forward_remap(ctx, dx, dz, packed_ws + slot[z], B, Co_l, Ho, Wo, Ci_l, c.nky, c.nkx, c.P, c.cy, c.cx, Hd,
+                                       Wd, c.py, c.px);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  // members in descending K (the long blocks are dispatched first)
+  int ord[4] = {0, 1, 2, 3};
+  for (int a = 0; a < 4; ++a)
+    for (int b = a + 1; b < 4; ++b)
+      if (cls[ord[b]].nky * cls[ord[b]].nkx > cls[ord[a]].nky * cls[ord[a]].nkx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+  ConvGroup g;
+  PackGroup pg;
+  g.n = pg.n = 4;
+  pg.Cout = Ci_l; pg.Cin = Co_l;
+  long tiles[4];
+  int pstart = 0;
+  for (int m = 0; m < 4; ++m) {
+    const S2Class& c = cls[ord[m]];
+    ConvParams& p = g.p[m];
+    const size_t half = packed_half(Ci_l, Co_l * c.nky * c.nkx);
+    p.in = dz; p.wp = packed_ws + slot[ord[m]]; p.bias = nullptr; p.out = dx;
+    p.B = B; p.Cin = Co_l; p.H = Ho; p.W = Wo; p.Cout = Ci_l;
+    p.Ho = Ho + 2 * c.P - c.nky + 1; p.Wo = Wo + 2 * c.P - c.nkx + 1;
+    p.stride = 1; p.pad = c.P;
+    p.nchunk = chunk_count(Co_l * c.nky * c.nkx);
+    p.ngran = gran_count(Ci_l);
+    p.out_ctotal = Ci_l; p.out_coff = 0; p.slope = 1.f; p.crop_y = p.crop_x = 0;
+    p.rm_on = 1; p.rm_cy = c.cy; p.rm_cx = c.cx; p.rm_hq = (Hd - c.py + 1) / 2; p.rm_wq = (Wd - c.px + 1) / 2;
+    p.rm_py = c.py; p.rm_px = c.px; p.rm_H = Hd; p.rm_W = Wd;
+    DI_REQUIRE(p.rm_hq + c.cy <= p.Ho && p.rm_wq + c.cx <= p.Wo, "conv2d_dgrad_s2: class window outside the convolution result");
+    p.npix = (long)B * p.Ho * p.Wo;
+    p.pad_bytes = (c.P * Wo + c.P) * 4;
+    p.in_bytes = (unsigned)in_bytes;
+    int2 *tab, *tab2;
+    int rc = get_tab(ctx, MODE_CONV, Co_l, c.nky, c.nkx, Ho, Wo, &tab);
+    if (rc) return rc;
+    rc = get_tab(ctx, MODE_DIRECT_TAB, Co_l, c.nky, c.nkx, Ho, Wo, &tab2);
+    if (rc) return rc;
+    p.tab = tab; p.tab2 = tab2;
+    p.wd = packed_ws + slot[ord[m]] + half; p.wd_bytes = (unsigned)(half * sizeof(float));
+    p.in_nc8 = 0; p.out_nc8 = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
+    p.swizzle = ctx->conv_xcd_swizzle;
+    p.gx = di_div_up(p.npix, 128); p.gy = di_div_up(Ci_l, 128);
+    p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
+    tiles[m] = (long)p.gx * p.gy;
+    // pack member
+    pg.dst[m] = packed_ws + slot[ord[m]] + half;
+    pg.total[m] = (long)half;
+    pg.khw[m] = c.nky * c.nkx;
+    pg.npair[m] = p.nchunk * (KT / 2);
+    pg.v[m] = WView{1, Ci_l, k, k, c.ky0, c.kx0, 2, c.nky, c.nkx};
+    pg.start[m] = pstart;
+    pstart += (int)di_div_up((long)half, 256);
+  }
+  pg.start[4] = pstart;
+  // joint plan: T = K chunks per block; member m runs ceil(nchunk_m / T) slices. cost as plan_ksplit: rounds of 256 blocks x the
+  // longest block, + the second pass
+  const int nch_max = g.p[0].nchunk;
+  const int cands[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 32};
+  float best = 1e30f;
+  int best_T = nch_max;
+  for (int sN : cands) {
+    const int T = di_div_up(nch_max, sN);
+    if (sN > 1 && T < 4) continue;
+    long blocks = 0, split_blocks = 0;
+    for (int m = 0; m < 4; ++m) {
+      const int ks = di_div_up(g.p[m].nchunk, T);
+      blocks += tiles[m] * ks;
+      if (ks > 1) split_blocks += tiles[m] * ks;
+    }
+    if (blocks > 8192) continue;
+    const float cost = (float)di_div_up(blocks, 256) * (float)T + (split_blocks ? 3.f + 0.016f * (float)split_blocks : 0.f);
+    if (cost < best * 0.985f) { best = cost; best_T = T; }
+  }
+  size_t partial_floats = 0;
+  for (int m = 0; m < 4; ++m) {
+    ConvParams& p = g.p[m];
+    p.ksplit = di_div_up(p.nchunk, best_T);
+    p.chunks_per_split = di_div_up(p.nchunk, p.ksplit);
+    p.ksplit = di_div_up(p.nchunk, p.chunks_per_split);
+    p.gz = p.ksplit;
+    p.partial_stride = (long)B * Ci_l * p.Ho * p.Wo;
+    if (p.ksplit > 1) partial_floats += (size_t)p.ksplit * p.partial_stride;
+  }
+  float* scratch = nullptr;
+  if (partial_floats) {
+    void* sp;
+    int rc = deepim_scratch(ctx, partial_floats * sizeof(float), &sp);
+    if (rc) return rc;
+    scratch = (float*)sp;
+  }
+  ReduceGroup rg;
+  rg.out = dx; rg.Cout = Ci_l; rg.n = 0;
+  int cstart = 0, rstart = 0;
+  size_t poff = 0;
+  for (int m = 0; m < 4; ++m) {
+    ConvParams& p = g.p[m];
+    p.partial = nullptr;
+    if (p.ksplit > 1) {
+      p.partial = scratch + poff;
+      poff += (size_t)p.ksplit * p.partial_stride;
+      const int j = rg.n++;
+      rg.partial[j] = p.partial; rg.total[j] = p.partial_stride; rg.stride[j] = p.partial_stride; rg.S[j] = p.ksplit;
+      rg.hw[j] = p.Ho * p.Wo; rg.rm[j] = remap_of(p); rg.start[j] = rstart;
+      rstart += (int)di_div_up(p.partial_stride, 256);
+    }
+    g.start[m] = cstart;
+    cstart += di_div_up(p.gx * p.gy * p.gz, 8) * 8;
+  }
+  g.start[4] = cstart;
+  for (int j = rg.n; j <= CONV_GROUP_MAX; ++j) rg.start[j] = rstart;
+  hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
+  hipLaunchKernelGGL(conv_direct_group_kernel, dim3(cstart), dim3(256), 0, ctx->stream, g);
+  if (rg.n) hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rstart), dim3(256), 0, ctx->stream, rg);
+  DI_LAUNCH_CHECK();
+  return 0;
 }
 
 // NCHW fp32 in → split16 out (conv1 of the split-fp16 encoder): the fp32 MFMA convolution with the split folded into its

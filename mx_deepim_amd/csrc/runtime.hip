@@ -35,6 +35,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->conv_xcd_swizzle = 1;
   c->f16_dev_flags = 0;
   c->wgrad_lds = 1;
+  c->dgrad_group = 1;
   c->conv_autotune = 0;
   c->conv_direct = 1;
   c->conv_tail_slots = 1024;
@@ -173,6 +174,7 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "conv_tail_slots") == 0) { DI_REQUIRE(value >= 8 && value % 8 == 0, "conv_tail_slots must be a positive multiple of 8"); ctx->conv_tail_slots = value; return 0; }
   if (strcmp(name, "conv_tile256") == 0) { ctx->conv_tile256 = value ? 1 : 0; return 0; }
   if (strcmp(name, "conv_autotune") == 0) { ctx->conv_autotune = value ? 1 : 0; return 0; }
+  if (strcmp(name, "dgrad_group") == 0) { ctx->dgrad_group = value ? 1 : 0; return 0; }
   if (strcmp(name, "wgrad_lds") == 0) { ctx->wgrad_lds = value ? 1 : 0; return 0; }
   if (strcmp(name, "f16_dev_flags") == 0) { DI_REQUIRE(value >= 0 && value < 16, "f16_dev_flags: bits 0..3"); ctx->f16_dev_flags = value; return 0; }
   if (strcmp(name, "conv_xcd_swizzle") == 0) {

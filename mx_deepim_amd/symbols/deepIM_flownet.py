@@ -584,6 +584,8 @@ def _train_methods():
                 dil = max(dil, B * cout * (h - k + 1 + 2 * p_) * (w - k + 1 + 2 * p_))
             wmax = max(wmax, cout * cin * k * k)
             pmax = max(pmax, psize(cin, cout, k, k) // 4)
+            if s_ == 2:
+                pmax = max(pmax, lib.load().deepim_conv_dgrad_s2_packed_size(cout, cin, k, p_) // 4)
         if self.with_decoder:
             # the un-cropped gradients of the two big transposed convolutions, and the role-swapped weights of the decoder layers
             dil = max(dil, B * 256 * 32 * 42, B * 512 * 18 * 22)
@@ -681,26 +683,19 @@ def _train_methods():
                                       ctypes.c_float(1.0), 0, 0)
             return
         assert s_ == 2
-        for py in range(2):
-            for px in range(2):
-                ky0, kx0 = (py + p_) % 2, (px + p_) % 2
-                nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
-                cy0, cx0 = (py + p_ - ky0) // 2, (px + p_ - kx0) // 2
-                P = max(nky, nkx) - 1
-                order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P)
-                lib.deepim_conv_pack_dgrad(h, self.ws["wt_packed"], w_raw, cout, cin, k, k, ky0, kx0, 2, nky, nkx, order)
-                # the conv kernels' final stores (and their split-K second pass) put the class window straight onto dx
-                lib.deepim_conv2d_forward_remap(h, dx, dz, self.ws["wt_packed"], B, cout, ho, wo, cin, nky, nkx, P,
-                                                cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
+        # the four parity classes packed, convolved and reduced by one launch each (class by class where the register-fed kernel
+        # does not take the geometry: conv2's 64-channel dx)
+        lib.deepim_conv2d_dgrad_s2(h, dx, dz, w_raw, self.ws["wt_packed"], B, cin, hh, ww, cout, k, p_)
 
-    def _conv_backward(self, li, dz, dx):
+    def _conv_backward(self, li, dz, dx, bias_done=False):
         """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into
         self.grad, data gradient into dx (None for the first layer)."""
         name, cin, hh, ww, cout, k, s_, p_ = self.enc_geom[li]
         h, B, A = self.ctx.handle, self.B, self.act
         ho, wo = _out_hw(hh, ww, k, s_, p_)
         src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
-        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
+        if not bias_done:
+            lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
         lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, k, k, s_, p_)
         if dx is not None:
             self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, k, s_, p_, ho, wo)
@@ -807,10 +802,12 @@ def _train_methods():
         for li in range(len(self.enc_geom) - 1, -1, -1):
             name = self.enc_geom[li][0]
             n_el = A[name].size
-            if name in skips:
-                lib.deepim_axpy(h, ga, W_[skips[name]], c(1.0), n_el)
-            lib.deepim_lrelu_backward(h, ga, ga, A[name], c(SLOPE), n_el)
-            self._conv_backward(li, ga, gb if li > 0 else None)
+            # skip-gradient add, LeakyReLU gradient and the bias gradient in one walk over the layer's output
+            _, cin_, hh_, ww_, cout_, k_, s_, p_ = self.enc_geom[li]
+            ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
+            lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_[skips[name]] if name in skips else None, A[name],
+                                           c(SLOPE), B, cout_, ho_ * wo_)
+            self._conv_backward(li, ga, gb if li > 0 else None, bias_done=True)
             ga, gb = gb, ga
         return G
 
@@ -821,12 +818,21 @@ def _train_methods():
         (attr lr_mult 0, deepIM_flownet.py:193,333,643,695)."""
         h = self.ctx.handle
         c = ctypes.c_float
-        for name, w in self.params.items():
-            if name.endswith("upsampling_weight"):
-                continue
-            wd_n = wd if name.endswith("_weight") else 0.0
-            lib.deepim_sgd_mom_update(h, w, self.mom[name], self.grad[name], c(lr), c(wd_n), c(momentum), c(rescale_grad),
-                                      c(clip_gradient or 0.0), w.size)
+        tab = getattr(self, "_sgd_table", None)
+        if tab is None or tab[0] != float(wd):
+            # one launch for all parameters: rows {w, mom, g, n, wd bits | first block << 32} (deepim_sgd_mom_update_multi)
+            rows, block = [], 0
+            for name, w in self.params.items():
+                if name.endswith("upsampling_weight"):
+                    continue
+                wd_n = wd if name.endswith("_weight") else 0.0
+                wd_bits = int(np.array([wd_n], np.float32).view(np.uint32)[0])
+                rows.append([w.ptr, self.mom[name].ptr, self.grad[name].ptr, w.size, wd_bits | (block << 32)])
+                block += (w.size + 255) // 256
+            dev = self.ctx.empty((len(rows), 5), np.uint64)
+            dev.copyfrom(np.array(rows, dtype=np.uint64))
+            tab = self._sgd_table = (float(wd), dev, len(rows), block)
+        lib.deepim_sgd_mom_update_multi(h, tab[1], tab[2], tab[3], c(lr), c(momentum), c(rescale_grad), c(clip_gradient or 0.0))
         for name, shape in self.arg_shape_dict().items():
             if not name.endswith("_weight") or len(shape) != 4 or name.endswith("upsampling_weight"):
                 continue

@@ -79,7 +79,7 @@ def test_conv_backward_kernels_match_oracle(ctx, case):
 
 # (B, Cin, H, W, Cout, k, p): stride-2 layers incl. odd frame sizes (conv6: 15x20 -> 8x10) and a 7x7 kernel
 S2_CASES = [(2, 64, 24, 32, 128, 5, 2), (2, 40, 16, 24, 70, 3, 1), (1, 512, 15, 20, 1024, 3, 1), (2, 6, 13, 17, 10, 3, 1),
-            (1, 8, 20, 28, 16, 7, 3), (2, 128, 30, 40, 256, 3, 1)]
+            (1, 8, 20, 28, 16, 7, 3), (2, 128, 30, 40, 256, 3, 1), (4, 512, 15, 20, 1024, 3, 1), (3, 130, 9, 11, 258, 5, 2)]
 
 
 @pytest.mark.parametrize("case", S2_CASES)
@@ -133,9 +133,30 @@ def test_stride2_dgrad_by_parity_classes_matches_oracle(ctx, case):
     np.testing.assert_array_equal(dx2.asnumpy(), got)
     # rows / columns no output pixel reaches (odd frame, pad) get exact zeros, like the oracle
     assert np.abs(got[dx_ref == 0]).max(initial=0.0) == 0.0
+    # the one-call form: class by class it is the loop above; grouped (default) the four classes share one pack / convolution /
+    # second-pass launch with a joint split-K plan — other slice boundaries, so equal to the oracle, not bit-equal to the loop
+    ws = DeviceArray(ctx, (lib.load().deepim_conv_dgrad_s2_packed_size(cout, cin, k, p) // 4,))
+    try:
+        lib.deepim_set_option(h, b"dgrad_group", 0)
+        dx3 = ctx.array(np.full(x.shape, 7.0, np.float32))
+        lib.deepim_conv2d_dgrad_s2(h, dx3, dz, wd, ws, B, cin, H, W, cout, k, p)
+        np.testing.assert_array_equal(dx3.asnumpy(), got)
+    finally:
+        lib.deepim_set_option(h, b"dgrad_group", 1)
+    res = []
+    for _ in range(2):
+        dx4 = ctx.array(np.full(x.shape, 7.0, np.float32))
+        lib.deepim_conv2d_dgrad_s2(h, dx4, dz, wd, ws, B, cin, H, W, cout, k, p)
+        res.append(dx4.asnumpy())
+    close(res[0], dx_ref)
+    np.testing.assert_array_equal(res[0], res[1])          # deterministic
+    assert np.abs(res[0][dx_ref == 0]).max(initial=0.0) == 0.0
 
 
-@pytest.mark.parametrize("case", WG_CASES + [(4, 64, 60, 80, 128, 5, 2, 2), (2, 512, 15, 20, 1024, 3, 2, 1)])
+@pytest.mark.parametrize("case", WG_CASES + [(4, 64, 60, 80, 128, 5, 2, 2), (2, 512, 15, 20, 1024, 3, 2, 1),
+                                  # few filters: the stream kernel (heads: 3x3 s1; flow upsamplers' role-swapped k4 s2)
+                                  (4, 770, 30, 40, 2, 3, 1, 1), (2, 6, 30, 40, 1, 3, 1, 1), (2, 2, 32, 42, 2, 4, 2, 0),
+                                  (3, 9, 10, 12, 4, 3, 1, 1), (2, 1026, 15, 20, 2, 3, 1, 1)])
 def test_wgrad_lds_kernel_vs_register_fed_kernel(ctx, case):
     """The LDS-staged weight-gradient kernel (default) and the round-2 register-fed one: both within 1e-4 of the float64
     oracle, and within fp32 re-association distance of each other; both deterministic."""
@@ -182,6 +203,59 @@ def test_fc_backward_and_sgd(ctx, shape):
         w_ref, m_ref = onet.sgd_mom_update(w, mom, dw.asnumpy(), 1e-4, 5e-4, 0.975, 0.5, clip)
         np.testing.assert_allclose(wd_.asnumpy(), w_ref, rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(md_.asnumpy(), m_ref, rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 240, 320), (2, 1024, 8, 10), (3, 5, 7, 9), (1, 130, 30, 40)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_lrelu_bias_backward_equals_the_separate_passes(ctx, shape, with_add):
+    """The fused walk (skip add + LeakyReLU gradient + bias-gradient first pass): dz bit-identical to axpy → lrelu_backward,
+    db within float64-accumulation distance of deepim_bias_grad on that dz (and of the numpy sum); in place over dy."""
+    B, C, H, W = shape
+    rng = np.random.default_rng(sum(shape))
+    dy = rng.standard_normal(shape).astype(np.float32)
+    y = rng.standard_normal(shape).astype(np.float32)
+    add = rng.standard_normal(shape).astype(np.float32) if with_add else None
+    h = ctx.handle
+    ref = ctx.array(dy)
+    if with_add:
+        lib.deepim_axpy(h, ref, ctx.array(add), cf(1.0), ref.size)
+    lib.deepim_lrelu_backward(h, ref, ref, ctx.array(y), cf(0.1), ref.size)
+    db_ref = ctx.empty((C,))
+    lib.deepim_bias_grad(h, db_ref, ref, B, C, H * W)
+    g, db = ctx.array(dy), ctx.empty((C,))
+    lib.deepim_lrelu_bias_backward(h, g, db, g, ctx.array(add) if with_add else None, ctx.array(y), cf(0.1), B, C, H * W)
+    np.testing.assert_array_equal(g.asnumpy(), ref.asnumpy())
+    host = ref.asnumpy().astype(np.float64).sum(axis=(0, 2, 3))
+    np.testing.assert_allclose(db.asnumpy(), host, rtol=2e-6, atol=1e-6 * np.sqrt(B * H * W))
+    np.testing.assert_allclose(db.asnumpy(), db_ref.asnumpy(), rtol=2e-6, atol=1e-6 * np.sqrt(B * H * W))
+
+
+def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
+    """deepim_sgd_mom_update_multi: one launch over a table of parameters (ragged sizes, weight decay per row) — the same bits as
+    one deepim_sgd_mom_update per tensor."""
+    rng = np.random.default_rng(5)
+    sizes = [1, 255, 256, 257, 64 * 8 * 49, 7, 1024 * 3 + 5]
+    h = ctx.handle
+    W = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    M = [(rng.standard_normal(n) * 1e-3).astype(np.float32) for n in sizes]
+    G_ = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    wds = [5e-4 if i % 2 == 0 else 0.0 for i in range(len(sizes))]
+    for clip in (0.0, 0.3):
+        ref_w, ref_m = [ctx.array(a) for a in W], [ctx.array(a) for a in M]
+        g = [ctx.array(a) for a in G_]
+        for i, n in enumerate(sizes):
+            lib.deepim_sgd_mom_update(h, ref_w[i], ref_m[i], g[i], cf(1e-3), cf(wds[i]), cf(0.975), cf(0.5), cf(clip), n)
+        w, m = [ctx.array(a) for a in W], [ctx.array(a) for a in M]
+        rows, block = [], 0
+        for i, n in enumerate(sizes):
+            rows.append([w[i].ptr, m[i].ptr, g[i].ptr, n, int(np.array([wds[i]], np.float32).view(np.uint32)[0]) | (block << 32)])
+            block += (n + 255) // 256
+        tab = ctx.empty((len(rows), 5), np.uint64)
+        tab.copyfrom(np.array(rows, dtype=np.uint64))
+        lib.deepim_sgd_mom_update_multi(h, tab, len(rows), block, cf(1e-3), cf(0.975), cf(0.5), cf(clip))
+        for i in range(len(sizes)):
+            np.testing.assert_array_equal(w[i].asnumpy(), ref_w[i].asnumpy())
+            np.testing.assert_array_equal(m[i].asnumpy(), ref_m[i].asnumpy())
 
 
 def _train_setup(ctx, B, seed, pred_heads):

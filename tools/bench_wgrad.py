@@ -50,17 +50,15 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
                 lib.deepim_conv_pack_dgrad(h, pk, w, cout, cin, k, k, 0, 0, 1, k, k, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p))
                 lib.deepim_conv2d_forward(h, dx, dz, pk, None, B, cout, ho, wo, cin, k, k, 1, k - 1 - p, cf(1.0), 0, 0)
                 return
-            for py in range(2):
-                for px in range(2):
-                    ky0, kx0 = (py + p) % 2, (px + p) % 2
-                    nky, nkx = (k - ky0 + 1) // 2, (k - kx0 + 1) // 2
-                    cy0, cx0 = (py + p - ky0) // 2, (px + p - kx0) // 2
-                    P = max(nky, nkx) - 1
-                    lib.deepim_conv_pack_dgrad(h, pk, w, cout, cin, k, k, ky0, kx0, 2, nky, nkx, lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, nky, nkx, 1, P))
-                    lib.deepim_conv2d_forward_remap(h, dx, dz, pk, B, cout, ho, wo, cin, nky, nkx, P, cy0 + P - (nky - 1), cx0 + P - (nkx - 1), hh, ww, py, px)
+            lib.deepim_conv2d_dgrad_s2(h, dx, dz, w, ws2, B, cin, hh, ww, cout, k, p)
+        ws2 = DeviceArray(ctx, (max(4, lib.load().deepim_conv_dgrad_s2_packed_size(cout, cin, k, p) // 4),))
         ms = timeit(dgrad)
         tot["dg"] += ms
         line += " | dgrad %.3f ms %5.1f TF" % (ms, fl / ms / 1e9)
+        if s == 2:   # class by class (the launches before the grouped plan)
+            lib.deepim_set_option(h, b"dgrad_group", 0)
+            line += " (class by class %.3f)" % timeit(dgrad)
+            lib.deepim_set_option(h, b"dgrad_group", 1)
     print(line)
     hh, ww, cin = ho, wo, cout
 print("totals B=%d: wgrad LDS %.2f ms, reg-fed %.2f ms, dgrad %.2f ms" % (B, tot["wg1"], tot["wg0"], tot["dg"]))
