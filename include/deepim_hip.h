@@ -479,7 +479,8 @@ int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const float* in, co
 /* The whole data gradient of a stride-2 convolution (kernel k x k, pad): dx (B,Ci_l,Hd,Wd) from dz (B,Co_l,Ho,Wo), Ho = (Hd + 2 pad
  * - k)/2 + 1, and the layer's RAW weights w_layer (Co_l,Ci_l,k,k). The four parity classes above are packed, convolved and
  * reduced TOGETHER — one launch each, the blocks of the convolution launch shared out over the classes — when the register-fed
- * 128x128 kernel takes the geometry (even Co_l, Ci_l > 64); class by class otherwise or with option "dgrad_group" = 0.
+ * kernel takes the geometry (even Co_l; 64 x 256 tiles for Ci_l <= 64, else 128 x 128); class by class otherwise or with option
+ * "dgrad_group" = 0.
  * packed_ws: device workspace of deepim_conv_dgrad_s2_packed_size bytes. */
 size_t deepim_conv_dgrad_s2_packed_size(int Co_l, int Ci_l, int k, int pad);
 int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B, int Ci_l,

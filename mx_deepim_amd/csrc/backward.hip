@@ -646,13 +646,21 @@ __global__ __launch_bounds__(256) void sgd_mom_kernel(float* __restrict__ w, flo
   w[i] = w[i] + m;
 }
 
-// every parameter in one launch: row r of the table = {w, mom, g, n, wd bits | first block << 32}; a block finds its row by
-// walking the (scalar, cached) table
+// every parameter in one launch: row r of the table = {w, mom, g, n, wd bits | first block << 32}; a block finds its row with a
+// ballot over the rows' first blocks
 __global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long long* __restrict__ table, int rows, float lr,
                                                             float momentum, float rescale, float clip) {
   const unsigned b = blockIdx.x;
-  int r = 0;
-  while (r + 1 < rows && (unsigned)(table[(r + 1) * 5 + 4] >> 32) <= b) ++r;
+  // row = number of rows that start at or before this block, minus one: every wave counts them 64 at a time with one load + ballot
+  // (a serial walk of the table cost the late rows ~40 dependent loads)
+  const int lane = threadIdx.x & 63;
+  int r = -1;
+  for (int base = 0; base < rows; base += 64) {
+    const int idx = base + lane;
+    const bool le = idx < rows && (unsigned)(table[idx * 5 + 4] >> 32) <= b;
+    r += __popcll(__ballot(le));
+  }
+  r = __builtin_amdgcn_readfirstlane(r);
   const unsigned long long* e = table + r * 5;
   float* w = reinterpret_cast<float*>(e[0]);
   float* mom = reinterpret_cast<float*>(e[1]);

@@ -710,6 +710,7 @@ struct ConvGroup {
   int start[CONV_GROUP_MAX + 1];   // first block of each member (multiples of 8: the XCD round-robin stays aligned); start[n] = grid
   int n;
 };
+template <int WMW>
 __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_group_kernel(ConvGroup g) {
   const int b = blockIdx.x;
   int c = 0;
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_group_kernel(Conv
   c = __builtin_amdgcn_readfirstlane(c);
   const int local = b - g.start[c];
   if (local >= g.p[c].gx * g.p[c].gy * g.p[c].gz) return;   // the padding up to the next multiple of 8
-  conv_direct_body<2>(g.p[c], local);
+  conv_direct_body<WMW>(g.p[c], local);
 }
 
 // The same LDS-free design on channel-blocked ("NC8") activations [n][C/8][h][w][8] — the layout the encoder layers
@@ -1621,8 +1622,10 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
   }
   const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
   const size_t in_bytes = (size_t)B * Co_l * Ho * Wo * 4;
-  const bool grouped = ctx->dgrad_group && direct && (Co_l & 1) == 0 && Ci_l > 64 &&
-                       !(ctx->conv_tile256 && Ci_l % 256 == 0) && in_bytes + (size_t)(4 * Wo + 4) * 4 < 0x7fffffffUL;
+  const bool grouped = ctx->dgrad_group && direct && (Co_l & 1) == 0 && !(ctx->conv_tile256 && Ci_l % 256 == 0) &&
+                       in_bytes + (size_t)(4 * Wo + 4) * 4 < 0x7fffffffUL;
+  // tile of the register-fed kernel: 128 x 128, or 64 rows x 256 pixels when dx has at most 64 channels (conv2's data gradient)
+  const int bm = Ci_l <= 64 ? 64 : 128, bn = Ci_l <= 64 ? 256 : 128;
   if (!grouped) {   // class by class: whatever kernel family deepim_conv2d_forward picks for the geometry
     for (int z = 0; z < 4; ++z) {
       const S2Class& c = cls[z];
@@ -1672,7 +1675,7 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
     p.wd = packed_ws + slot[ord[m]] + half; p.wd_bytes = (unsigned)(half * sizeof(float));
     p.in_nc8 = 0; p.out_nc8 = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
     p.swizzle = ctx->conv_xcd_swizzle;
-    p.gx = di_div_up(p.npix, 128); p.gy = di_div_up(Ci_l, 128);
+    p.gx = di_div_up(p.npix, bn); p.gy = di_div_up(Ci_l, bm);
     p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
     tiles[m] = (long)p.gx * p.gy;
     // pack member
@@ -1742,7 +1745,8 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
   g.start[4] = cstart;
   for (int j = rg.n; j <= CONV_GROUP_MAX; ++j) rg.start[j] = rstart;
   hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
-  hipLaunchKernelGGL(conv_direct_group_kernel, dim3(cstart), dim3(256), 0, ctx->stream, g);
+  if (bm == 64) hipLaunchKernelGGL(conv_direct_group_kernel<1>, dim3(cstart), dim3(256), 0, ctx->stream, g);
+  else hipLaunchKernelGGL(conv_direct_group_kernel<2>, dim3(cstart), dim3(256), 0, ctx->stream, g);
   if (rg.n) hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rstart), dim3(256), 0, ctx->stream, rg);
   DI_LAUNCH_CHECK();
   return 0;

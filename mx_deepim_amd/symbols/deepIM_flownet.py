@@ -683,8 +683,7 @@ def _train_methods():
                                       ctypes.c_float(1.0), 0, 0)
             return
         assert s_ == 2
-        # the four parity classes packed, convolved and reduced by one launch each (class by class where the register-fed kernel
-        # does not take the geometry: conv2's 64-channel dx)
+        # the four parity classes packed, convolved and reduced by one launch each
         lib.deepim_conv2d_dgrad_s2(h, dx, dz, w_raw, self.ws["wt_packed"], B, cin, hh, ww, cout, k, p_)
 
     def _conv_backward(self, li, dz, dx, bias_done=False):
@@ -833,6 +832,7 @@ def _train_methods():
             dev.copyfrom(np.array(rows, dtype=np.uint64))
             tab = self._sgd_table = (float(wd), dev, len(rows), block)
         lib.deepim_sgd_mom_update_multi(h, tab[1], tab[2], tab[3], c(lr), c(momentum), c(rescale_grad), c(clip_gradient or 0.0))
+        orders = self._train_pack_orders()
         for name, shape in self.arg_shape_dict().items():
             if not name.endswith("_weight") or len(shape) != 4 or name.endswith("upsampling_weight"):
                 continue
@@ -840,12 +840,24 @@ def _train_methods():
             if base.startswith("deconv") or base.startswith("upsample_flow"):
                 lib.deepim_deconv_pack_weights(h, self.packed[base], self.params[name], shape[0], shape[1])
             else:
-                lib.deepim_conv_pack_weights_ex(h, self.packed[base], self.params[name], shape[0], shape[1], shape[2], shape[3], 3)
+                lib.deepim_conv_pack_weights_ex(h, self.packed[base], self.params[name], shape[0], shape[1], shape[2], shape[3],
+                                                orders.get(base, 3))
         lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
+
+    def _train_pack_orders(self):
+        """layer → the ONE packed operand order its forward convolution reads in the training graph (NCHW activations,
+        deepim_conv_weight_order): the per-step re-pack writes only that one."""
+        order = lib.load().deepim_conv_weight_order      # evaluated per update: follows the context's conv options
+        h, B = self.ctx.handle, self.B
+        geo = {g[0]: g[1:] for g in self.enc_geom}
+        geo.update({"Convolution1": (1024, 8, 10, 2, 3, 1, 1), "Convolution2": (1026, 15, 20, 2, 3, 1, 1),
+                    "Convolution3": (770, 30, 40, 2, 3, 1, 1), "mask_conv3": (770, 30, 40, 1, 3, 1, 1)})
+        return {n: order(h, B, cin, hh, ww, cout, k, k, s_, p_) for n, (cin, hh, ww, cout, k, s_, p_) in geo.items()}
 
     return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad, _conv_backward=_conv_backward,
                 _small_conv_backward=_small_conv_backward, _head_conv_backward=_head_conv_backward,
-                _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update)
+                _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update,
+                _train_pack_orders=_train_pack_orders)
 
 
 for _name, _fn in _train_methods().items():
