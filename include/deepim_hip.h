@@ -485,6 +485,16 @@ int deepim_conv2d_forward_remap(deepim_ctx* ctx, float* out, const float* in, co
 size_t deepim_conv_dgrad_s2_packed_size(int Co_l, int Ci_l, int k, int pad);
 int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B, int Ci_l,
                            int Hd, int Wd, int Co_l, int k, int pad);
+/* Data gradient of a Convolution layer (weights (Co_l,Ci_l,k,k), stride 1 or 2, pad) from its RAW weights, optionally already
+ * multiplied by the activation gradient of the layer below: dx (B,Ci_l,Hd,Wd) = lrelu'(act_y) * (dgrad(dz) [+ add]) — act_y =
+ * that layer's saved output, add = the gradient reaching it over a skip connection, both laid out like dx; NULL act_y = plain
+ * data gradient (add must then be NULL). Stride 1 = deepim_conv_pack_dgrad + the forward kernel, stride 2 =
+ * deepim_conv2d_dgrad_s2; the activation gradient rides in the final stores of the register-fed kernels and their split-K
+ * second passes (no pass of its own over dx), other kernel families get it as one extra pass. What module.backward does per
+ * encoder layer (deepim/core/module.py:1131-1137). packed_ws: deepim_conv_dgrad_packed_size bytes. */
+size_t deepim_conv_dgrad_packed_size(int Co_l, int Ci_l, int k, int stride, int pad);
+int deepim_conv2d_dgrad(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B, int Ci_l,
+                        int Hd, int Wd, int Co_l, int k, int stride, int pad, const float* act_y, const float* add, float slope);
 /* out (BC,Hd,Wd) = in (BC,Ho,Wo) with stride-1 zeros between the samples (data gradient of a strided convolution) */
 int deepim_dilate2d(deepim_ctx* ctx, float* out, const float* in, int BC, int Ho, int Wo, int Hd, int Wd, int stride);
 /* the same with an offset: out[bc][off_y + stride*y][off_x + stride*x] = in[bc][y][x], zeros elsewhere — also the backward of
@@ -502,6 +512,10 @@ int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float* src, int s
  * with the pixels as the reduction dimension; Ho*Wo must be a multiple of 4 */
 int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W, int Cout,
                         int kh, int kw, int stride, int pad);
+/* weight AND bias gradient of a layer (db[c] = sum of dz): one launch for the few-filter layers (Cout <= 4, 3x3 / 4x4: the
+ * prediction heads), deepim_bias_grad + deepim_conv2d_wgrad otherwise */
+int deepim_conv2d_wgrad_bias(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
+                             int Cout, int kh, int kw, int stride, int pad);
 /* FullyConnected backward: dx (B,I) = dy·w, dw (O,I) = dyT·x, db (O) = sum_b dy; any of dx/dw/db may be NULL */
 int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* db, const float* dy, const float* x, const float* w,
                        int B, int I, int O);

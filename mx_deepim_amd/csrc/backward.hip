@@ -457,9 +457,13 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
 template <int CO, int KS>
 __global__ __launch_bounds__(256) void wgrad_fewout_kernel(float* __restrict__ dw, const float* __restrict__ x,
                                                            const float* __restrict__ dz, int B, int Cin, int H, int W, int Cout,
-                                                           int Ho, int Wo, int stride, int pad) {
+                                                           int Ho, int Wo, int stride, int pad, float* __restrict__ db) {
   constexpr int T = KS * KS;
   const int ci = blockIdx.x, tid = threadIdx.x;
+  const bool with_bias = db != nullptr && ci == 0;   // block 0 also sums dz per filter (the bias gradient): it reads dz anyway
+  float accb[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) accb[co] = 0.f;
   float acc[CO][T];
 #pragma unroll
   for (int co = 0; co < CO; ++co)
@@ -474,6 +478,8 @@ __global__ __launch_bounds__(256) void wgrad_fewout_kernel(float* __restrict__ d
       float g[CO];
 #pragma unroll
       for (int co = 0; co < CO; ++co) g[co] = co < Cout ? zp[(long)co * HW + r] : 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) accb[co] += g[co];
       const int hi0 = ho * stride - pad, wi0 = wo * stride - pad;
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky)
@@ -487,7 +493,16 @@ __global__ __launch_bounds__(256) void wgrad_fewout_kernel(float* __restrict__ d
     }
   }
   __shared__ float sh[4][CO * T];
+  __shared__ float shb[4][CO];
   const int lane = tid & 63, wave = tid >> 6;
+  if (with_bias) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float v = accb[co];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) shb[wave][co] = v;
+    }
+  }
 #pragma unroll
   for (int co = 0; co < CO; ++co)
 #pragma unroll
@@ -501,6 +516,7 @@ __global__ __launch_bounds__(256) void wgrad_fewout_kernel(float* __restrict__ d
     const int co = tid / T, t = tid - co * T;
     if (co < Cout) dw[((long)co * Cin + ci) * T + t] = ((sh[0][tid] + sh[1][tid]) + sh[2][tid]) + sh[3][tid];
   }
+  if (with_bias && tid < Cout) db[tid] = ((shb[0][tid] + shb[1][tid]) + shb[2][tid]) + shb[3][tid];
 }
 
 // dw[i] = Σ_s partial[s][i], slices in order
@@ -788,8 +804,24 @@ extern "C" int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float*
   return 0;
 }
 
+static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
+                             int Cout, int kh, int kw, int stride, int pad);
+
 extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W,
                                    int Cout, int kh, int kw, int stride, int pad) {
+  return conv2d_wgrad_impl(ctx, dw, nullptr, x, dz, B, Cin, H, W, Cout, kh, kw, stride, pad);
+}
+
+// weight and bias gradient of one layer: one launch for the few-filter layers (the stream kernel's first block sums dz on the way),
+// deepim_bias_grad + the MFMA kernel otherwise
+extern "C" int deepim_conv2d_wgrad_bias(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin,
+                                        int H, int W, int Cout, int kh, int kw, int stride, int pad) {
+  DI_REQUIRE(db != nullptr, "conv2d_wgrad_bias: db is NULL (use deepim_conv2d_wgrad)");
+  return conv2d_wgrad_impl(ctx, dw, db, x, dz, B, Cin, H, W, Cout, kh, kw, stride, pad);
+}
+
+static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
+                             int Cout, int kh, int kw, int stride, int pad) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   WgradParams p;
@@ -805,12 +837,16 @@ extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, c
   p.mtiles = di_div_up(Cout, bm);
   const long n_dw = (long)Cout * p.K;
   if (ctx->wgrad_lds && Cout <= 4 && kh == kw && (kh == 3 || kh == 4)) {   // prediction heads, flow upsamplers
-#define DI_WG_FEW(CO, KS) hipLaunchKernelGGL((wgrad_fewout_kernel<CO, KS>), dim3(Cin), dim3(256), 0, ctx->stream, dw, x, dz, B, Cin, H, W, Cout, p.Ho, p.Wo, stride, pad)
+#define DI_WG_FEW(CO, KS) hipLaunchKernelGGL((wgrad_fewout_kernel<CO, KS>), dim3(Cin), dim3(256), 0, ctx->stream, dw, x, dz, B, Cin, H, W, Cout, p.Ho, p.Wo, stride, pad, db)
     if (kh == 3) { if (Cout == 1) DI_WG_FEW(1, 3); else if (Cout == 2) DI_WG_FEW(2, 3); else DI_WG_FEW(4, 3); }
     else { if (Cout == 1) DI_WG_FEW(1, 4); else if (Cout == 2) DI_WG_FEW(2, 4); else DI_WG_FEW(4, 4); }
 #undef DI_WG_FEW
     DI_LAUNCH_CHECK();
     return 0;
+  }
+  if (db) {
+    const int rc = deepim_bias_grad(ctx, db, dz, B, Cout, (size_t)HW);
+    if (rc) return rc;
   }
   if (ctx->wgrad_lds && (size_t)B * Cin * H * W * 4 < 0x7fffffffUL && (size_t)B * Cout * HW * 4 < 0x7fffffffUL) {
     // LDS-staged kernel: chunks of 16 pixels of one sample; slices of whole chunks, fixed by the geometry (deterministic)

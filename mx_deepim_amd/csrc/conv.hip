@@ -97,11 +97,18 @@ struct ConvParams {
   // the (Ho, Wo) result goes to out[.., 2i + rm_py, 2j + rm_px] of a (rm_H, rm_W) plane; pixels outside the window are dropped.
   // This is how a parity class of a stride-2 data gradient lands in dx without a class buffer (deepim_conv2d_forward_remap).
   int rm_on, rm_cy, rm_cx, rm_hq, rm_wq, rm_py, rm_px, rm_H, rm_W;
+  // Activation-gradient epilogue of a DATA GRADIENT (register-fed kernels and the split-K second passes only): the final NCHW store
+  // becomes out = lrelu'(ep_y)·(v [+ ep_add]) with ep_y / ep_add laid out like out — the previous layer's saved output and the
+  // gradient arriving over a skip connection. NULL ep_y = off.
+  const float* ep_y;
+  const float* ep_add;
+  float ep_slope;
   const float* wd8;         // weights for NC8 inputs [Cout/32][group = (c8,ky,kx)][lane][4]
   const int2* tab8;         // per group: {byte offset (c8*H*W + ky*W + kx)*32, bit ky*8+kx}
 };
 
 struct Remap { int on, cy, cx, hq, wq, py, px, H, W, Wo; };
+struct ActGrad { const float* y; const float* add; float slope; };   // ConvParams::ep_* of a launch
 __host__ __device__ inline Remap remap_of(const ConvParams& p) {
   return {p.rm_on, p.rm_cy, p.rm_cx, p.rm_hq, p.rm_wq, p.rm_py, p.rm_px, p.rm_H, p.rm_W, p.Wo};
 }
@@ -685,6 +692,10 @@ __device__ __forceinline__ void conv_direct_body(const ConvParams& p, const int 
           if (!partial) {
             v = v + (p.bias ? p.bias[co] : 0.f);
             v = v > 0.f ? v : v * p.slope;
+            if (p.ep_y) {
+              if (p.ep_add) v += p.ep_add[obase + (long)co * plane];
+              v = p.ep_y[obase + (long)co * plane] > 0.f ? v : v * p.ep_slope;
+            }
           }
           outp[obase + (long)co * plane] = v;
         }
@@ -998,7 +1009,8 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                             const float* __restrict__ bias, long total, long stride,
                                                             int S, int Cout, int hw, int ctotal, int coff,
-                                                            float slope, Remap rm) {
+                                                            float slope, Remap rm, const float* __restrict__ ep_y,
+                                                            const float* __restrict__ ep_add, float ep_slope) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int r = (int)(i % hw);
@@ -1010,7 +1022,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ 
   const long n = i / ((long)hw * Cout);
   v = v + (bias ? bias[c] : 0.f);
   v = v > 0.f ? v : v * slope;
-  out[(n * ctotal + coff + c) * plane + poff] = v;
+  const long o = (n * ctotal + coff + c) * plane + poff;
+  if (ep_y) {
+    if (ep_add) v += ep_add[o];
+    v = ep_y[o] > 0.f ? v : v * ep_slope;
+  }
+  out[o] = v;
 }
 
 // the second passes of a ConvGroup launch in one: member m sums its own slices onto its own remap window of `out`
@@ -1022,6 +1039,9 @@ struct ReduceGroup {
   Remap rm[CONV_GROUP_MAX];
   int start[CONV_GROUP_MAX + 1];
   int n, Cout;
+  const float* ep_y;      // activation-gradient epilogue (ConvParams::ep_*)
+  const float* ep_add;
+  float ep_slope;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup g) {
   const int b = blockIdx.x;
@@ -1042,7 +1062,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup g)
   for (int s = 1; s < g.S[m]; ++s) v += partial[(long)s * stride + i];
   const int c = (int)((i / hw) % g.Cout);
   const long n = i / ((long)hw * g.Cout);
-  g.out[(n * g.Cout + c) * plane + poff] = v;
+  const long o = (n * g.Cout + c) * plane + poff;
+  if (g.ep_y) {
+    if (g.ep_add) v += g.ep_add[o];
+    v = g.ep_y[o] > 0.f ? v : v * g.ep_slope;
+  }
+  g.out[o] = v;
 }
 
 // tail-split second pass: one block per remainder tile; out = lrelu(Σ_slice partial + bias), slices in fixed order
@@ -1290,6 +1315,11 @@ TileChoice choose_tile(const deepim_ctx* ctx, int Cout, long npix, int nchunk, i
 template <int MODE>
 int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
   if (p.out_nc8 == 2) t.ksplit = 1, t.tail_s = 0;   // the split16 epilogue has no split-K second pass
+  if (p.ep_y) {   // only the register-fed kernels' epilogue and the plain split-K second pass apply it
+    t.tail_s = 0;
+    DI_REQUIRE(MODE == MODE_CONV && p.tab2 != nullptr && !p.in_nc8 && !p.out_nc8 && ((t.bm == 128 && t.bn == 128) || (t.bm == 64 && t.bn == 256)),
+               "conv: activation-gradient epilogue asked of a kernel family that has none");
+  }
   p.ksplit = t.ksplit;
   p.chunks_per_split = di_div_up(p.nchunk, t.ksplit);
   if (p.in_nc8) p.chunks_per_split = (p.chunks_per_split + 1) & ~1;   // the NC8 kernel consumes whole pairs of chunks
@@ -1353,7 +1383,7 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
                          p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
-                         p.slope, remap_of(p));
+                         p.slope, remap_of(p), p.ep_y, p.ep_add, p.ep_slope);
   }
   DI_LAUNCH_CHECK();
   return 0;
@@ -1552,7 +1582,7 @@ extern "C" int deepim_conv2d_forward(deepim_ctx* ctx, float* out, const float* i
 static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
                                int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
                                int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale,
-                               const Remap* rm = nullptr);
+                               const Remap* rm = nullptr, const ActGrad* ag = nullptr);
 
 extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const float* packed_w,
                                         const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
@@ -1607,8 +1637,63 @@ extern "C" size_t deepim_conv_dgrad_s2_packed_size(int Co_l, int Ci_l, int k, in
   return total * sizeof(float);
 }
 
+namespace {
+// the epilogue as a pass of its own, for the kernel families that do not carry it
+__global__ __launch_bounds__(256) void actgrad_kernel(float* __restrict__ dx, const float* __restrict__ y, const float* __restrict__ add,
+                                                      float slope, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = dx[i];
+  if (add) v += add[i];
+  dx[i] = y[i] > 0.f ? v : v * slope;
+}
+int actgrad_pass(deepim_ctx* ctx, float* dx, const ActGrad& ag, size_t n) {
+  hipLaunchKernelGGL(actgrad_kernel, dim3(di_div_up((long)n, 256)), dim3(256), 0, ctx->stream, dx, ag.y, ag.add, ag.slope, n);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
+                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag);
+
 extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
                                       int Ci_l, int Hd, int Wd, int Co_l, int k, int pad) {
+  return conv2d_dgrad_s2_impl(ctx, dx, dz, w_layer, packed_ws, B, Ci_l, Hd, Wd, Co_l, k, pad, nullptr);
+}
+
+extern "C" size_t deepim_conv_dgrad_packed_size(int Co_l, int Ci_l, int k, int stride, int pad) {
+  return stride == 2 ? deepim_conv_dgrad_s2_packed_size(Co_l, Ci_l, k, pad) : deepim_conv_packed_size(Ci_l, Co_l, k, k);
+}
+
+// Data gradient of a Convolution layer (Co_l,Ci_l,k,k; stride 1 or 2) from its raw weights, optionally already multiplied by the
+// activation gradient of the layer below: dx = lrelu'(act_y)·(dgrad [+ add]) — act_y = that layer's saved output, add = the
+// gradient reaching it over a skip connection (both laid out like dx; NULL act_y = plain dgrad). The epilogue rides in the final
+// stores of the register-fed kernels / their split-K second passes; other kernel families get it as one extra pass.
+extern "C" int deepim_conv2d_dgrad(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
+                                   int Ci_l, int Hd, int Wd, int Co_l, int k, int stride, int pad, const float* act_y,
+                                   const float* add, float slope) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(stride == 1 || stride == 2, "conv2d_dgrad: stride 1 or 2");
+  DI_REQUIRE(act_y != nullptr || add == nullptr, "conv2d_dgrad: add without act_y");
+  const ActGrad ag = {act_y, add, slope};
+  if (stride == 2) return conv2d_dgrad_s2_impl(ctx, dx, dz, w_layer, packed_ws, B, Ci_l, Hd, Wd, Co_l, k, pad, act_y ? &ag : nullptr);
+  const int Ho = Hd + 2 * pad - k + 1, Wo = Wd + 2 * pad - k + 1, P = k - 1 - pad;
+  DI_REQUIRE(P >= 0, "conv2d_dgrad: pad > k - 1");
+  const int order = deepim_conv_weight_order(ctx, B, Co_l, Ho, Wo, Ci_l, k, k, 1, P);
+  int rc = deepim_conv_pack_dgrad(ctx, packed_ws, w_layer, Co_l, Ci_l, k, k, 0, 0, 1, k, k, order);
+  if (rc) return rc;
+  const bool fused = act_y && order == 2 && (size_t)B * Co_l * Ho * Wo * 4 + (size_t)(P * Wo + P) * 4 < 0x7fffffffUL;
+  rc = conv2d_forward_impl(ctx, dx, dz, packed_ws, nullptr, B, Co_l, Ho, Wo, Ci_l, k, k, 1, P, 1.f, 0, 0, 0, 0, 1.f, nullptr,
+                           fused ? &ag : nullptr);
+  if (rc) return rc;
+  if (act_y && !fused) return actgrad_pass(ctx, dx, ag, (size_t)B * Ci_l * Hd * Wd);
+  return 0;
+}
+
+static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
+                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(k >= 2 && k <= 7 && pad >= 0 && pad < k, "conv2d_dgrad_s2: kernel 2 … 7, pad < k");
@@ -1636,7 +1721,7 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
                                        Wd, c.py, c.px);
       if (rc) return rc;
     }
-    return 0;
+    return ag ? actgrad_pass(ctx, dx, *ag, (size_t)B * Ci_l * Hd * Wd) : 0;
   }
   // members in descending K (the long blocks are dispatched first)
   int ord[4] = {0, 1, 2, 3};
@@ -1674,6 +1759,7 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
     p.tab = tab; p.tab2 = tab2;
     p.wd = packed_ws + slot[ord[m]] + half; p.wd_bytes = (unsigned)(half * sizeof(float));
     p.in_nc8 = 0; p.out_nc8 = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
+    p.ep_y = ag ? ag->y : nullptr; p.ep_add = ag ? ag->add : nullptr; p.ep_slope = ag ? ag->slope : 1.f;
     p.swizzle = ctx->conv_xcd_swizzle;
     p.gx = di_div_up(p.npix, bn); p.gy = di_div_up(Ci_l, bm);
     p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
@@ -1726,6 +1812,7 @@ extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* d
   }
   ReduceGroup rg;
   rg.out = dx; rg.Cout = Ci_l; rg.n = 0;
+  rg.ep_y = ag ? ag->y : nullptr; rg.ep_add = ag ? ag->add : nullptr; rg.ep_slope = ag ? ag->slope : 1.f;
   int cstart = 0, rstart = 0;
   size_t poff = 0;
   for (int m = 0; m < 4; ++m) {
@@ -1764,7 +1851,8 @@ extern "C" int deepim_conv2d_forward_split16(deepim_ctx* ctx, void* out_split16,
 
 static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B,
                                int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, float slope,
-                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale, const Remap* rm) {
+                               int out_ctotal, int out_coff, int in_nc8, int out_nc8, float out_scale, const Remap* rm,
+                               const ActGrad* ag) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE((long)Cin * H * W < (1L << 31), "conv2d: per-sample input too large for 32-bit offsets");
@@ -1773,6 +1861,7 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
     // so a launch sees < 2 GiB of input; larger batches run as consecutive sub-batches (samples are independent)
     const size_t per_sample = (size_t)Cin * H * W * 4, limit = 0x7fffffffUL - (size_t)(pad * W + pad) * 4;
     if ((size_t)B * per_sample >= limit) {
+      DI_REQUIRE(ag == nullptr, "conv2d: activation-gradient epilogue on a sub-batched launch (input >= 2 GiB)");
       const int Bc = (int)((limit - 1) / per_sample);
       DI_REQUIRE(Bc >= 1, "conv2d: one sample exceeds 2 GiB");
       const int Ho_ = (H + 2 * pad - kh) / stride + 1, Wo_ = (W + 2 * pad - kw) / stride + 1;
@@ -1814,6 +1903,7 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
   p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8; p.out_scale = out_scale; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
+  p.ep_y = ag ? ag->y : nullptr; p.ep_add = ag ? ag->add : nullptr; p.ep_slope = ag ? ag->slope : 1.f;
   if (out_nc8 == 2) DI_REQUIRE(!in_nc8, "conv2d: split16 output is built for the NCHW-input LDS-free kernel (conv1)");
   if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
   if (in_nc8) {
@@ -1902,6 +1992,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
   p.in_nc8 = p.out_nc8 = 0; p.wd8 = nullptr; p.tab8 = nullptr;
+  p.ep_y = p.ep_add = nullptr; p.ep_slope = 1.f;
   return launch_conv<MODE_DECONV>(ctx, p, 4);
 }
 

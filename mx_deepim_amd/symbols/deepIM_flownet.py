@@ -565,7 +565,14 @@ def _train_methods():
         assert getattr(self, "is_train", False), "call get_symbol(cfg, is_train=True) first"
         self.bind(ctx, batch_size, arg_params)
         B, H, W = self.B, self.H, self.W
+        # rot / trans FullyConnected run their backward as ONE 7-row layer: their weights and gradients live as row ranges of
+        # shared (7,256) / (7,) buffers, so nothing is assembled or split per step
+        w7, dw7, db7 = ctx.empty((7, 256)), ctx.zeros((7, 256)), ctx.zeros((7,))
+        w7[0:4].copyfrom(self.params["rot_weight"]); w7[4:7].copyfrom(self.params["trans_weight"])
+        self.params["rot_weight"], self.params["trans_weight"] = w7[0:4], w7[4:7]
         self.grad = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
+        self.grad["rot_weight"], self.grad["trans_weight"] = dw7[0:4], dw7[4:7]
+        self.grad["rot_bias"], self.grad["trans_bias"] = db7[0:4], db7[4:7]
         self.mom = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
         A = self.act
         A["rot"], A["rot_norm"] = ctx.empty((B, 4)), ctx.empty((B, 4))
@@ -573,23 +580,18 @@ def _train_methods():
         A["points_est"] = ctx.empty((B, 3, num_points))
         A["pm_loss"], A["pm_loss_sum"] = ctx.empty((B, 3, num_points)), ctx.empty((1,))
         self.num_points = num_points
-        # backward workspaces: two ping-pong activation-gradient buffers, the dilated gradient of the stride-2 layers, the
-        # transposed+flipped weights and their packed form (sized for the largest layer)
+        # backward workspaces: two ping-pong activation-gradient buffers, the un-cropped gradient of the decoder's transposed
+        # convolutions, and the packed data-gradient weights (sized for the largest layer)
         big = max(int(np.prod(A[g[0]].shape)) for g in self.enc_geom)
         self.ws = {"ga": ctx.empty((big,)), "gb": ctx.empty((big,))}
-        dil, wmax, pmax = 4, 4, 4
+        dil, pmax = 4, 4
         psize = lib.load().deepim_conv_packed_size
         for name, cin, h, w, cout, k, s_, p_ in self.enc_geom[1:]:
-            if s_ > 1:
-                dil = max(dil, B * cout * (h - k + 1 + 2 * p_) * (w - k + 1 + 2 * p_))
-            wmax = max(wmax, cout * cin * k * k)
             pmax = max(pmax, psize(cin, cout, k, k) // 4)
-            if s_ == 2:
-                pmax = max(pmax, lib.load().deepim_conv_dgrad_s2_packed_size(cout, cin, k, p_) // 4)
+            pmax = max(pmax, lib.load().deepim_conv_dgrad_packed_size(cout, cin, k, s_, p_) // 4)
         if self.with_decoder:
             # the un-cropped gradients of the two big transposed convolutions, and the role-swapped weights of the decoder layers
             dil = max(dil, B * 256 * 32 * 42, B * 512 * 18 * 22)
-            wmax = max(wmax, 1026 * 256 * 16, 1024 * 512 * 16)
             pmax = max(pmax, psize(1026, 256, 4, 4) // 4, psize(1024, 512, 4, 4) // 4, psize(1026, 2, 3, 3) // 4,
                        psize(770, 2, 3, 3) // 4)
             W_ = self.ws
@@ -608,9 +610,9 @@ def _train_methods():
             A["mask_prob"], A["zoom_mask_gt_observed"] = ctx.empty((B, 1, H, W)), ctx.empty((B, 1, H, W))
             self.ws["zm_a"], self.ws["zm_b"], self.ws["zm_f"] = ctx.empty((B, 1, H, W)), ctx.empty((B, 1, H, W)), ctx.empty((B, 4))
             self.ws["d_mask_hi"] = ctx.empty((B, 1, H, W))
-        self.ws["dil"], self.ws["wt"], self.ws["wt_packed"] = ctx.empty((dil,)), ctx.empty((wmax,)), ctx.empty((pmax,))
+        self.ws["dil"], self.ws["wt_packed"] = ctx.empty((dil,)), ctx.empty((pmax,))
         self.ws["g256a"], self.ws["g256b"] = ctx.empty((B, 256)), ctx.empty((B, 256))
-        self.ws["dy7"], self.ws["w7"], self.ws["dw7"], self.ws["db7"] = ctx.empty((B, 7)), ctx.empty((7, 256)), ctx.empty((7, 256)), ctx.empty((7,))
+        self.ws["dy7"], self.ws["w7"], self.ws["dw7"], self.ws["db7"] = ctx.empty((B, 7)), w7, dw7, db7
         self.ws["d_points"] = ctx.empty((B, 3, num_points))
         self.ws["d_rot_norm"], self.ws["d_trans_est"] = ctx.empty((B, 4)), ctx.empty((B, 3))
         self.ws["d_rot"], self.ws["d_trans"] = ctx.empty((B, 4)), ctx.empty((B, 3))
@@ -669,26 +671,21 @@ def _train_methods():
         self._train_io = (data, label)
         return A["pm_loss_sum"]
 
-    def _dgrad(self, dx, dz, w_raw, B, cin, hh, ww, cout, k, s_, p_, ho, wo):
-        """dx (B,cin,hh,ww) of a Convolution (cout,cin,k,k; stride s_, pad p_) given dz (B,cout,ho,wo).
+    def _dgrad(self, dx, dz, w_raw, B, cin, hh, ww, cout, k, s_, p_, ho, wo, act_y=None, add=None):
+        """dx (B,cin,hh,ww) of a Convolution (cout,cin,k,k; stride s_, pad p_) given dz (B,cout,ho,wo); with act_y (the saved output
+        of the layer below, [+ add: the gradient arriving over its skip connection]) dx already is that layer's dz =
+        lrelu'(act_y)·(dx + add), applied in the convolution's final stores.
         stride 1: the forward MFMA conv kernel on dz with the transposed, flipped weights, pad k-1-p.
         stride 2: four stride-1 convolutions of the UN-dilated dz, one per output parity class (y % 2, x % 2) with the
         sub-kernel of the taps that class meets (k = 3: 1, 2, 2 and 4 taps; k = 5: 4, 6, 6 and 9), each storing its result
-        window on its parity positions of dx — exactly the ideal multiply-adds (round 2 convolved a zero-dilated dz: 4x those)."""
-        h = self.ctx.handle
-        if s_ == 1:
-            order = lib.load().deepim_conv_weight_order(h, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_)   # packed for one use
-            lib.deepim_conv_pack_dgrad(h, self.ws["wt_packed"], w_raw, cout, cin, k, k, 0, 0, 1, k, k, order)   # transposed + flipped
-            lib.deepim_conv2d_forward(h, dx, dz, self.ws["wt_packed"], None, B, cout, ho, wo, cin, k, k, 1, k - 1 - p_,
-                                      ctypes.c_float(1.0), 0, 0)
-            return
-        assert s_ == 2
-        # the four parity classes packed, convolved and reduced by one launch each
-        lib.deepim_conv2d_dgrad_s2(h, dx, dz, w_raw, self.ws["wt_packed"], B, cin, hh, ww, cout, k, p_)
+        window on its parity positions of dx — exactly the ideal multiply-adds (round 2 convolved a zero-dilated dz: 4x those);
+        the four classes are packed, convolved and reduced by one launch each."""
+        lib.deepim_conv2d_dgrad(self.ctx.handle, dx, dz, w_raw, self.ws["wt_packed"], B, cin, hh, ww, cout, k, s_, p_, act_y, add,
+                                ctypes.c_float(SLOPE))
 
-    def _conv_backward(self, li, dz, dx, bias_done=False):
+    def _conv_backward(self, li, dz, dx, bias_done=False, act_y=None, add=None):
         """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into
-        self.grad, data gradient into dx (None for the first layer)."""
+        self.grad, data gradient into dx (None for the first layer) — with act_y already as the dz of the layer below (_dgrad)."""
         name, cin, hh, ww, cout, k, s_, p_ = self.enc_geom[li]
         h, B, A = self.ctx.handle, self.B, self.act
         ho, wo = _out_hw(hh, ww, k, s_, p_)
@@ -697,13 +694,13 @@ def _train_methods():
             lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
         lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, k, k, s_, p_)
         if dx is not None:
-            self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, k, s_, p_, ho, wo)
+            self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, k, s_, p_, ho, wo, act_y, add)
 
     def _small_conv_backward(self, name, src, dz, dx, cin, hh, ww, cout):
         """A 3x3 s1 p1 prediction layer (Convolution1/2/3, mask_conv3): gradients into self.grad, data gradient into dx."""
         h, B = self.ctx.handle, self.B
-        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, hh * ww)
-        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, 3, 3, 1, 1)
+        lib.deepim_conv2d_wgrad_bias(h, self.grad[name + "_weight"], self.grad[name + "_bias"], src, dz, B, cin, hh, ww, cout, 3, 3,
+                                     1, 1)
         self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, 3, 1, 1, hh, ww)
 
     def _head_conv_backward(self, name, d_low, cout, first):
@@ -781,11 +778,7 @@ def _train_methods():
         # rot / trans FullyConnected as one 7-row layer: dy7 = [d_rot | d_trans], w7 = [rot_weight; trans_weight]
         lib.deepim_copy_channels(h, W_["dy7"], 7, 0, W_["d_rot"], 4, B, 1)
         lib.deepim_copy_channels(h, W_["dy7"], 7, 4, W_["d_trans"], 3, B, 1)
-        W_["w7"][0:4].copyfrom(P["rot_weight"])
-        W_["w7"][4:7].copyfrom(P["trans_weight"])
-        lib.deepim_fc_backward(h, W_["g256a"], W_["dw7"], W_["db7"], W_["dy7"], A["fc7"], W_["w7"], B, 256, 7)
-        G["rot_weight"].copyfrom(W_["dw7"][0:4]); G["trans_weight"].copyfrom(W_["dw7"][4:7])
-        G["rot_bias"].copyfrom(W_["db7"][0:4]); G["trans_bias"].copyfrom(W_["db7"][4:7])
+        lib.deepim_fc_backward(h, W_["g256a"], W_["dw7"], W_["db7"], W_["dy7"], A["fc7"], W_["w7"], B, 256, 7)   # G[rot_*], G[trans_*] are its rows
         # fc7, fc6 (LeakyReLU gradient from the saved outputs)
         lib.deepim_lrelu_backward(h, W_["g256a"], W_["g256a"], A["fc7"], c(SLOPE), B * 256)
         lib.deepim_fc_backward(h, W_["g256b"], G["fc7_weight"], G["fc7_bias"], W_["g256a"], A["fc6"], P["fc7_weight"], B, 256, 256)
@@ -794,19 +787,20 @@ def _train_methods():
         ga, gb = W_["ga"], W_["gb"]
         lib.deepim_fc_backward(h, ga, G["fc6_weight"], G["fc6_bias"], W_["g256b"], A["conv6_1"].reshape((B, n6)),
                                P["fc6_weight"], B, n6, 256)
-        if self.with_decoder:
-            lib.deepim_axpy(h, ga, W_["d_dec61"], c(1.0), B * n6)
         skips = {"conv5_1": "d_skip5", "conv4_1": "d_skip4"} if self.with_decoder else {}
-        # encoder, last layer first: dz in place over dy, dx into the other buffer
-        for li in range(len(self.enc_geom) - 1, -1, -1):
-            name = self.enc_geom[li][0]
-            n_el = A[name].size
-            # skip-gradient add, LeakyReLU gradient and the bias gradient in one walk over the layer's output
-            _, cin_, hh_, ww_, cout_, k_, s_, p_ = self.enc_geom[li]
-            ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
-            lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_[skips[name]] if name in skips else None, A[name],
-                                           c(SLOPE), B, cout_, ho_ * wo_)
-            self._conv_backward(li, ga, gb if li > 0 else None, bias_done=True)
+        # encoder, last layer first. The top layer's dz = lrelu'(conv6_1)·dy comes from one fused walk (with its bias gradient);
+        # below it every data gradient leaves its convolution already multiplied by the activation gradient of the layer it
+        # lands on (+ that layer's skip gradient), so a layer costs bias gradient + weight gradient + data gradient, no more.
+        top = len(self.enc_geom) - 1
+        for li in range(top, -1, -1):
+            name, cin_, hh_, ww_, cout_, k_, s_, p_ = self.enc_geom[li]
+            if li == top:
+                ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
+                lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_["d_dec61"] if self.with_decoder else None, A[name],
+                                               c(SLOPE), B, cout_, ho_ * wo_)      # + the decoder's gradient on conv6_1
+            below = self.enc_geom[li - 1][0] if li > 0 else None
+            self._conv_backward(li, ga, gb if li > 0 else None, bias_done=(li == top), act_y=A[below] if below else None,
+                                add=W_[skips[below]] if below in skips else None)
             ga, gb = gb, ga
         return G
 

@@ -153,6 +153,38 @@ def test_stride2_dgrad_by_parity_classes_matches_oracle(ctx, case):
     assert np.abs(res[0][dx_ref == 0]).max(initial=0.0) == 0.0
 
 
+DG_CASES = [(2, 256, 8, 10, 256, 3, 1, 1), (3, 24, 16, 20, 136, 3, 1, 1), (1, 5, 12, 12, 3, 3, 1, 1), (2, 128, 30, 40, 130, 3, 1, 1),
+            (2, 64, 24, 32, 128, 5, 2, 2), (4, 512, 15, 20, 1024, 3, 2, 1), (2, 6, 13, 17, 10, 3, 2, 1), (1, 8, 20, 28, 17, 7, 2, 3),
+            (2, 128, 30, 40, 256, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("case", DG_CASES)
+@pytest.mark.parametrize("with_add", [False, True])
+def test_dgrad_with_activation_gradient_epilogue(ctx, case, with_add):
+    """deepim_conv2d_dgrad: the plain data gradient against the oracle; with act_y [and add] the result is bit-identical to the
+    plain one followed by (dx + add) · lrelu'(act_y) — whether the epilogue rode in the convolution's stores (register-fed
+    kernels, grouped stride-2 classes, split-K second passes) or ran as a pass of its own (other kernel families)."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case) + 21)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz_h = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    dx_ref, _, _ = onet.conv2d_backward(x, w, dz_h, s, p)
+    h = ctx.handle
+    dz, wd = ctx.array(dz_h), ctx.array(w)
+    ws = DeviceArray(ctx, (lib.load().deepim_conv_dgrad_packed_size(cout, cin, k, s, p) // 4,))
+    plain = ctx.array(np.full(x.shape, 7.0, np.float32))
+    lib.deepim_conv2d_dgrad(h, plain, dz, wd, ws, B, cin, H, W, cout, k, s, p, None, None, cf(0.1))
+    close(plain.asnumpy(), dx_ref)
+    y = rng.standard_normal(x.shape).astype(np.float32)
+    add = rng.standard_normal(x.shape).astype(np.float32) if with_add else None
+    got = ctx.array(np.full(x.shape, 7.0, np.float32))
+    lib.deepim_conv2d_dgrad(h, got, dz, wd, ws, B, cin, H, W, cout, k, s, p, ctx.array(y), ctx.array(add) if with_add else None, cf(0.1))
+    v = plain.asnumpy() + add if with_add else plain.asnumpy()
+    np.testing.assert_array_equal(got.asnumpy(), np.where(y > 0, v, v * np.float32(0.1)).astype(np.float32))
+
+
 @pytest.mark.parametrize("case", WG_CASES + [(4, 64, 60, 80, 128, 5, 2, 2), (2, 512, 15, 20, 1024, 3, 2, 1),
                                   # few filters: the stream kernel (heads: 3x3 s1; flow upsamplers' role-swapped k4 s2)
                                   (4, 770, 30, 40, 2, 3, 1, 1), (2, 6, 30, 40, 1, 3, 1, 1), (2, 2, 32, 42, 2, 4, 2, 0),
@@ -183,6 +215,24 @@ def test_wgrad_lds_kernel_vs_register_fed_kernel(ctx, case):
     finally:
         lib.deepim_set_option(h, b"wgrad_lds", 1)
     close(res[1], res[0].astype(np.float64), 1e-5)
+
+
+@pytest.mark.parametrize("case", [(4, 770, 30, 40, 2, 3, 1, 1), (2, 6, 30, 40, 1, 3, 1, 1), (3, 9, 10, 12, 4, 3, 1, 1), (2, 24, 16, 20, 136, 3, 1, 1)])
+def test_wgrad_with_bias_in_one_call(ctx, case):
+    """deepim_conv2d_wgrad_bias = deepim_conv2d_wgrad + the bias gradient (in the same launch for the few-filter layers)."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz_h = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    h = ctx.handle
+    xd, dz = ctx.array(x), ctx.array(dz_h)
+    dw_ref = ctx.empty((cout, cin, k, k))
+    lib.deepim_conv2d_wgrad(h, dw_ref, xd, dz, B, cin, H, W, cout, k, k, s, p)
+    dw, db = ctx.empty((cout, cin, k, k)), ctx.empty((cout,))
+    lib.deepim_conv2d_wgrad_bias(h, dw, db, xd, dz, B, cin, H, W, cout, k, k, s, p)
+    np.testing.assert_array_equal(dw.asnumpy(), dw_ref.asnumpy())
+    close(db.asnumpy(), dz_h.astype(np.float64).sum(axis=(0, 2, 3)), 1e-5)
 
 
 @pytest.mark.parametrize("shape", [(4, 81920, 256), (3, 256, 256), (5, 256, 7)])
