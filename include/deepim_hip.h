@@ -64,6 +64,10 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * (and the few-filter stream kernel for Cout <= 4), 0 = the round-2 register-fed kernel; "dgrad_group": 1 (default) = the four
  * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
+/* Device-side ordering between two contexts (two streams) of ONE GPU: work queued on `waiter` after this call starts only after
+ * everything queued on `ctx` before it has finished; the host does not block. Lets independent kernels of one graph (the weight
+ * and the data gradient of a layer) share the chip: each context has its own stream and scratch. */
+int deepim_stream_wait(deepim_ctx* waiter, deepim_ctx* ctx);
 /* HIP-event stopwatch on the context stream (bench.py's per-kernel timing) */
 int deepim_timer_create(deepim_ctx* ctx, int* timer_id);
 int deepim_timer_start(deepim_ctx* ctx, int timer_id);

@@ -38,6 +38,7 @@ struct deepim_ctx {
   int* box_words;   // DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: bbox accumulators of mask_box, armed inside every call
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
+  hipEvent_t sync_event;   // deepim_stream_wait: "everything queued on this stream so far" (created on first use)
   std::vector<hipGraphExec_t> graphs;
   bool capturing;
   std::vector<ConvTab> conv_tabs;

@@ -28,6 +28,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->capturing = false;
+  c->sync_event = nullptr;
   c->comm = nullptr;
   c->comm_rank = 0;
   c->comm_world = 1;
@@ -74,6 +75,7 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
   for (auto g : ctx->graphs) hipGraphExecDestroy(g);
   for (auto e : ctx->timer_start) hipEventDestroy(e);
   for (auto e : ctx->timer_stop) hipEventDestroy(e);
+  if (ctx->sync_event) hipEventDestroy(ctx->sync_event);
   for (auto& t : ctx->conv_tabs) hipFree(t.tab);
   for (auto p : ctx->retired_scratch) hipFree(p);
   if (ctx->scratch) hipFree(ctx->scratch);
@@ -190,6 +192,19 @@ extern "C" int deepim_sync(deepim_ctx* ctx) {
   return 0;
 }
 extern "C" void* deepim_stream(deepim_ctx* ctx) { return (void*)ctx->stream; }
+
+// Device-side ordering between two contexts (= two streams) of one GPU: work queued on `waiter` after this call runs only after
+// everything queued on `ctx` before it. No host synchronisation.
+extern "C" int deepim_stream_wait(deepim_ctx* waiter, deepim_ctx* ctx) {
+  DI_REQUIRE(waiter != nullptr && ctx != nullptr && waiter->device == ctx->device, "stream_wait: two contexts of the same device");
+  DI_REQUIRE(!waiter->capturing && !ctx->capturing, "stream_wait during graph capture");
+  if (waiter == ctx) return 0;
+  DI_DEVICE(ctx);
+  if (!ctx->sync_event) DI_CHECK(hipEventCreateWithFlags(&ctx->sync_event, hipEventDisableTiming));
+  DI_CHECK(hipEventRecord(ctx->sync_event, ctx->stream));
+  DI_CHECK(hipStreamWaitEvent(waiter->stream, ctx->sync_event, 0));
+  return 0;
+}
 
 extern "C" int deepim_timer_create(deepim_ctx* ctx, int* timer_id) {
   DI_DEVICE(ctx);

@@ -109,6 +109,7 @@ class deepIM_flownet(object):
         self.get_test_symbol_share(cfg)
         self.is_train = True
         self.nc8 = False          # NCHW activations: what the backward kernels read
+        self.two_streams = True   # backward(): weight gradients on a second stream next to the data gradients (False: one stream)
         self.with_mask_head, self.with_flow_head = bool(n.PRED_MASK), bool(n.PRED_FLOW)    # :183, :314
         self.with_decoder = self.with_mask_head or self.with_flow_head
         return self
@@ -567,6 +568,7 @@ def _train_methods():
         B, H, W = self.B, self.H, self.W
         # rot / trans FullyConnected run their backward as ONE 7-row layer: their weights and gradients live as row ranges of
         # shared (7,256) / (7,) buffers, so nothing is assembled or split per step
+        self.side = Context(ctx.device_id) if self.two_streams else None     # second stream of the backward (see backward())
         w7, dw7, db7 = ctx.empty((7, 256)), ctx.zeros((7, 256)), ctx.zeros((7,))
         w7[0:4].copyfrom(self.params["rot_weight"]); w7[4:7].copyfrom(self.params["trans_weight"])
         self.params["rot_weight"], self.params["trans_weight"] = w7[0:4], w7[4:7]
@@ -683,19 +685,6 @@ def _train_methods():
         lib.deepim_conv2d_dgrad(self.ctx.handle, dx, dz, w_raw, self.ws["wt_packed"], B, cin, hh, ww, cout, k, s_, p_, act_y, add,
                                 ctypes.c_float(SLOPE))
 
-    def _conv_backward(self, li, dz, dx, bias_done=False, act_y=None, add=None):
-        """Gradients of encoder layer li given dz = dLoss/d(pre-activation) (B,Cout,Ho,Wo): bias and weight gradients into
-        self.grad, data gradient into dx (None for the first layer) — with act_y already as the dz of the layer below (_dgrad)."""
-        name, cin, hh, ww, cout, k, s_, p_ = self.enc_geom[li]
-        h, B, A = self.ctx.handle, self.B, self.act
-        ho, wo = _out_hw(hh, ww, k, s_, p_)
-        src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
-        if not bias_done:
-            lib.deepim_bias_grad(h, self.grad[name + "_bias"], dz, B, cout, ho * wo)
-        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], src, dz, B, cin, hh, ww, cout, k, k, s_, p_)
-        if dx is not None:
-            self._dgrad(dx, dz, self.params[name + "_weight"], B, cin, hh, ww, cout, k, s_, p_, ho, wo, act_y, add)
-
     def _small_conv_backward(self, name, src, dz, dx, cin, hh, ww, cout):
         """A 3x3 s1 p1 prediction layer (Convolution1/2/3, mask_conv3): gradients into self.grad, data gradient into dx."""
         h, B = self.ctx.handle, self.B
@@ -788,20 +777,29 @@ def _train_methods():
         lib.deepim_fc_backward(h, ga, G["fc6_weight"], G["fc6_bias"], W_["g256b"], A["conv6_1"].reshape((B, n6)),
                                P["fc6_weight"], B, n6, 256)
         skips = {"conv5_1": "d_skip5", "conv4_1": "d_skip4"} if self.with_decoder else {}
-        # encoder, last layer first. The top layer's dz = lrelu'(conv6_1)·dy comes from one fused walk (with its bias gradient);
-        # below it every data gradient leaves its convolution already multiplied by the activation gradient of the layer it
-        # lands on (+ that layer's skip gradient), so a layer costs bias gradient + weight gradient + data gradient, no more.
-        top = len(self.enc_geom) - 1
-        for li in range(top, -1, -1):
+        # encoder, last layer first: dz = lrelu'(y)·(dy [+ the gradient over the layer's skip connection]) and the bias gradient in
+        # one fused walk, in place over dy; dx into the other buffer. (_dgrad can apply the activation gradient of the layer below
+        # in the convolution's own final stores instead — measured slower, 4.56 → 4.63 ms: the scattered epilogue reads of the
+        # saved output cost more than the streaming pass they replace. profiles/r03_train_backward.md)
+        # The weight gradient of a layer runs on a SECOND stream (self.side: own context, own scratch) next to the data gradient:
+        # both only read dz, and on conv4 … conv6_1 neither fills the chip through its pack → convolution → second-pass chain.
+        # Ordering: side waits for dz; main waits for the previous layer's weight gradient before its data gradient overwrites
+        # the buffer that one reads (the two gradient buffers ping-pong).
+        extra = {"conv6_1": "d_dec61", **skips} if self.with_decoder else {}
+        side = self.side.handle if self.side is not None else h
+        for li in range(len(self.enc_geom) - 1, -1, -1):
             name, cin_, hh_, ww_, cout_, k_, s_, p_ = self.enc_geom[li]
-            if li == top:
-                ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
-                lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_["d_dec61"] if self.with_decoder else None, A[name],
-                                               c(SLOPE), B, cout_, ho_ * wo_)      # + the decoder's gradient on conv6_1
-            below = self.enc_geom[li - 1][0] if li > 0 else None
-            self._conv_backward(li, ga, gb if li > 0 else None, bias_done=(li == top), act_y=A[below] if below else None,
-                                add=W_[skips[below]] if below in skips else None)
+            ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
+            lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_[extra[name]] if name in extra else None, A[name],
+                                           c(SLOPE), B, cout_, ho_ * wo_)
+            lib.deepim_stream_wait(h, side)      # weight gradient of layer li+1 done: gb may be overwritten
+            lib.deepim_stream_wait(side, h)      # dz of this layer ready
+            src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
+            lib.deepim_conv2d_wgrad(side, G[name + "_weight"], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)
+            if li > 0:
+                self._dgrad(gb, ga, P[name + "_weight"], B, cin_, hh_, ww_, cout_, k_, s_, p_, ho_, wo_)
             ga, gb = gb, ga
+        lib.deepim_stream_wait(h, side)          # every gradient is in place when the main stream goes on (update)
         return G
 
     def update(self, lr, wd=0.0005, momentum=0.975, rescale_grad=1.0, clip_gradient=None):
@@ -848,7 +846,7 @@ def _train_methods():
                     "Convolution3": (770, 30, 40, 2, 3, 1, 1), "mask_conv3": (770, 30, 40, 1, 3, 1, 1)})
         return {n: order(h, B, cin, hh, ww, cout, k, k, s_, p_) for n, (cin, hh, ww, cout, k, s_, p_) in geo.items()}
 
-    return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad, _conv_backward=_conv_backward,
+    return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad,
                 _small_conv_backward=_small_conv_backward, _head_conv_backward=_head_conv_backward,
                 _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update,
                 _train_pack_orders=_train_pack_orders)
