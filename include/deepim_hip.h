@@ -509,6 +509,11 @@ int deepim_scatter2d(deepim_ctx* ctx, float* out, const float* in, int BC, int H
  * deepIM_flownet.py:185-200,326-340): d_in (B,C,H,W) from dy (B,C,Ho,Wo) */
 int deepim_upsample16_crop_backward(deepim_ctx* ctx, float* d_in, const float* dy, const float* w, int B, int C, int H, int W,
                                     int Ho, int Wo, int crop_y, int crop_x, float scale);
+/* backward of [Concat slice -> LeakyReLU -> Crop] in front of a Deconvolution, in one walk: out (B,C,hf,wf) = channels
+ * [coff, coff+C) of dcat (B,ctotal,ho,wo) times lrelu'(same slice of ycat; NULL: no activation) at offset (off_y, off_x), zeros
+ * around; db[c] = its sum (NULL: skipped). deepIM_flownet.py:120-167 */
+int deepim_slice_lrelu_bias_scatter(deepim_ctx* ctx, float* out, float* db, const float* dcat, const float* ycat, int B, int ctotal,
+                                    int coff, int C, int ho, int wo, int hf, int wf, int off_y, int off_x, float slope);
 /* backward of Concat: dst (B,C,hw) = channels [src_coff, src_coff+C) of src (B,src_ctotal,hw) */
 int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float* src, int src_ctotal, int src_coff, int C, int B,
                             size_t hw);

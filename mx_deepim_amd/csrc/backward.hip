@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void lrelu_backward_kernel(float* dz, const fl
 // sums of a channel in order. One block per channel (round 2) left 64-128 blocks walking 300 k elements each on the first
 // layers: 0.32 ms for conv1's gradient alone.
 __global__ __launch_bounds__(256) void bias_grad_kernel(double* __restrict__ partial, const float* __restrict__ dz, int B, int C,
-                                                        long HW, int S, long per_slice) {
+                                                        long HW, int S, long per_slice, float* __restrict__ db) {
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const long lo = (long)sl * per_slice, hi = min(HW, lo + per_slice);
   double acc = 0.0;
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(double* __restrict__ par
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
-  if (tid == 0) partial[(long)c * S + sl] = red[0];
+  if (tid == 0) {
+    if (S == 1) db[c] = (float)red[0];     // a single slice is the sum itself: no second pass
+    else partial[(long)c * S + sl] = red[0];
+  }
 }
 
 // The same walk with the LeakyReLU gradient folded in: dz = lrelu'(y)·(dy [+ add]) is written AND summed by block (c, slice) — one
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(double* __restrict__ par
 template <bool V4>
 __global__ __launch_bounds__(256) void lrelu_bias_backward_kernel(double* __restrict__ partial, float* dz, const float* dy,
                                                                   const float* add, const float* __restrict__ y, float slope,
-                                                                  int B, int C, long HW, int S, long per_slice) {
+                                                                  int B, int C, long HW, int S, long per_slice, float* __restrict__ db) {
   const int c = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const long lo = (long)sl * per_slice, hi = min(HW, lo + per_slice);
   double acc = 0.0;
@@ -90,7 +93,44 @@ __global__ __launch_bounds__(256) void lrelu_bias_backward_kernel(double* __rest
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
-  if (tid == 0) partial[(long)c * S + sl] = red[0];
+  if (tid == 0) {
+    if (S == 1) db[c] = (float)red[0];     // a single slice is the sum itself: no second pass
+    else partial[(long)c * S + sl] = red[0];
+  }
+}
+
+// Backward of [Concat slice → LeakyReLU → Crop] in front of a transposed convolution, in one walk: channels [coff, coff + C) of
+// the concat gradient (B,ctotal,ho,wo), times lrelu'(y) of the same slice of the saved concat output (y NULL: no activation),
+// placed at (off_y, off_x) of the un-cropped frame (B,C,hf,wf) with zeros around, and summed per channel (the bias gradient).
+// Block = one channel. Replaces two slice copies, the activation gradient, both bias-gradient passes and the scatter.
+__global__ __launch_bounds__(256) void slice_lrelu_bias_scatter_kernel(float* __restrict__ out, float* __restrict__ db,
+                                                                       const float* __restrict__ dcat, const float* __restrict__ ycat,
+                                                                       int B, int ctotal, int coff, int C, int ho, int wo, int hf,
+                                                                       int wf, int off_y, int off_x, float slope) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double acc = 0.0;
+  for (int n = 0; n < B; ++n) {
+    const long src = ((long)n * ctotal + coff + c) * ho * wo;
+    float* o = out + ((long)n * C + c) * hf * wf;
+    for (int i = tid; i < hf * wf; i += 256) {
+      const int y = i / wf - off_y, x = i % wf - off_x;
+      float g = 0.f;
+      if ((unsigned)y < (unsigned)ho && (unsigned)x < (unsigned)wo) {
+        g = dcat[src + y * wo + x];
+        if (ycat) g = ycat[src + y * wo + x] > 0.f ? g : g * slope;
+        acc += (double)g;
+      }
+      o[i] = g;
+    }
+  }
+  __shared__ double red[256];
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0 && db) db[c] = (float)red[0];
 }
 
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(float* __restrict__ db, const double* __restrict__ partial, int C,
@@ -723,11 +763,25 @@ extern "C" int deepim_lrelu_bias_backward(deepim_ctx* ctx, float* dz, float* db,
   if (rc) return rc;
   if (hw % 4 == 0)
     hipLaunchKernelGGL(lrelu_bias_backward_kernel<true>, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, dy, add, y,
-                       slope, B, C, (long)hw, S, per_slice);
+                       slope, B, C, (long)hw, S, per_slice, db);
   else
     hipLaunchKernelGGL(lrelu_bias_backward_kernel<false>, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, dy, add, y,
-                       slope, B, C, (long)hw, S, per_slice);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
+                       slope, B, C, (long)hw, S, per_slice, db);
+  if (S > 1)
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_slice_lrelu_bias_scatter(deepim_ctx* ctx, float* out, float* db, const float* dcat, const float* ycat, int B,
+                                               int ctotal, int coff, int C, int ho, int wo, int hf, int wf, int off_y, int off_x,
+                                               float slope) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(coff >= 0 && C >= 0 && coff + C <= ctotal && off_y >= 0 && off_x >= 0 && off_y + ho <= hf && off_x + wo <= wf,
+             "slice_lrelu_bias_scatter: slice outside the concat / frame too small");
+  if (B == 0 || C == 0) return 0;
+  hipLaunchKernelGGL(slice_lrelu_bias_scatter_kernel, dim3(C), dim3(256), 0, ctx->stream, out, db, dcat, ycat, B, ctotal, coff, C, ho,
+                     wo, hf, wf, off_y, off_x, slope);
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -750,8 +804,9 @@ extern "C" int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int
   void* scratch;
   int rc = deepim_scratch(ctx, (size_t)C * S * sizeof(double), &scratch);
   if (rc) return rc;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, B, C, (long)hw, S, per_slice);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C, S), dim3(256), 0, ctx->stream, (double*)scratch, dz, B, C, (long)hw, S, per_slice, db);
+  if (S > 1)
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(di_div_up(C, 256)), dim3(256), 0, ctx->stream, db, (const double*)scratch, C, S);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -600,8 +600,6 @@ def _train_methods():
             W_["d_Concat3"], W_["d_Concat2"] = ctx.empty((B, 770, 30, 40)), ctx.empty((B, 1026, 15, 20))
             W_["d_skip4"], W_["d_skip5"] = ctx.empty((B, 512, 30, 40)), ctx.empty((B, 512, 15, 20))
             W_["d_dec61"] = ctx.empty((B, 1024, 8, 10))
-            sl = max(B * 256 * 30 * 40, B * 512 * 15 * 20)
-            W_["sl_dy"], W_["sl_y"] = ctx.empty((sl,)), ctx.empty((sl,))
             W_["d_flow5"], W_["d_flow6"] = ctx.empty((B, 2, 15, 20)), ctx.empty((B, 2, 8, 10))
             W_["d_low"] = ctx.empty((B, 2, 30, 40))
         if self.with_flow_head:
@@ -702,15 +700,17 @@ def _train_methods():
             self._small_conv_backward(name, self.act["Concat3"], d_low, tmp, 770, 30, 40, cout)
             lib.deepim_axpy(self.ctx.handle, W_["d_Concat3"], tmp, ctypes.c_float(1.0), W_["d_Concat3"].size)
 
-    def _deconv_backward(self, name, x, dy, dx, cin, hh, ww, cout, ho, wo):
-        """Deconvolution k4 s2 + Crop(1,1) given dy = gradient of the cropped, pre-activation output (B,cout,ho,wo),
-        contiguous: bias / weight gradients into self.grad, data gradient (B,cin,hh,ww) into dx. The MXNet weight
-        (cin,cout,4,4) already is the Convolution layout of the adjoint (filters = cin, channels = cout), so the data gradient
-        is a stride-2 convolution of the un-cropped dy and the weight gradient a conv wgrad with input and output swapped."""
+    def _deconv_backward(self, name, x, dcat, ycat, ctotal, coff, dx, cin, hh, ww, cout, ho, wo):
+        """Deconvolution k4 s2 + Crop(1,1) [+ LeakyReLU] whose output is channels [coff, coff+cout) of a Concat: dcat = gradient of
+        the concat (B,ctotal,ho,wo), ycat = the saved concat (None: no activation). Bias / weight gradients into self.grad, data
+        gradient (B,cin,hh,ww) into dx. One walk slices the concat gradient, applies the activation gradient, sums the bias gradient
+        and puts the result back into the un-cropped frame; the MXNet weight (cin,cout,4,4) already is the Convolution layout of the
+        adjoint (filters = cin, channels = cout), so the data gradient is a stride-2 convolution of that frame and the weight
+        gradient a conv wgrad with input and output swapped."""
         h, B = self.ctx.handle, self.B
         hf, wf = 2 * hh + 2, 2 * ww + 2
-        lib.deepim_bias_grad(h, self.grad[name + "_bias"], dy, B, cout, ho * wo)
-        lib.deepim_scatter2d(h, self.ws["dil"], dy, B * cout, ho, wo, hf, wf, 1, 1, 1)
+        lib.deepim_slice_lrelu_bias_scatter(h, self.ws["dil"], self.grad[name + "_bias"], dcat, ycat, B, ctotal, coff, cout, ho, wo,
+                                            hf, wf, 1, 1, ctypes.c_float(SLOPE))
         lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
         order = lib.load().deepim_conv_weight_order(h, B, cout, hf, wf, cin, 4, 4, 2, 0)         # packed for this one use
         lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.params[name + "_weight"], cin, cout, 4, 4, order)
@@ -733,22 +733,14 @@ def _train_methods():
             self._head_conv_backward("mask_conv3", W_["d_low"], 1, first=not self.with_flow_head)
         # Concat3 = [conv4_1 | lrelu(deconv4) | upsample_flow5to4]
         ext(h, W_["d_skip4"], W_["d_Concat3"], 770, 0, 512, B, 1200)
-        ext(h, W_["sl_dy"], W_["d_Concat3"], 770, 512, 256, B, 1200)
-        ext(h, W_["sl_y"], A["Concat3"], 770, 512, 256, B, 1200)
-        lib.deepim_lrelu_backward(h, W_["sl_dy"], W_["sl_dy"], W_["sl_y"], c(SLOPE), B * 256 * 1200)
-        self._deconv_backward("deconv4", A["Concat2"], W_["sl_dy"], W_["d_Concat2"], 1026, 15, 20, 256, 30, 40)
-        ext(h, W_["sl_dy"], W_["d_Concat3"], 770, 768, 2, B, 1200)
-        self._deconv_backward("upsample_flow5to4", A["flow5"], W_["sl_dy"], W_["d_flow5"], 2, 15, 20, 2, 30, 40)
+        self._deconv_backward("deconv4", A["Concat2"], W_["d_Concat3"], A["Concat3"], 770, 512, W_["d_Concat2"], 1026, 15, 20, 256, 30, 40)
+        self._deconv_backward("upsample_flow5to4", A["flow5"], W_["d_Concat3"], None, 770, 768, W_["d_flow5"], 2, 15, 20, 2, 30, 40)
         self._small_conv_backward("Convolution2", A["Concat2"], W_["d_flow5"], W_["ga"], 1026, 15, 20, 2)
         lib.deepim_axpy(h, W_["d_Concat2"], W_["ga"], c(1.0), W_["d_Concat2"].size)
         # Concat2 = [conv5_1 | lrelu(deconv5) | upsample_flow6to5]
         ext(h, W_["d_skip5"], W_["d_Concat2"], 1026, 0, 512, B, 300)
-        ext(h, W_["sl_dy"], W_["d_Concat2"], 1026, 512, 512, B, 300)
-        ext(h, W_["sl_y"], A["Concat2"], 1026, 512, 512, B, 300)
-        lib.deepim_lrelu_backward(h, W_["sl_dy"], W_["sl_dy"], W_["sl_y"], c(SLOPE), B * 512 * 300)
-        self._deconv_backward("deconv5", A["conv6_1"], W_["sl_dy"], W_["d_dec61"], 1024, 8, 10, 512, 15, 20)
-        ext(h, W_["sl_dy"], W_["d_Concat2"], 1026, 1024, 2, B, 300)
-        self._deconv_backward("upsample_flow6to5", A["flow6"], W_["sl_dy"], W_["d_flow6"], 2, 8, 10, 2, 15, 20)
+        self._deconv_backward("deconv5", A["conv6_1"], W_["d_Concat2"], A["Concat2"], 1026, 512, W_["d_dec61"], 1024, 8, 10, 512, 15, 20)
+        self._deconv_backward("upsample_flow6to5", A["flow6"], W_["d_Concat2"], None, 1026, 1024, W_["d_flow6"], 2, 8, 10, 2, 15, 20)
         self._small_conv_backward("Convolution1", A["conv6_1"], W_["d_flow6"], W_["ga"], 1024, 8, 10, 2)
         lib.deepim_axpy(h, W_["d_dec61"], W_["ga"], c(1.0), W_["d_dec61"].size)
 

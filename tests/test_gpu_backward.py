@@ -397,6 +397,21 @@ def test_deconv_crop_backward_matches_oracle(ctx, case):
     lib.deepim_conv_pack_weights(h, pk, ctx.array(w), cin, cout, 4, 4)
     lib.deepim_conv2d_forward(h, dx, full, pk, None, B, cout, hf, wf, cin, 4, 4, 2, 0, cf(1.0), 0, 0)
     close(db.asnumpy(), db_ref); close(dw.asnumpy(), dw_ref); close(dx.asnumpy(), dx_ref)
+    # the one-walk front of it (what the training graph runs): slice of a concat gradient x lrelu'(slice of the saved concat) →
+    # un-cropped frame + bias gradient; bit-identical frame, same bias sum
+    ctotal, coff = cout + 5, 3
+    dcat = rng.standard_normal((B, ctotal, ho, wo)).astype(np.float32)
+    ycat = rng.standard_normal((B, ctotal, ho, wo)).astype(np.float32)
+    for use_y in (True, False):
+        sl = dcat[:, coff:coff + cout]
+        ref = np.where(ycat[:, coff:coff + cout] > 0, sl, sl * np.float32(0.1)).astype(np.float32) if use_y else sl
+        out, db2 = ctx.array(np.full((B, cout, hf, wf), 7.0, np.float32)), ctx.empty((cout,))
+        lib.deepim_slice_lrelu_bias_scatter(h, out, db2, ctx.array(dcat), ctx.array(ycat) if use_y else None, B, ctotal, coff, cout,
+                                            ho, wo, hf, wf, 1, 1, cf(0.1))
+        want = np.zeros((B, cout, hf, wf), np.float32)
+        want[:, :, 1:1 + ho, 1:1 + wo] = ref
+        np.testing.assert_array_equal(out.asnumpy(), want)
+        close(db2.asnumpy(), ref.astype(np.float64).sum(axis=(0, 2, 3)), 1e-6)
 
 
 @pytest.mark.parametrize("shape", [(2, 2, 30, 40, 480, 640), (1, 1, 30, 40, 480, 640), (3, 2, 5, 7, 70, 100)])
