@@ -344,24 +344,26 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.B * p.Cin * p.H * p.W * 4), 0x00020000);
   // dZ loader: rows rowA (+ 64) of the tile, pixels 4 qA … 4 qA + 3 of the chunk
   const int rowA = tid >> 2, qA = tid & 3;
-  unsigned a_row[NA];
+  unsigned a_off[NA];       // byte offset of the row inside a sample; bit 31 = row past Cout (→ out of range → 0.0)
 #pragma unroll
   for (int r = 0; r < NA; ++r) {
     const int co = mt * BM + rowA + 64 * r;
-    a_row[r] = co < p.Cout ? (unsigned)co : OOB;
+    a_off[r] = co < p.Cout ? (unsigned)(co * HW * 4) : OOB;
   }
   // im2col loader: pixel pixB of the chunk, columns krow0 + 16 e of the tile
   const int pixB = tid & 15, krow0 = tid >> 4;
-  unsigned b_plane[8];      // element offset of channel ci(k) inside a sample, or OOB for k >= K
-  int b_tap[8];             // (ky - pad) << 16 | (kx - pad) & 0xffff
+  int b_off[8];             // byte offset of tap (ci, ky - pad, kx - pad) from the pixel's (hi0, wi0) inside a sample (may be < 0)
+  int b_tap[8];             // (ky - pad) << 16 | (kx - pad) & 0xffff; a column past K gets a row far outside the image
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = kt * 128 + krow0 + 16 * e;
     const int kc = k < p.K ? k : 0;
     const int ci = kc / (p.kh * p.kw), t = kc - ci * (p.kh * p.kw);
-    b_plane[e] = k < p.K ? (unsigned)(ci * p.H * p.W) : OOB;
-    b_tap[e] = ((t / p.kw - p.pad) << 16) | ((t % p.kw - p.pad) & 0xffff);
+    const int ty = k < p.K ? t / p.kw - p.pad : 0x4000, tx = t % p.kw - p.pad;
+    b_off[e] = k < p.K ? (ci * p.H * p.W + ty * p.W + tx) * 4 : 0;
+    b_tap[e] = (ty << 16) | (tx & 0xffff);
   }
+  const int Hm1 = p.H - 1, Wm1 = p.W - 1;
   f32x16 acc[TM][2];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -382,28 +384,31 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
   // `valid ? offset : OOB` into branches — the selects below are plain bit operations (bit 31 set = out of range → 0.0)
   // (chunks at or past c_end load zeros: the loop below is branch-free — with loads under `if` the compiler cannot count what is in
   // flight and drains vmcnt(0) at every LDS store, i.e. the prefetch depth collapses to one chunk)
+  // Validity is integer arithmetic on the sign bit, never a compare: `x >= y ? … : …` becomes v_cmp → s_or_b64 → v_cndmask, and a
+  // VALU operation that reads an SGPR written by the scalar unit inside the MFMA shadow stalls the SIMD's issue (the effect
+  // measured on the forward kernel, tools/mfma_issue_probe.hip). v is outside [0, n) iff (v | (n - 1 - v)) is negative.
   auto load_regs = [&](int c, f32x4 (&ra)[NA], float (&rb)[8]) {
-    const unsigned dead = (unsigned)(c >= c_end);
+    const int deadm = -(int)(c >= c_end);             // scalar: all ones for a chunk past the slice
     c = min(c, chunks - 1);
     const int n = c / cps;                            // 32-bit: a 64-bit division is a software loop inside the pipeline
     const int pc = (c - n * cps) * WG_PIX;
     const int pa = pc + qA * 4;                       // HW % 4 == 0: the quad is entirely inside or entirely outside the sample
     unsigned offa[NA], offb[8];
+    const int basea = (n * p.Cout * HW + pa) * 4;
+    const unsigned inva = (unsigned)(deadm | (HW - 1 - pa));
 #pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const unsigned inv = dead | (a_row[r] >> 31) | (unsigned)(pa >= HW);
-      offa[r] = ((unsigned)(((n * p.Cout + (int)(a_row[r] & 0x7fffffffu)) * HW + pa) * 4) & 0x7fffffffu) | (inv << 31);
-    }
+    for (int r = 0; r < NA; ++r)
+      offa[r] = ((unsigned)(basea + (int)(a_off[r] & 0x7fffffffu)) & 0x7fffffffu) | ((inva | a_off[r]) & OOB);
     const int pb = pc + pixB;
     const int ho = pb / p.Wo, wo = pb - ho * p.Wo;
     const int hi0 = ho * p.stride, wi0 = wo * p.stride;
-    const unsigned nbase = (unsigned)(n * p.Cin * p.H * p.W);
-    const unsigned pinv = dead | (unsigned)(pb >= HW);
+    const int baseb = (n * p.Cin * p.H * p.W + hi0 * p.W + wi0) * 4;
+    const int pinv = deadm | (HW - 1 - pb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
-      const unsigned inv = pinv | (b_plane[e] >> 31) | (unsigned)((unsigned)hi >= (unsigned)p.H) | (unsigned)((unsigned)wi >= (unsigned)p.W);
-      offb[e] = (((nbase + (b_plane[e] & 0x7fffffffu) + (unsigned)(hi * p.W + wi)) * 4u) & 0x7fffffffu) | (inv << 31);
+      const int bad = pinv | hi | (Hm1 - hi) | wi | (Wm1 - wi);
+      offb[e] = ((unsigned)(baseb + b_off[e]) & 0x7fffffffu) | ((unsigned)bad & OOB);
     }
 #if !WG_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);

@@ -109,7 +109,7 @@ class deepIM_flownet(object):
         self.get_test_symbol_share(cfg)
         self.is_train = True
         self.nc8 = False          # NCHW activations: what the backward kernels read
-        self.two_streams = True   # backward(): weight gradients on a second stream next to the data gradients (False: one stream)
+        self.two_streams = False  # backward(): weight gradients on a second stream next to the data gradients (False: one stream)
         self.with_mask_head, self.with_flow_head = bool(n.PRED_MASK), bool(n.PRED_FLOW)    # :183, :314
         self.with_decoder = self.with_mask_head or self.with_flow_head
         return self
