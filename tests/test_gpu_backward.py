@@ -370,6 +370,34 @@ def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
     assert np.isfinite(loss2) and loss2 != loss
 
 
+def test_backward_on_two_streams_is_bit_identical(ctx):
+    """backward() with the weight gradients on a second context / stream (deepim_stream_wait orders the two; off by default:
+    measured no faster) gives the same bits as the one-stream order, run after run — with the decoder and both heads."""
+    from mx_deepim_amd.runtime import Context
+    B = 2
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 77, True)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    net.forward_train(data, label)
+    one = {k: v.asnumpy() for k, v in net.backward().items()}
+    net.side = Context(ctx.device_id)          # what bind_train does under net.two_streams = True
+    for _ in range(3):
+        two = net.backward()
+        ctx.sync()
+        for k in sorted(one):
+            np.testing.assert_array_equal(two[k].asnumpy(), one[k], err_msg=k)
+    # the primitive on its own: B queues behind A without the host waiting in between
+    a, b = ctx, net.side
+    x = a.zeros((1 << 22,))
+    for _ in range(20):
+        lib.deepim_axpy(a.handle, x, a.array(np.ones(1 << 22, np.float32)), cf(1.0), x.size)
+    lib.deepim_stream_wait(b.handle, a.handle)
+    y = DeviceArray(b, x.shape)
+    lib.deepim_d2d(b.handle, y, x, x.nbytes)
+    b.sync()
+    np.testing.assert_array_equal(y.asnumpy(), np.full(1 << 22, 20.0, np.float32))
+
+
 DEC_CASES = [(2, 70, 6, 8, 24, 13, 17), (1, 2, 8, 10, 2, 15, 20), (1, 1026, 15, 20, 256, 30, 40)]
 
 
