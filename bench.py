@@ -307,7 +307,34 @@ def main():
     h = ctx.handle
     if args.autotune:
         lib.deepim_set_option(h, b"conv_autotune", 1)
-    comm = parallel.PoseComm(ctx, rdzv) if (world > 1 and backend == "rccl") else None
+    comm, comm_note = None, None
+    if world > 1 and backend == "rccl":
+        # bring RCCL up, prove the all-gather on rank-stamped poses, and let the ranks AGREE on the outcome: if any of them could
+        # not (library missing, init error, wrong bytes back) all of them use the rendezvous exchange and the line says so —
+        # a scaling run that dies in the bootstrap measures nothing
+        err = None
+        try:
+            comm = parallel.PoseComm(ctx, rdzv)
+            probe_in = ctx.array(np.full((1, 3, 4), float(rank), np.float32))
+            probe_out = ctx.zeros((world, 3, 4))
+            comm.all_gather_poses(probe_out, probe_in)
+            got = probe_out.asnumpy()[:, 0, 0]
+            if not np.array_equal(got, np.arange(world, dtype=np.float32)):
+                err = "all-gather returned %s" % got.tolist()
+        except Exception as e:          # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        errs = rdzv.all_gather((err or "").encode())
+        bad = [(r, e.decode(errors="replace")) for r, e in enumerate(errs) if e]
+        if bad:
+            if comm is not None:
+                try:
+                    comm.close()
+                except Exception:       # noqa: BLE001
+                    pass
+            comm = None
+            comm_note = "RCCL unavailable (rank %d: %s) — poses exchanged through the TCP rendezvous instead" % bad[0]
+            if rank == 0:
+                sys.stderr.write("bench: %s\n" % comm_note)
     NIT = args.iters
     if args.global_batch:
         lo, hi = parallel.shard_bounds(args.global_batch, world, rank)
@@ -480,8 +507,9 @@ def main():
                            "closed loop: on-device re-render + mask update between iterations"),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT,
                        "encoder_launch": "hipGraph replay" if use_graph else "direct launches",
-                       "parallelism": "pairs sharded across %d GPU(s), one process per GPU, one ncclAllGather (RCCL) of the "
-                                      "refined poses per iteration on the compute stream, no torch" % world},
+                       "parallelism": ("pairs sharded across %d GPU(s), one process per GPU, one ncclAllGather (RCCL) of the "
+                                       "refined poses per iteration on the compute stream, no torch" % world) if comm_note is None
+                                      else "pairs sharded across %d GPU(s), one process per GPU; %s" % (world, comm_note)},
             "roofline": {"bound": "mfma", "kernel": ("conv_f16_dma_kernel / conv1 patch kernel (fp16 MFMA 32x32x16)" if args.fp16 else "conv_f16_dma_kernel<X3> (conv2-conv6_1: 3 fp16 "
                                                       "MFMAs per product; peak = 2.5 PF / 3) + conv_direct_kernel (conv1, fp32)"
                                                       if args.x3 else "conv_nc8_kernel / conv_direct_kernel") +

@@ -313,11 +313,16 @@ class PoseComm(object):
         if self.world > 1:
             uid = None
             if self.rank == 0:
-                buf = ctypes.create_string_buffer(COMM_ID_BYTES)
-                lib.deepim_comm_unique_id(buf)
-                uid = buf.raw
+                # a failure here (librccl missing, …) must still reach the broadcast, or every other rank waits for the id
+                try:
+                    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+                    lib.deepim_comm_unique_id(buf)
+                    uid = buf.raw
+                except Exception as e:      # noqa: BLE001 — shipped to the peers as text, re-raised below on every rank
+                    uid = ("rank 0 could not make the RCCL id: %s" % e).encode()[:COMM_ID_BYTES - 1]
             uid = rdzv.broadcast(uid, 0)
-            assert isinstance(uid, bytes) and len(uid) == COMM_ID_BYTES
+            if not (isinstance(uid, bytes) and len(uid) == COMM_ID_BYTES):
+                raise RuntimeError(uid.decode(errors="replace") if isinstance(uid, bytes) else "no RCCL id from rank 0")
             lib.deepim_comm_init(ctx.handle, self.rank, self.world, ctypes.create_string_buffer(uid, COMM_ID_BYTES))
 
     def all_gather_poses(self, all_poses, poses):
