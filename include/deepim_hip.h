@@ -521,6 +521,12 @@ int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float* src, int s
  * with the pixels as the reduction dimension; Ho*Wo must be a multiple of 4 */
 int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W, int Cout,
                         int kh, int kw, int stride, int pad);
+/* the weight gradient in TAP-MAJOR layout dw_tm (Cout, kh*kw, Cin) — what the LDS-staged kernel produces fastest (one range
+ * check and one address per eight channels of a tap). Same sums, same order as deepim_conv2d_wgrad; needs Cin % 8 == 0, Cout > 4,
+ * option "wgrad_lds" on. deepim_sgd_mom_update_multi reads it in place; deepim_weight_grad_to_natural gives (Cout,Cin,kh,kw). */
+int deepim_conv2d_wgrad_tm(deepim_ctx* ctx, float* dw_tm, const float* x, const float* dz, int B, int Cin, int H, int W, int Cout,
+                           int kh, int kw, int stride, int pad);
+int deepim_weight_grad_to_natural(deepim_ctx* ctx, float* dw, const float* dw_tm, int Cout, int Cin, int khw);
 /* weight AND bias gradient of a layer (db[c] = sum of dz): one launch for the few-filter layers (Cout <= 4, 3x3 / 4x4: the
  * prediction heads), deepim_bias_grad + deepim_conv2d_wgrad otherwise */
 int deepim_conv2d_wgrad_bias(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
@@ -532,9 +538,10 @@ int deepim_fc_backward(deepim_ctx* ctx, float* dx, float* dw, float* db, const f
 int deepim_sgd_mom_update(deepim_ctx* ctx, float* w, float* mom, const float* g, float lr, float wd, float momentum,
                           float rescale, float clip, size_t n);
 
-/* the same update of every parameter in one launch. table (device): `rows` rows of five 64-bit words {w, mom, g (device
- * addresses), n, (bits of float wd) | (first block of the row << 32)}; a row owns ceil(n/256) blocks, rows in block order,
- * total_blocks = their sum. Results are bit-identical to per-tensor deepim_sgd_mom_update calls. */
+/* the same update of every parameter in one launch. table (device): `rows` rows of six 64-bit words {w, mom, g (device
+ * addresses), n, (bits of float wd) | (first block of the row << 32), layout of g: 0 = like w, else Cin | (kh*kw << 32) = the
+ * tap-major gradient of deepim_conv2d_wgrad_tm}; a row owns ceil(n/256) blocks, rows in block order, total_blocks = their sum.
+ * Results are bit-identical to per-tensor deepim_sgd_mom_update calls on natural gradients. */
 int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long long* table, int rows, int total_blocks, float lr,
                                 float momentum, float rescale, float clip);
 

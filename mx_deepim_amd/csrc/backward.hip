@@ -329,7 +329,12 @@ constexpr int WG_PIX = 16, WG_P = 20;
 #ifndef WG_INTERLEAVE
 #define WG_INTERLEAVE 1   // 1: one iteration is ONE scheduling region and the memory operations are spread over the MFMA slots
 #endif
-template <int BM>
+// TAPM ("tap-major", Cin % 8 == 0): the K rows run (tap, channel) instead of (channel, tap), and a thread's eight im2col rows
+// are ONE tap of eight consecutive channels — one range check and one address per chunk instead of eight (the plane stride goes
+// into the loads' scalar offset), and sixteen fewer registers. An ablation with the per-row range arithmetic removed ran 9 %
+// faster (19 % on conv1): that arithmetic, not memory, was what the waves were short of. The gradient then comes out as
+// dw_tm[co][tap][ci]; whoever reads it (the SGD kernel, deepim_weight_grad_to_natural) applies the permutation.
+template <int BM, bool TAPM = false>
 __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   // 41 KB of LDS per block: three blocks per CU
   constexpr int TM = BM / 64, NA = BM / 64;          // MFMA row tiles per wave; dZ dwordx4 loads per thread and chunk
   __shared__ __attribute__((aligned(16))) float As[2][BM * WG_P];
@@ -364,6 +369,17 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
     b_tap[e] = (ty << 16) | (tx & 0xffff);
   }
   const int Hm1 = p.H - 1, Wm1 = p.W - 1;
+  // TAPM: rows 8 krow0 … 8 krow0 + 7 of the tile = tap tm_tap, channels tm_ci0 … tm_ci0 + 7
+  int tm_ty = 0x4000, tm_tx = 0, tm_off = 0;
+  if (TAPM) {
+    const int k0 = kt * 128 + 8 * krow0;
+    if (k0 < p.K) {
+      const int t = k0 / p.Cin, ci0 = k0 - t * p.Cin;
+      tm_ty = t / p.kw - p.pad; tm_tx = t % p.kw - p.pad;
+      tm_off = (ci0 * p.H * p.W + tm_ty * p.W + tm_tx) * 4;
+    }
+  }
+  const int plane_bytes = p.H * p.W * 4;
   f32x16 acc[TM][2];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -404,10 +420,20 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
     const int hi0 = ho * p.stride, wi0 = wo * p.stride;
     const int baseb = (n * p.Cin * p.H * p.W + hi0 * p.W + wi0) * 4;
     const int pinv = deadm | (HW - 1 - pb);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
+    if (TAPM) {
+      const int hi = hi0 + tm_ty, wi = wi0 + tm_tx;
       const int bad = pinv | hi | (Hm1 - hi) | wi | (Wm1 - wi);
+      offb[0] = ((unsigned)(baseb + tm_off) & 0x7fffffffu) | ((unsigned)bad & OOB);
+    }
+#pragma unroll
+    for (int e = 0; e < (TAPM ? 0 : 8); ++e) {
+      const int hi = hi0 + (b_tap[e] >> 16), wi = wi0 + (int)(short)(b_tap[e] & 0xffff);
+#ifdef WG_ABL   // dev ablation (wrong results at the borders): what the per-tap range arithmetic costs
+      const int bad = pinv;
+      (void)hi; (void)wi;
+#else
+      const int bad = pinv | hi | (Hm1 - hi) | wi | (Wm1 - wi);
+#endif
       offb[e] = ((unsigned)(baseb + b_off[e]) & 0x7fffffffu) | ((unsigned)bad & OOB);
     }
 #if !WG_INTERLEAVE
@@ -416,7 +442,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
 #pragma unroll
     for (int r = 0; r < NA; ++r) ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (int)offa[r], 0, 0));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
+    for (int e = 0; e < 8; ++e)   // TAPM: the channel plane rides in the scalar offset (not range-checked: bit 31 of the vector offset decides)
+      rb[e] = __builtin_bit_cast(float, TAPM ? __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[0], e * plane_bytes, 0)
+                                             : __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)offb[e], 0, 0));
 #if !WG_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -425,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_lds_kernel(WgradParams p) {   //
 #pragma unroll
     for (int r = 0; r < NA; ++r) *reinterpret_cast<f32x4*>(&As[buf][(rowA + 64 * r) * WG_P + qA * 4]) = ra[r];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Bs[buf][(krow0 + 16 * e) * WG_P + pixB] = rb[e];
+    for (int e = 0; e < 8; ++e) Bs[buf][(TAPM ? 8 * krow0 + e : krow0 + 16 * e) * WG_P + pixB] = rb[e];
   };
 
   auto compute = [&](int buf) {
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(256) void sgd_mom_kernel(float* __restrict__ w, flo
   w[i] = w[i] + m;
 }
 
-// every parameter in one launch: row r of the table = {w, mom, g, n, wd bits | first block << 32}; a block finds its row with a
+// every parameter in one launch: row r of the table = {w, mom, g, n, wd bits | first block << 32, Cin | kh*kw << 32 (0: natural g)}; a block finds its row with a
 // ballot over the rows' first blocks
 __global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long long* __restrict__ table, int rows, float lr,
                                                             float momentum, float rescale, float clip) {
@@ -718,11 +746,11 @@ __global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long 
   int r = -1;
   for (int base = 0; base < rows; base += 64) {
     const int idx = base + lane;
-    const bool le = idx < rows && (unsigned)(table[idx * 5 + 4] >> 32) <= b;
+    const bool le = idx < rows && (unsigned)(table[idx * 6 + 4] >> 32) <= b;
     r += __popcll(__ballot(le));
   }
   r = __builtin_amdgcn_readfirstlane(r);
-  const unsigned long long* e = table + r * 5;
+  const unsigned long long* e = table + r * 6;
   float* w = reinterpret_cast<float*>(e[0]);
   float* mom = reinterpret_cast<float*>(e[1]);
   const float* g = reinterpret_cast<const float*>(e[2]);
@@ -730,7 +758,15 @@ __global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long 
   const float wd = __uint_as_float((unsigned)e[4]);
   const size_t i = (size_t)(b - (unsigned)(e[4] >> 32)) * 256 + threadIdx.x;
   if (i >= n) return;
-  float gg = g[i] * rescale;
+  size_t gi = i;
+  const int cin = (int)(unsigned)e[5], khw = (int)(e[5] >> 32);
+  if (cin) {   // the gradient lies tap-major (co, tap, ci): deepim_conv2d_wgrad_tm
+    const int K = cin * khw;
+    const size_t co = i / K;
+    const int rem = (int)(i - co * K), ci = rem / khw, t = rem - ci * khw;
+    gi = co * K + (size_t)t * cin + ci;
+  }
+  float gg = g[gi] * rescale;
   if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
   const float m = momentum * mom[i] - lr * (gg + wd * w[i]);
   mom[i] = m;
@@ -865,7 +901,7 @@ extern "C" int deepim_extract_channels(deepim_ctx* ctx, float* dst, const float*
 }
 
 static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
-                             int Cout, int kh, int kw, int stride, int pad);
+                             int Cout, int kh, int kw, int stride, int pad, bool tap_major = false);
 
 extern "C" int deepim_conv2d_wgrad(deepim_ctx* ctx, float* dw, const float* x, const float* dz, int B, int Cin, int H, int W,
                                    int Cout, int kh, int kw, int stride, int pad) {
@@ -880,8 +916,39 @@ extern "C" int deepim_conv2d_wgrad_bias(deepim_ctx* ctx, float* dw, float* db, c
   return conv2d_wgrad_impl(ctx, dw, db, x, dz, B, Cin, H, W, Cout, kh, kw, stride, pad);
 }
 
+// The weight gradient in TAP-MAJOR layout dw_tm[co][ky*kw + kx][ci] (Cin % 8 == 0, Cout > 4, the LDS-staged kernel): same sums in the
+// same order as deepim_conv2d_wgrad, K rows permuted — see wgrad_lds_kernel<BM, TAPM>.
+extern "C" int deepim_conv2d_wgrad_tm(deepim_ctx* ctx, float* dw_tm, const float* x, const float* dz, int B, int Cin, int H, int W,
+                                      int Cout, int kh, int kw, int stride, int pad) {
+  DI_REQUIRE((Cin & 7) == 0 && Cout > 4 && ctx->wgrad_lds, "conv2d_wgrad_tm: needs Cin % 8 == 0, Cout > 4 and the LDS-staged kernel");
+  return conv2d_wgrad_impl(ctx, dw_tm, nullptr, x, dz, B, Cin, H, W, Cout, kh, kw, stride, pad, true);
+}
+
+namespace {
+// natural (co, ci, tap) ← tap-major (co, tap, ci): thread per natural element (coalesced writes, 4-byte gathers whose neighbours
+// in ci are adjacent)
+__global__ __launch_bounds__(256) void grad_to_natural_kernel(float* __restrict__ nat, const float* __restrict__ tm, int Cin, int khw,
+                                                              long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int K = Cin * khw;
+  const long co = i / K;
+  const int rem = (int)(i - co * K), ci = rem / khw, t = rem - ci * khw;
+  nat[i] = tm[co * K + (long)t * Cin + ci];
+}
+}  // namespace
+
+extern "C" int deepim_weight_grad_to_natural(deepim_ctx* ctx, float* dw, const float* dw_tm, int Cout, int Cin, int khw) {
+  DI_DEVICE(ctx);
+  const long total = (long)Cout * Cin * khw;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(grad_to_natural_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dw, dw_tm, Cin, khw, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
 static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
-                             int Cout, int kh, int kw, int stride, int pad) {
+                             int Cout, int kh, int kw, int stride, int pad, bool tap_major) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   WgradParams p;
@@ -935,12 +1002,17 @@ static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float*
       if (rc) return rc;
       p.partial = (float*)scratch;
     }
-    if (bm == 64) hipLaunchKernelGGL(wgrad_lds_kernel<64>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL(wgrad_lds_kernel<128>, dim3(p.ktiles * p.mtiles * p.S), dim3(256), 0, ctx->stream, p);
+    const dim3 grid(p.ktiles * p.mtiles * p.S);
+    if (tap_major) {
+      if (bm == 64) hipLaunchKernelGGL((wgrad_lds_kernel<64, true>), grid, dim3(256), 0, ctx->stream, p);
+      else hipLaunchKernelGGL((wgrad_lds_kernel<128, true>), grid, dim3(256), 0, ctx->stream, p);
+    } else if (bm == 64) hipLaunchKernelGGL(wgrad_lds_kernel<64>, grid, dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(wgrad_lds_kernel<128>, grid, dim3(256), 0, ctx->stream, p);
     if (p.S > 1) launch_wgrad_reduce(ctx, dw, p.partial, n_dw, p.S);
     DI_LAUNCH_CHECK();
     return 0;
   }
+  DI_REQUIRE(!tap_major, "conv2d_wgrad_tm: tensors of 2 GiB and more take the register-fed kernel, which has no tap-major order");
   const long groups = (long)B * ((HW + 7) >> 3);
   // enough pixel slices to fill the chip (~1024 blocks), each at least 64 groups (512 pixels) long; fixed by the geometry
   long S = di_div_up(1024, p.ktiles * p.mtiles);

@@ -73,6 +73,29 @@ class _Activations(dict):
         return dict.__getitem__(self, key)
 
 
+class _Grads(dict):
+    """name → gradient in the parameter's own layout. The conv / deconv weight gradients that the LDS-staged kernel leaves
+    tap-major (`tm`: name → (raw (Cout,kh*kw,Cin) buffer, Cout, Cin, kh*kw), deepim_conv2d_wgrad_tm) are permuted into the stored
+    natural buffer when somebody asks for them; the SGD kernel reads the raw buffers in place, so a training step never does."""
+
+    def __init__(self, ctx, *a, **kw):
+        super().__init__(*a, **kw)
+        self._ctx, self.tm = ctx, {}
+
+    def __getitem__(self, name):
+        out = dict.__getitem__(self, name)
+        if name in self.tm:
+            raw, cout, cin, khw = self.tm[name]
+            lib.deepim_weight_grad_to_natural(self._ctx.handle, out, raw, cout, cin, khw)
+        return out
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+    def values(self):
+        return [self[k] for k in self]
+
+
 class deepIM_flownet(object):
     def __init__(self):
         self.cfg = None
@@ -572,7 +595,12 @@ def _train_methods():
         w7, dw7, db7 = ctx.empty((7, 256)), ctx.zeros((7, 256)), ctx.zeros((7,))
         w7[0:4].copyfrom(self.params["rot_weight"]); w7[4:7].copyfrom(self.params["trans_weight"])
         self.params["rot_weight"], self.params["trans_weight"] = w7[0:4], w7[4:7]
-        self.grad = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
+        self.grad = _Grads(ctx, {name: ctx.zeros(a.shape) for name, a in self.params.items()})
+        for gname, cin, _h, _w, cout, k, _s, _p in self.enc_geom:       # conv layers: (Cout, Cin, k, k)
+            self.grad.tm[gname + "_weight"] = (ctx.zeros((cout, k * k, cin)), cout, cin, k * k)
+        if self.with_decoder:                                            # deconvs: MXNet (cin, cout, 4, 4) = filters cin, channels cout
+            for gname, cin, cout in (("deconv4", 1026, 256), ("deconv5", 1024, 512)):
+                self.grad.tm[gname + "_weight"] = (ctx.zeros((cin, 16, cout)), cin, cout, 16)
         self.grad["rot_weight"], self.grad["trans_weight"] = dw7[0:4], dw7[4:7]
         self.grad["rot_bias"], self.grad["trans_bias"] = db7[0:4], db7[4:7]
         self.mom = {name: ctx.zeros(a.shape) for name, a in self.params.items()}
@@ -711,7 +739,10 @@ def _train_methods():
         hf, wf = 2 * hh + 2, 2 * ww + 2
         lib.deepim_slice_lrelu_bias_scatter(h, self.ws["dil"], self.grad[name + "_bias"], dcat, ycat, B, ctotal, coff, cout, ho, wo,
                                             hf, wf, 1, 1, ctypes.c_float(SLOPE))
-        lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
+        if name + "_weight" in self.grad.tm:
+            lib.deepim_conv2d_wgrad_tm(h, self.grad.tm[name + "_weight"][0], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
+        else:
+            lib.deepim_conv2d_wgrad(h, self.grad[name + "_weight"], self.ws["dil"], x, B, cout, hf, wf, cin, 4, 4, 2, 0)
         order = lib.load().deepim_conv_weight_order(h, B, cout, hf, wf, cin, 4, 4, 2, 0)         # packed for this one use
         lib.deepim_conv_pack_weights_ex(h, self.ws["wt_packed"], self.params[name + "_weight"], cin, cout, 4, 4, order)
         lib.deepim_conv2d_forward(h, dx, self.ws["dil"], self.ws["wt_packed"], None, B, cout, hf, wf, cin, 4, 4, 2, 0,
@@ -787,7 +818,7 @@ def _train_methods():
             lib.deepim_stream_wait(h, side)      # weight gradient of layer li+1 done: gb may be overwritten
             lib.deepim_stream_wait(side, h)      # dz of this layer ready
             src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
-            lib.deepim_conv2d_wgrad(side, G[name + "_weight"], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)
+            lib.deepim_conv2d_wgrad_tm(side, G.tm[name + "_weight"][0], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)   # tap-major: _Grads
             if li > 0:
                 self._dgrad(gb, ga, P[name + "_weight"], B, cin_, hh_, ww_, cout_, k_, s_, p_, ho_, wo_)
             ga, gb = gb, ga
@@ -803,16 +834,21 @@ def _train_methods():
         c = ctypes.c_float
         tab = getattr(self, "_sgd_table", None)
         if tab is None or tab[0] != float(wd):
-            # one launch for all parameters: rows {w, mom, g, n, wd bits | first block << 32} (deepim_sgd_mom_update_multi)
+            # one launch for all parameters: rows {w, mom, g, n, wd bits | first block << 32, layout of g} (deepim_sgd_mom_update_multi)
             rows, block = [], 0
             for name, w in self.params.items():
                 if name.endswith("upsampling_weight"):
                     continue
                 wd_n = wd if name.endswith("_weight") else 0.0
                 wd_bits = int(np.array([wd_n], np.float32).view(np.uint32)[0])
-                rows.append([w.ptr, self.mom[name].ptr, self.grad[name].ptr, w.size, wd_bits | (block << 32)])
+                if name in self.grad.tm:       # tap-major gradient, read in place: layout word = Cin | kh*kw << 32
+                    raw, _co, cin_l, khw = self.grad.tm[name]
+                    g_ptr, layout = raw.ptr, cin_l | (khw << 32)
+                else:
+                    g_ptr, layout = dict.__getitem__(self.grad, name).ptr, 0
+                rows.append([w.ptr, self.mom[name].ptr, g_ptr, w.size, wd_bits | (block << 32), layout])
                 block += (w.size + 255) // 256
-            dev = self.ctx.empty((len(rows), 5), np.uint64)
+            dev = self.ctx.empty((len(rows), 6), np.uint64)
             dev.copyfrom(np.array(rows, dtype=np.uint64))
             tab = self._sgd_table = (float(wd), dev, len(rows), block)
         lib.deepim_sgd_mom_update_multi(h, tab[1], tab[2], tab[3], c(lr), c(momentum), c(rescale_grad), c(clip_gradient or 0.0))

@@ -217,6 +217,41 @@ def test_wgrad_lds_kernel_vs_register_fed_kernel(ctx, case):
     close(res[1], res[0].astype(np.float64), 1e-5)
 
 
+@pytest.mark.parametrize("case", [c for c in WG_CASES if c[1] % 8 == 0 and c[4] > 4] +
+                         [(4, 64, 60, 80, 128, 5, 2, 2), (2, 512, 15, 20, 1024, 3, 2, 1), (1, 8, 480, 640, 64, 7, 2, 3), (2, 256, 32, 42, 1026, 4, 2, 0)])
+def test_tap_major_wgrad_is_the_natural_one_permuted(ctx, case):
+    """deepim_conv2d_wgrad_tm: (Cout, kh*kw, Cin) layout, bit-identical to deepim_conv2d_wgrad after the permutation (same pixel
+    chunks, same slices, same order — only the K rows move); deepim_weight_grad_to_natural and the SGD kernel's layout word
+    both apply that permutation."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case) + 33)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dz_h = rng.standard_normal((B, cout, ho, wo)).astype(np.float32)
+    h = ctx.handle
+    xd, dz = ctx.array(x), ctx.array(dz_h)
+    nat = ctx.empty((cout, cin, k, k))
+    lib.deepim_conv2d_wgrad(h, nat, xd, dz, B, cin, H, W, cout, k, k, s, p)
+    tm = ctx.empty((cout, k * k, cin))
+    lib.deepim_conv2d_wgrad_tm(h, tm, xd, dz, B, cin, H, W, cout, k, k, s, p)
+    want = nat.asnumpy()
+    np.testing.assert_array_equal(tm.asnumpy(), want.reshape(cout, cin, k * k).transpose(0, 2, 1))
+    back = ctx.empty((cout, cin, k, k))
+    lib.deepim_weight_grad_to_natural(h, back, tm, cout, cin, k * k)
+    np.testing.assert_array_equal(back.asnumpy(), want)
+    # SGD on the tap-major gradient in place == SGD on the natural one
+    w0 = rng.standard_normal(want.shape).astype(np.float32)
+    res = []
+    for g, layout in ((nat, 0), (tm, cin | ((k * k) << 32))):
+        w, m = ctx.array(w0), ctx.zeros(want.shape)
+        tab = ctx.empty((1, 6), np.uint64)
+        tab.copyfrom(np.array([[w.ptr, m.ptr, g.ptr, w.size, int(np.array([5e-4], np.float32).view(np.uint32)[0]), layout]], dtype=np.uint64))
+        lib.deepim_sgd_mom_update_multi(h, tab, 1, (w.size + 255) // 256, cf(1e-3), cf(0.975), cf(1.0), cf(0.0))
+        res.append((w.asnumpy(), m.asnumpy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("case", [(4, 770, 30, 40, 2, 3, 1, 1), (2, 6, 30, 40, 1, 3, 1, 1), (3, 9, 10, 12, 4, 3, 1, 1), (2, 24, 16, 20, 136, 3, 1, 1)])
 def test_wgrad_with_bias_in_one_call(ctx, case):
     """deepim_conv2d_wgrad_bias = deepim_conv2d_wgrad + the bias gradient (in the same launch for the few-filter layers)."""
@@ -298,9 +333,9 @@ def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
         w, m = [ctx.array(a) for a in W], [ctx.array(a) for a in M]
         rows, block = [], 0
         for i, n in enumerate(sizes):
-            rows.append([w[i].ptr, m[i].ptr, g[i].ptr, n, int(np.array([wds[i]], np.float32).view(np.uint32)[0]) | (block << 32)])
+            rows.append([w[i].ptr, m[i].ptr, g[i].ptr, n, int(np.array([wds[i]], np.float32).view(np.uint32)[0]) | (block << 32), 0])
             block += (n + 255) // 256
-        tab = ctx.empty((len(rows), 5), np.uint64)
+        tab = ctx.empty((len(rows), 6), np.uint64)
         tab.copyfrom(np.array(rows, dtype=np.uint64))
         lib.deepim_sgd_mom_update_multi(h, tab, len(rows), block, cf(1e-3), cf(0.975), cf(0.5), cf(clip))
         for i in range(len(sizes)):

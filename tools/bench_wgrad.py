@@ -36,9 +36,10 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
         lib.deepim_set_option(h, b"wgrad_lds", mode)
         res[mode] = timeit(lambda: lib.deepim_conv2d_wgrad(h, dw, x, dz, B, cin, hh, ww, cout, k, k, s, p))
     lib.deepim_set_option(h, b"wgrad_lds", 1)
-    line = "%-8s Cin %4d %3dx%3d Cout %4d k%d s%d | wgrad LDS %.3f ms %5.1f TF | reg-fed %.3f ms %5.1f TF" % (
-        name, cin, hh, ww, cout, k, s, res[1], fl / res[1] / 1e9, res[0], fl / res[0] / 1e9)
-    tot["wg1"] += res[1]; tot["wg0"] += res[0]
+    res[2] = timeit(lambda: lib.deepim_conv2d_wgrad_tm(h, dw, x, dz, B, cin, hh, ww, cout, k, k, s, p))   # tap-major rows (the graph's)
+    line = "%-8s Cin %4d %3dx%3d Cout %4d k%d s%d | wgrad tap-major %.3f ms %5.1f TF | LDS %.3f ms %5.1f TF | reg-fed %.3f ms %5.1f TF" % (
+        name, cin, hh, ww, cout, k, s, res[2], fl / res[2] / 1e9, res[1], fl / res[1] / 1e9, res[0], fl / res[0] / 1e9)
+    tot["wg1"] += res[1]; tot["wg0"] += res[0]; tot["wg2"] = tot.get("wg2", 0.0) + res[2]
     if li > 0:
         dx = ctx.empty((B, cin, hh, ww))
         wt = ctx.empty((cin * cout * k * k,))
@@ -61,4 +62,4 @@ for li, (name, cout, k, s, p) in enumerate(ENCODER):
             lib.deepim_set_option(h, b"dgrad_group", 1)
     print(line)
     hh, ww, cin = ho, wo, cout
-print("totals B=%d: wgrad LDS %.2f ms, reg-fed %.2f ms, dgrad %.2f ms" % (B, tot["wg1"], tot["wg0"], tot["dg"]))
+print("totals B=%d: wgrad tap-major %.2f ms, LDS %.2f ms, reg-fed %.2f ms, dgrad %.2f ms" % (B, tot["wg2"], tot["wg1"], tot["wg0"], tot["dg"]))
