@@ -501,11 +501,23 @@ class deepIM_flownet(object):
         lib.deepim_relayout_nc8(self.ctx.handle, out, a, a.shape[0], a.shape[1], a.shape[2] * a.shape[3], 0)
         return out
 
+    FC6_PLAIN_MAX_BATCH = 4   # measured (tools/bench_fc6.py): B = 1 / 4 / 32 → plain 20 / 24 / 79 µs, packed MFMA 31 / 31 / 32 µs
+
+    def _fc6(self, flat):
+        """fc6 (81920 → 256): up to FC6_PLAIN_MAX_BATCH pairs the plain kernel streams the raw weights once faster than the MFMA
+        kernel runs on the packed ones (and a training step then needs no 38 µs re-pack of 84 MB); larger batches take the packed
+        MFMA path. Fixed by the batch size, so every rank and run sums in the same order."""
+        A, P, h, B = self.act, self.params, self.ctx.handle, self.B
+        if B <= self.FC6_PLAIN_MAX_BATCH:
+            lib.deepim_fc_forward(h, A["fc6"], flat, P["fc6_weight"], P["fc6_bias"], B, flat.shape[1], 256, ctypes.c_float(SLOPE))
+        else:
+            lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256,
+                                         ctypes.c_float(SLOPE))
+
     def pose_head(self):
         A, P, h, B = self.act, self.params, self.ctx.handle, self.B
         flat = A["conv6_1"].reshape((B, -1))
-        lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256,
-                                     ctypes.c_float(SLOPE))
+        self._fc6(flat)
         lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256,
                               ctypes.c_float(SLOPE))
         lib.deepim_pose_head_forward(h, A["se3"], A["fc7"], P["rot_weight"], P["rot_bias"], P["trans_weight"],
@@ -683,7 +695,7 @@ def _train_methods():
             lib.deepim_mask_logistic(h, A["mask_prob"], self.ws["d_mask_hi"], A["mask_logits"], A["zoom_mask_gt_observed"],
                                      c(t.LW_MASK / (H * W)), B * H * W)
         flat = A["conv6_1"].reshape((B, -1))
-        lib.deepim_fc_forward_packed(h, A["fc6"], flat, self.packed["fc6"], P["fc6_bias"], B, flat.shape[1], 256, c(SLOPE))
+        self._fc6(flat)
         lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256, c(SLOPE))
         lib.deepim_fc_forward(h, A["rot"], A["fc7"], P["rot_weight"], P["rot_bias"], B, 256, 4, c(1.0))
         lib.deepim_fc_forward(h, A["zoom_trans"], A["fc7"], P["trans_weight"], P["trans_bias"], B, 256, 3, c(1.0))
@@ -862,7 +874,8 @@ def _train_methods():
             else:
                 lib.deepim_conv_pack_weights_ex(h, self.packed[base], self.params[name], shape[0], shape[1], shape[2], shape[3],
                                                 orders.get(base, 3))
-        lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
+        if self.B > self.FC6_PLAIN_MAX_BATCH:      # small batches read fc6's raw weights (_fc6)
+            lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
 
     def _train_pack_orders(self):
         """layer → the ONE packed operand order its forward convolution reads in the training graph (NCHW activations,
