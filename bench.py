@@ -277,6 +277,8 @@ def main():
                     "second passes + layout passes) from one captured hipGraph instead of issuing them one by one. Measured "
                     "(profiles/r03_fp16_config5.md): no gain at B = 8 / B = 4 — the kernel trace shows no idle gaps between the "
                     "encoder's launches, the queue stays ahead of the GPU — so direct launches stay the default")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="dev: deepim_set_option on the context "
+                    "before anything runs (labelled in the line)")
     ap.add_argument("--dry-run", action="store_true", help="launch rehearsal without a GPU: the same rank / rendezvous / shard / "
                     "per-iteration pose all-gather (host backend) / max-over-ranks / one-JSON-line-from-rank-0 code path with a "
                     "host stand-in for the refinement step; the line carries \"dry_run\": true and no roofline")
@@ -307,6 +309,9 @@ def main():
     h = ctx.handle
     if args.autotune:
         lib.deepim_set_option(h, b"conv_autotune", 1)
+    for o in args.opt:
+        name, _, val = o.partition("=")
+        lib.deepim_set_option(h, name.encode(), int(val))
     comm, comm_note = None, None
     if world > 1 and backend == "rccl":
         # bring RCCL up, prove the all-gather on rank-stamped poses, and let the ranks AGREE on the outcome: if any of them could
