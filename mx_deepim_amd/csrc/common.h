@@ -52,7 +52,6 @@ struct deepim_ctx {
   int conv_autotune;  // 1: time split-K candidates on the first call of a geometry (default 0: deterministic cost-model plan)
   int conv_max_split;  // 0 auto, 1 off, n cap
   int conv_xcd_swizzle;  // 1: XCD-aware tile order (default), 0: plain
-  int conv_stagger;      // dev (default 0): start-up stagger of the co-resident conv blocks, see ConvParams::stagger
   int dgrad_group;       // 1 (default): the four parity classes of a stride-2 data gradient share one launch; 0: class by class
   int wgrad_lds;         // 1 (default): LDS-staged weight-gradient kernel; 0: the round-2 register-fed kernel (A/B measurements)
   int f16_dev_flags;     // dev: DI_F16_* bits — alternative tilings of the fp16 / x3 conv kernels (default 0)

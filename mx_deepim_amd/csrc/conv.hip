@@ -79,7 +79,6 @@ struct ConvParams {
   float* partial;           // [ksplit][B][Cout][Ho][Wo] raw partial sums when ksplit > 1
   long partial_stride;
   int swizzle;              // XCD-aware tile order on/off
-  int stagger;              // dev: first-round blocks of resident slot k (block / 256 % 3) sleep k x stagger x ~3.4 µs before starting
   int gx, gy, gz;           // logical grid (pixel tiles, M tiles, classes*ksplit); launched 1-D and XCD-swizzled
   int pad_bytes;            // buffer-descriptor base shift: (pad*W + pad)*4 so tap origins are >= 0
   unsigned in_bytes;        // size of the input tensor (must stay < 2 GiB: 0x80000000 is the OOB marker)
@@ -494,10 +493,6 @@ __device__ __forceinline__ void conv_direct_body(const ConvParams& p, const int 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = WMW == 2 ? (wave >> 1) * 64 : 0, wn0 = WMW == 2 ? (wave & 1) * 64 : wave * 64;
-  if (p.stagger && blockIdx.x < 768) {   // dev experiment: take the co-resident blocks of a CU out of lockstep
-    const int slot = (blockIdx.x >> 8) % 3;
-    for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   int vid, split, tail_item = -1;
   if (p.tail_s > 0) {
     // every XCD (block b → XCD b % 8) first walks its eighth of the full tiles, then its eighth of the tail items,
@@ -763,10 +758,6 @@ __global__ __launch_bounds__(256, NC8_OCC) void conv_nc8_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = WIDE ? 0 : (wave >> 1) * 64, wn0 = WIDE ? wave * 64 : (wave & 1) * 64;
-  if (p.stagger && blockIdx.x < 768) {   // dev experiment: take the co-resident blocks of a CU out of lockstep
-    const int slot = (blockIdx.x >> 8) % 3;
-    for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   int vid;
   {
     const int total = p.gx * p.gy * p.gz, bid = blockIdx.x;
@@ -1341,7 +1332,7 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     if (rc) return rc;
     p.partial = (float*)scratch;
   }
-  p.swizzle = ctx->conv_xcd_swizzle; p.stagger = ctx->conv_stagger;
+  p.swizzle = ctx->conv_xcd_swizzle;
   p.gx = di_div_up(p.npix, t.bn); p.gy = di_div_up(p.Cout, t.bm); p.gz = classes * p.ksplit;
   p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
   const bool direct_ok = MODE == MODE_CONV && t.bm == 128 && t.bn == 128 && p.tab2 != nullptr;
@@ -1769,7 +1760,7 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     p.wd = packed_ws + slot[ord[m]] + half; p.wd_bytes = (unsigned)(half * sizeof(float));
     p.in_nc8 = 0; p.out_nc8 = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
     p.ep_y = ag ? ag->y : nullptr; p.ep_add = ag ? ag->add : nullptr; p.ep_slope = ag ? ag->slope : 1.f;
-    p.swizzle = ctx->conv_xcd_swizzle; p.stagger = 0;
+    p.swizzle = ctx->conv_xcd_swizzle;
     p.gx = di_div_up(p.npix, bn); p.gy = di_div_up(Ci_l, bm);
     p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
     tiles[m] = (long)p.gx * p.gy;

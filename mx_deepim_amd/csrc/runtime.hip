@@ -34,7 +34,6 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->comm_world = 1;
   c->conv_max_split = 0;
   c->conv_xcd_swizzle = 1;
-  c->conv_stagger = 0;
   c->f16_dev_flags = 0;
   c->wgrad_lds = 1;
   c->dgrad_group = 1;
@@ -180,7 +179,6 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "dgrad_group") == 0) { ctx->dgrad_group = value ? 1 : 0; return 0; }
   if (strcmp(name, "wgrad_lds") == 0) { ctx->wgrad_lds = value ? 1 : 0; return 0; }
   if (strcmp(name, "f16_dev_flags") == 0) { DI_REQUIRE(value >= 0 && value < 16, "f16_dev_flags: bits 0..3"); ctx->f16_dev_flags = value; return 0; }
-  if (strcmp(name, "conv_stagger") == 0) { DI_REQUIRE(value >= 0 && value <= 64, "conv_stagger: 0..64"); ctx->conv_stagger = value; return 0; }
   if (strcmp(name, "conv_xcd_swizzle") == 0) {
     ctx->conv_xcd_swizzle = value ? 1 : 0;
     return 0;
