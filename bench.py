@@ -584,7 +584,8 @@ def other_configs(left=lambda: 1e9):
     """Short secondary runs (separate processes, after the timed region of the headline) of the other BASELINE.json
     configurations on this GPU, so that they are measured by the same driver command: configs[1] (batch 16), the per-GPU share
     of configs[2] (batch 4), configs[3] (decoder + mask / flow heads in every iteration) and configs[4] AS WRITTEN (RGB-D pairs,
-    INPUT_DEPTH, fp16 conv path) at its per-GPU share (batch 8) and at batch 32. Each entry: value (it/s), ms_per_step,
+    INPUT_DEPTH, fp16 conv path) at its per-GPU share (batch 8) and at batch 32, and the training-style iteration of SURVEY 8f-4
+    (forward + backward + SGD step at batch 4, with and without the decoder and heads: `training_iteration_*`). Each entry: value (it/s), ms_per_step,
     conv-stack TFLOP/s and its fraction of the peak, and — where the run carries one — its own `parity` block.
     `left()` = seconds of the extras budget still available; runs that no longer fit are reported as skipped."""
     import subprocess
@@ -598,7 +599,23 @@ def other_configs(left=lambda: 1e9):
             ("split_fp16_x3_conv_batch4", ["--x3", "--batch", "4", "--verify", "0"]),
             ("configs[3]_heads_split_fp16_x3_batch32", ["--x3", "--heads", "--verify", "0"])]
     res = {}
+
+    def training():
+        # SURVEY 8f-4 (module.backward + sgd of the reference's training loop) at the per-GPU share of config 4, tools/bench_train.py
+        for name, extra in (("training_iteration_heads_batch4", ["4", "heads", "json"]), ("training_iteration_pose_branch_batch4", ["4", "json"])):
+            if left() < 30:
+                res[name] = {"skipped": "extras budget spent"}
+                continue
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py")] + extra, capture_output=True, text=True,
+                                   timeout=max(30.0, min(120.0, left())))
+                res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:      # noqa: BLE001
+                res[name] = {"error": repr(e)[:200]}
+
     for name, extra in runs:
+        if name.startswith("configs[4]") and "training_iteration_heads_batch4" not in res:
+            training()
         if left() < 30:
             res[name] = {"skipped": "extras budget spent"}
             continue

@@ -1,5 +1,6 @@
 """Dev probe: time one training-style iteration (forward_train + backward + update) and its pieces.
-usage: bench_train.py [B] [heads]   — `heads` adds the refinement decoder with the flow and mask losses."""
+usage: bench_train.py [B] [heads] [json]   — `heads` adds the refinement decoder with the flow and mask losses; `json` prints one
+JSON line instead of the sentence (bench.py's other_configs["training_iteration_*"])."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,7 @@ from mx_deepim_amd.symbols import deepIM_flownet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ctx = Context.get(0)
 d = synthetic.make_batch(B, seed=910, n_frames=1)
-HEADS = len(sys.argv) > 2 and sys.argv[2] == "heads"
+HEADS = "heads" in sys.argv[2:]
 cfg = default_config(); cfg.network.PRED_FLOW = cfg.network.PRED_MASK = HEADS
 net = deepIM_flownet().get_symbol(cfg, is_train=True)
 net.bind_train(ctx, B, net.init_weights(cfg, seed=91))
@@ -37,5 +38,14 @@ for _ in range(N):
     for i in range(3): acc[i] += ts[i].elapsed_ms()
 fwd, bwd, upd = (a / N for a in acc)
 gf = 38.834e9 * B
+if "json" in sys.argv[2:]:
+    import json
+    print(json.dumps({"value": 1e3 / (fwd + bwd + upd), "unit": "training iterations/s (forward + backward + SGD step, batch %d)" % B,
+                      "forward_ms": fwd, "backward_ms": bwd, "update_repack_ms": upd, "pairs_per_s": B * 1e3 / (fwd + bwd + upd),
+                      "backward_tflops_on_ideal_flops": 2 * gf / bwd / 1e9, "dtype": "f32",
+                      "workload": "SURVEY 8f-4: one training-style iteration, %s, 480x640, synthetic pairs" % (
+                          "full graph: encoder + refinement decoder + flow and mask heads + point-matching loss" if HEADS else
+                          "pose branch: encoder + fc + point-matching loss")}))
+    sys.exit(0)
 print(("heads " if HEADS else "pose ") + "B=%d: forward %.2f ms (%.0f TF), backward %.2f ms (%.0f TF on 2x forward FLOPs), update+repack %.2f ms; %.1f training iterations/s (pairs/s %.0f)"
       % (B, fwd, gf / fwd / 1e9, bwd, 2 * gf / bwd / 1e9, upd, 1e3 / (fwd + bwd + upd), B * 1e3 / (fwd + bwd + upd)))
