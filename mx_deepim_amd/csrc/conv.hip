@@ -927,7 +927,10 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
                                                           const float* __restrict__ wp, const float* __restrict__ bias,
                                                           int Cin, int H, int W, int Ho, int Wo, int kh, int kw,
                                                           int stride, int pad, long npix, int out_ctotal, int out_coff,
-                                                          float slope) {
+                                                          float slope, float* __restrict__ partial, int cslice) {
+  // few pixels (B = 4 heads: 75 … 5 blocks of 64 pixels for 256 CUs, each wave walking 48-64 channels one after the other —
+  // 60 µs for 0.13 GFLOP): gridDim.y slices of `cslice` input channels each, raw sums to partial[slice][n][co][hw], bias +
+  // activation in splitk_reduce_kernel
   constexpr int NW = 16;   // waves per block = channel shares
   __shared__ float part[NW - 1][COUT][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -938,8 +941,9 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
   const int r = live ? (int)(pix - n * hw) : 0;
   const int ho = r / Wo, wo = r - ho * Wo;
   const int hi0 = ho * stride - pad, wi0 = wo * stride - pad;
-  const int cq = (Cin + NW - 1) / NW;
-  const int c_lo = min(Cin, wave * cq), c_hi = min(Cin, c_lo + cq);
+  const int s_lo = blockIdx.y * cslice, s_hi = min(Cin, s_lo + cslice);
+  const int cq = (s_hi - s_lo + NW - 1) / NW;
+  const int c_lo = min(s_hi, s_lo + wave * cq), c_hi = min(s_hi, c_lo + cq);
   float acc[COUT];
 #pragma unroll
   for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
@@ -998,6 +1002,10 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
       float v = acc[co];
 #pragma unroll
       for (int q = 0; q < NW - 1; ++q) v += part[q][co][lane];
+      if (partial) {
+        partial[((long)blockIdx.y * (npix / hw) * COUT + n * COUT + co) * hw + r] = v;
+        continue;
+      }
       v = v + (bias ? bias[co] : 0.f);
       v = v > 0.f ? v : v * slope;
       out[(n * out_ctotal + out_coff + co) * hw + r] = v;
@@ -1919,16 +1927,34 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
     return launch_conv<MODE_CONV>(ctx, p, 1);
   }
   if (Cout <= 4 && ctx->conv_max_split != 1 && p.out_nc8 == 0) {   // heads: a stream over the input, not an MFMA problem
-    const dim3 grid(di_div_up(p.npix, 64));
+    // channel slices when the pixels alone leave the chip empty: ~512 blocks, slices of at least 32 channels (fixed by the geometry)
+    const int nblk = di_div_up(p.npix, 64);
+    int S = max(1, min(min(512 / nblk, Cin / 32), 16));
+    const int cslice = di_div_up(Cin, S);
+    S = di_div_up(Cin, cslice);
+    float* partial = nullptr;
+    const long total = (long)B * Cout * p.Ho * p.Wo;
+    if (S > 1) {
+      void* scratch;
+      rc = deepim_scratch(ctx, (size_t)S * total * sizeof(float), &scratch);
+      if (rc) return rc;
+      partial = (float*)scratch;
+    }
+    const dim3 grid(nblk, S);
 #define DI_FEWOUT(C, KS)                                                                                               \
   hipLaunchKernelGGL((conv_fewout_kernel<C, KS>), grid, dim3(1024), 0, ctx->stream, out, in, packed_w, bias, Cin, H, W, p.Ho, \
-                     p.Wo, kh, kw, stride, pad, p.npix, p.out_ctotal, out_coff, slope)
+                     p.Wo, kh, kw, stride, pad, p.npix, p.out_ctotal, out_coff, slope, partial, cslice)
     const bool k3 = kh == 3 && kw == 3;   // the heads are all 3x3; other sizes take the generic loop
     if (Cout == 1) { if (k3) DI_FEWOUT(1, 3); else DI_FEWOUT(1, 0); }
     else if (Cout == 2) { if (k3) DI_FEWOUT(2, 3); else DI_FEWOUT(2, 0); }
     else if (Cout == 3) { if (k3) DI_FEWOUT(3, 3); else DI_FEWOUT(3, 0); }
     else { if (k3) DI_FEWOUT(4, 3); else DI_FEWOUT(4, 0); }
 #undef DI_FEWOUT
+    if (S > 1) {
+      Remap none = {};
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out, partial, bias, total, total,
+                         S, Cout, p.Ho * p.Wo, p.out_ctotal, out_coff, slope, none, (const float*)nullptr, (const float*)nullptr, 1.f);
+    }
     DI_LAUNCH_CHECK();
     return 0;
   }

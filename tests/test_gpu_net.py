@@ -307,10 +307,12 @@ def test_conv_tail_split_plan(ctx):
 
 
 @pytest.mark.parametrize("case", [(2, 770, 30, 40, 2, 3, 1, 1), (1, 1026, 15, 20, 2, 3, 1, 1), (3, 37, 19, 23, 3, 5, 2, 2),
-                                  (2, 5, 9, 70, 4, 7, 1, 3), (1, 3, 8, 8, 1, 1, 1, 0)])
+                                  (2, 5, 9, 70, 4, 7, 1, 3), (1, 3, 8, 8, 1, 1, 1, 0), (16, 64, 30, 40, 2, 3, 1, 1), (4, 1024, 8, 10, 2, 3, 1, 1)])
 def test_conv_few_output_channels(ctx, case):
     """Cout <= 4 (flow / mask heads) runs on the VALU streaming kernel by default: sixteen (ci,ky,kx)-ordered chains over
-    channel shares, added in order — within fp32 re-association distance of the canonical chain; writes into a channel slice too."""
+    channel shares, added in order (and, when the pixels alone would leave the chip empty, up to sixteen channel slices over
+    grid.y with a fixed-order second pass) — within fp32 re-association distance of the canonical chain; writes into a channel
+    slice too."""
     B, cin, H, W, cout, k, s, p = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
