@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: Prop string-kwarg parsing, shape inference, op registry,
 pair sharding and the world_size-2 gloo all-gather of refined poses."""
 import os
+import types
 
 import numpy as np
 import pytest
@@ -106,6 +107,52 @@ def test_rendezvous_all_gather_world2(counts):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _FailingLib(object):
+    """Stands in for the C library: rank 0 cannot make the RCCL id (librccl missing, …)."""
+
+    def deepim_comm_unique_id(self, buf):
+        raise RuntimeError("librccl.so: cannot open shared object file")
+
+    def deepim_comm_init(self, *a):
+        raise AssertionError("must not be reached: nobody got an id")
+
+
+def _posecomm_worker(rank, port, q):
+    try:
+        import mx_deepim_amd.runtime as rt
+        rt.lib = _FailingLib()                       # PoseComm imports `lib` from the runtime module at construction
+        rd = parallel.Rendezvous(rank, 2, "127.0.0.1", port)
+        try:
+            parallel.PoseComm(types.SimpleNamespace(handle=None), rd)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            errs = rd.all_gather(str(e).encode())    # what bench.py does next: the ranks agree on the verdict
+            q.put((rank, [x.decode() for x in errs]))
+        rd.close()
+    except Exception as e:   # surface the failure instead of a queue timeout
+        q.put((rank, repr(e)))
+
+
+def test_rccl_id_failure_on_rank0_reaches_every_rank():
+    """Rank 0's failure to make the RCCL id travels to the peers in the id's place: every rank raises the same RuntimeError
+    (nobody waits for an id that never comes, nobody enters the collective init) and the rendezvous stays usable for the
+    fallback exchange."""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctxm.Process(target=_posecomm_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        assert isinstance(res[r], list) and len(res[r]) == 2, res
+        assert all("librccl.so" in m for m in res[r]), res
 
 
 def test_rendezvous_single_rank_is_a_no_op():
