@@ -131,10 +131,7 @@ class deepIM_flownet(object):
             raise NotImplementedError("training graph runs the fp32 convolutions only (network.FP16_CONV / X3_CONV unset)")
         self.get_test_symbol_share(cfg)
         self.is_train = True
-        # forward convolutions on the channel-blocked (NC8) kernels of the inference path — 15-20 % faster than the NCHW ones at
-        # small batch; the backward kernels read NCHW, so forward_train converts every activation once (one streaming pass each,
-        # ≈0.1 ms at B = 4 against ≈0.3 ms saved). False: NCHW kernels throughout (round 2 / early round 3).
-        self.nc8 = True
+        self.nc8 = False          # NCHW activations: what the backward kernels read
         self.two_streams = False  # backward(): weight gradients on a second stream next to the data gradients (False: one stream)
         self.with_mask_head, self.with_flow_head = bool(n.PRED_MASK), bool(n.PRED_FLOW)    # :183, :314
         self.with_decoder = self.with_mask_head or self.with_flow_head
@@ -676,8 +673,6 @@ def _train_methods():
             data.get("depth_observed") if self.input_depth else None, data.get("depth_rendered") if self.input_depth else None,
             data["src_pose"], self.K, self.pixel_means, A["net_input"], A["zoom_factor"], B, H, W)
         self.encoder()
-        # what the backward reads: every encoder activation as NCHW (the converted copies when the encoder ran channel-blocked)
-        self._act_nchw = {g[0]: self.activation_nchw(g[0]) for g in self.enc_geom}
         if self.with_decoder:
             self.decoder()
         if self.with_flow_head:   # deepIM_flownet.py:183-207 (+ the ZoomFlow of the labels, :478-492)
@@ -826,16 +821,15 @@ def _train_methods():
         # Ordering: side waits for dz; main waits for the previous layer's weight gradient before its data gradient overwrites
         # the buffer that one reads (the two gradient buffers ping-pong).
         extra = {"conv6_1": "d_dec61", **skips} if self.with_decoder else {}
-        N = self._act_nchw
         side = self.side.handle if self.side is not None else h
         for li in range(len(self.enc_geom) - 1, -1, -1):
             name, cin_, hh_, ww_, cout_, k_, s_, p_ = self.enc_geom[li]
             ho_, wo_ = _out_hw(hh_, ww_, k_, s_, p_)
-            lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_[extra[name]] if name in extra else None, N[name],
+            lib.deepim_lrelu_bias_backward(h, ga, G[name + "_bias"], ga, W_[extra[name]] if name in extra else None, A[name],
                                            c(SLOPE), B, cout_, ho_ * wo_)
             lib.deepim_stream_wait(h, side)      # weight gradient of layer li+1 done: gb may be overwritten
             lib.deepim_stream_wait(side, h)      # dz of this layer ready
-            src = A["net_input"] if li == 0 else N[self.enc_geom[li - 1][0]]
+            src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
             lib.deepim_conv2d_wgrad_tm(side, G.tm[name + "_weight"][0], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)   # tap-major: _Grads
             if li > 0:
                 self._dgrad(gb, ga, P[name + "_weight"], B, cin_, hh_, ww_, cout_, k_, s_, p_, ho_, wo_)
@@ -888,14 +882,10 @@ def _train_methods():
         deepim_conv_weight_order): the per-step re-pack writes only that one."""
         order = lib.load().deepim_conv_weight_order      # evaluated per update: follows the context's conv options
         h, B = self.ctx.handle, self.B
-        geo = {"Convolution1": (1024, 8, 10, 2, 3, 1, 1), "Convolution2": (1026, 15, 20, 2, 3, 1, 1),
-               "Convolution3": (770, 30, 40, 2, 3, 1, 1), "mask_conv3": (770, 30, 40, 1, 3, 1, 1)}
-        if not self.nc8:
-            geo.update({g[0]: g[1:] for g in self.enc_geom})
-        orders = {n: order(h, B, cin, hh, ww, cout, k, k, s_, p_) for n, (cin, hh, ww, cout, k, s_, p_) in geo.items()}
-        if self.nc8:   # channel-blocked encoder: conv1 = register-fed kernel on the NCHW net input (order 2), the rest the NC8 order (4)
-            orders.update({g[0]: (2 if i == 0 else 4) for i, g in enumerate(self.enc_geom)})
-        return orders
+        geo = {g[0]: g[1:] for g in self.enc_geom}
+        geo.update({"Convolution1": (1024, 8, 10, 2, 3, 1, 1), "Convolution2": (1026, 15, 20, 2, 3, 1, 1),
+                    "Convolution3": (770, 30, 40, 2, 3, 1, 1), "mask_conv3": (770, 30, 40, 1, 3, 1, 1)})
+        return {n: order(h, B, cin, hh, ww, cout, k, k, s_, p_) for n, (cin, hh, ww, cout, k, s_, p_) in geo.items()}
 
     return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad,
                 _small_conv_backward=_small_conv_backward, _head_conv_backward=_head_conv_backward,

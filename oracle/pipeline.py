@@ -109,7 +109,7 @@ def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coor
 
 def train_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", lw_pm=0.1,
                     num_3d_sample=3000, normalize_3d=0.1, loss_type="L1", sigma=1.0, pred_flow=False, pred_mask=False,
-                    lw_flow=0.25, lw_mask=0.03, normalize_flow=20.0, nc8=False):
+                    lw_flow=0.25, lw_mask=0.03, normalize_flow=20.0):
     """Forward + backward of the training graph (deepIM_flownet.py:367-546, losses :170-365; backward = module.backward,
     deepim/core/module.py:1131-1137): the point-matching pose branch, plus — pred_flow / pred_mask — the FlowNetS refinement
     decoder with the flow loss (:183-207) and the mask loss (:314-361). Returns (loss_sum, grads keyed like params, forward
@@ -118,7 +118,7 @@ def train_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, ro
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"),
                            mask_gt_observed=label["mask_gt_observed"])
-    acts = encoder(params, x, nc8=nc8)        # nc8: the forward convolutions accumulate in the channel-blocked kernels' order
+    acts = encoder(params, x)
     B, _, H, W = x.shape
     feat = acts["conv6_1"].reshape(B, -1)
     fc6 = net.fc(feat, params["fc6_weight"], params["fc6_bias"], SLOPE)

@@ -386,7 +386,7 @@ def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
     t = cfg.train_iter
     ref_loss, g_ref, fwd = opipe.train_pose_iteration(params, data_np, label_np, d["K"], MEANS_REV, cfg.dataset.trans_means,
                                                       cfg.dataset.trans_stds, cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE,
-                                                      cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR, nc8=net.nc8)
+                                                      cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR)
     np.testing.assert_array_equal(net.act["net_input"].asnumpy(), fwd["net_input"])
     np.testing.assert_array_equal(net.act["conv6_1"].asnumpy(), fwd["conv6_1"])
     close(net.act["points_est"].asnumpy(), fwd["points_est"])
@@ -513,7 +513,7 @@ def test_training_iteration_with_flow_and_mask_heads_matches_oracle(ctx):
                                                  cfg.dataset.trans_stds, cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE,
                                                  cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR,
                                                  pred_flow=True, pred_mask=True, lw_flow=t.LW_FLOW, lw_mask=t.LW_MASK,
-                                                 normalize_flow=cfg.dataset.NORMALIZE_FLOW, nc8=net.nc8)
+                                                 normalize_flow=cfg.dataset.NORMALIZE_FLOW)
     A = net.act
     np.testing.assert_array_equal(A["conv6_1"].asnumpy(), fwd["conv6_1"])
     np.testing.assert_array_equal(A["Concat3"].asnumpy(), fwd["Concat3"])
