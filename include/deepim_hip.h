@@ -540,7 +540,8 @@ int deepim_sgd_mom_update(deepim_ctx* ctx, float* w, float* mom, const float* g,
 
 /* the same update of every parameter in one launch. table (device): `rows` rows of six 64-bit words {w, mom, g (device
  * addresses), n, (bits of float wd) | (first block of the row << 32), layout of g: 0 = like w, else Cin | (kh*kw << 32) = the
- * tap-major gradient of deepim_conv2d_wgrad_tm}; a row owns ceil(n/256) blocks, rows in block order, total_blocks = their sum.
+ * tap-major gradient of deepim_conv2d_wgrad_tm}; a row owns ceil(n/1024) blocks (four parameters per thread: w, mom and a natural g
+ * must be 16-byte aligned), rows in block order, total_blocks = their sum.
  * Results are bit-identical to per-tensor deepim_sgd_mom_update calls on natural gradients. */
 int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long long* table, int rows, int total_blocks, float lr,
                                 float momentum, float rescale, float clip);

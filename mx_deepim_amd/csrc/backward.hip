@@ -756,21 +756,48 @@ __global__ __launch_bounds__(256) void sgd_mom_multi_kernel(const unsigned long 
   const float* g = reinterpret_cast<const float*>(e[2]);
   const size_t n = e[3];
   const float wd = __uint_as_float((unsigned)e[4]);
-  const size_t i = (size_t)(b - (unsigned)(e[4] >> 32)) * 256 + threadIdx.x;
-  if (i >= n) return;
-  size_t gi = i;
+  // four consecutive parameters per thread (dwordx4 on w / mom and on a natural g; tensors and their row views are 16-byte aligned)
+  const size_t i0 = ((size_t)(b - (unsigned)(e[4] >> 32)) * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
   const int cin = (int)(unsigned)e[5], khw = (int)(e[5] >> 32);
+  const int cnt = (int)min((size_t)4, n - i0);
+  float wv[4], mv[4], gv[4];
+  if (cnt == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(w + i0), c = *reinterpret_cast<const float4*>(mom + i0);
+    wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w;
+    mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+  } else {
+    for (int j = 0; j < cnt; ++j) { wv[j] = w[i0 + j]; mv[j] = mom[i0 + j]; }
+  }
   if (cin) {   // the gradient lies tap-major (co, tap, ci): deepim_conv2d_wgrad_tm
     const int K = cin * khw;
-    const size_t co = i / K;
-    const int rem = (int)(i - co * K), ci = rem / khw, t = rem - ci * khw;
-    gi = co * K + (size_t)t * cin + ci;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j >= cnt) break;
+      const size_t i = i0 + j, co = i / K;
+      const int rem = (int)(i - co * K), ci = rem / khw, t = rem - ci * khw;
+      gv[j] = g[co * K + (size_t)t * cin + ci];
+    }
+  } else if (cnt == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(g + i0);
+    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z; gv[3] = a.w;
+  } else {
+    for (int j = 0; j < cnt; ++j) gv[j] = g[i0 + j];
   }
-  float gg = g[gi] * rescale;
-  if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
-  const float m = momentum * mom[i] - lr * (gg + wd * w[i]);
-  mom[i] = m;
-  w[i] = w[i] + m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float gg = gv[j] * rescale;
+    if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+    const float m = momentum * mv[j] - lr * (gg + wd * wv[j]);
+    mv[j] = m;
+    wv[j] = wv[j] + m;
+  }
+  if (cnt == 4) {
+    *reinterpret_cast<float4*>(mom + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(w + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+  } else {
+    for (int j = 0; j < cnt; ++j) { mom[i0 + j] = mv[j]; w[i0 + j] = wv[j]; }
+  }
 }
 
 void launch_wgrad_reduce(deepim_ctx* ctx, float* dw, const float* partial, long n, int S) {
@@ -785,7 +812,7 @@ void launch_wgrad_reduce(deepim_ctx* ctx, float* dw, const float* partial, long 
 extern "C" int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long long* table, int rows, int total_blocks,
                                            float lr, float momentum, float rescale, float clip) {
   DI_DEVICE(ctx);
-  DI_REQUIRE(rows >= 0 && table != nullptr, "sgd_mom_update_multi: no table");
+  DI_REQUIRE(rows >= 0 && table != nullptr, "sgd_mom_update_multi: no table");   // (w, mom, g 16-byte aligned: unchecked, device-side data)
   if (rows == 0 || total_blocks <= 0) return 0;
   hipLaunchKernelGGL(sgd_mom_multi_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, table, rows, lr, momentum, rescale, clip);
   DI_LAUNCH_CHECK();

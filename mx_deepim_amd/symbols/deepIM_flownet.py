@@ -859,7 +859,7 @@ def _train_methods():
                 else:
                     g_ptr, layout = dict.__getitem__(self.grad, name).ptr, 0
                 rows.append([w.ptr, self.mom[name].ptr, g_ptr, w.size, wd_bits | (block << 32), layout])
-                block += (w.size + 255) // 256
+                block += (w.size + 1023) // 1024
             dev = self.ctx.empty((len(rows), 6), np.uint64)
             dev.copyfrom(np.array(rows, dtype=np.uint64))
             tab = self._sgd_table = (float(wd), dev, len(rows), block)

@@ -246,7 +246,7 @@ def test_tap_major_wgrad_is_the_natural_one_permuted(ctx, case):
         w, m = ctx.array(w0), ctx.zeros(want.shape)
         tab = ctx.empty((1, 6), np.uint64)
         tab.copyfrom(np.array([[w.ptr, m.ptr, g.ptr, w.size, int(np.array([5e-4], np.float32).view(np.uint32)[0]), layout]], dtype=np.uint64))
-        lib.deepim_sgd_mom_update_multi(h, tab, 1, (w.size + 255) // 256, cf(1e-3), cf(0.975), cf(1.0), cf(0.0))
+        lib.deepim_sgd_mom_update_multi(h, tab, 1, (w.size + 1023) // 1024, cf(1e-3), cf(0.975), cf(1.0), cf(0.0))
         res.append((w.asnumpy(), m.asnumpy()))
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
@@ -334,7 +334,7 @@ def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
         rows, block = [], 0
         for i, n in enumerate(sizes):
             rows.append([w[i].ptr, m[i].ptr, g[i].ptr, n, int(np.array([wds[i]], np.float32).view(np.uint32)[0]) | (block << 32), 0])
-            block += (n + 255) // 256
+            block += (n + 1023) // 1024
         tab = ctx.empty((len(rows), 6), np.uint64)
         tab.copyfrom(np.array(rows, dtype=np.uint64))
         lib.deepim_sgd_mom_update_multi(h, tab, len(rows), block, cf(1e-3), cf(0.975), cf(0.5), cf(clip))
