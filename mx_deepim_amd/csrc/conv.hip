@@ -1193,35 +1193,6 @@ __global__ void pack_direct_kernel(float* __restrict__ packed, const float* __re
   const int co = mt * 32 + r, ci = 2 * (g / khw) + h, t = g % khw;
   packed[i] = (co < Cout && ci < Cin) ? wview_at(v, w, co, ci, t, Cin, khw) : 0.f;
 }
-// The same layout from a PLAIN (Cout,Cin,kh,kw) tensor with coalesced reads: in the kernel above a lane's source element lies one
-// filter (Cin·kh·kw floats) away from its neighbour's, so every 4-byte read touches its own sector (conv6_1: 38 MB in 38 µs). Here a
-// block stages 32 filters x NC2 channel pairs — per filter ONE contiguous run of 2·NC2·kh·kw floats — through LDS (pitch + 1: the
-// 32 rows of a read land in 32 banks) and writes whole 1 KB groups. The training step re-packs every layer's weights.
-__global__ __launch_bounds__(256) void pack_direct_tiled_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout,
-                                                                int Cin, int khw, int npair, int NC2) {
-  extern __shared__ float pk_lds[];
-  const int mt = blockIdx.x, c0 = blockIdx.y * NC2;            // 32-filter tile, first channel pair
-  const int L = 2 * NC2 * khw, P = L + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long K = (long)Cin * khw;
-  for (int r = wave; r < 32; r += 4) {
-    const int co = mt * 32 + r;
-    const long base = (long)co * K + (long)2 * c0 * khw;       // run [base, base + L), cut at the end of the filter (odd / ragged Cin)
-    const long lim = co < Cout ? (long)(co + 1) * K : base;
-    for (int o = lane; o < L; o += 64) pk_lds[r * P + o] = base + o < lim ? w[base + o] : 0.f;
-  }
-  __syncthreads();
-  const int G = NC2 * khw;                                      // pairs of this tile (a multiple of 4)
-  const int g0 = c0 * khw;
-  for (int j = tid; j < G * 64; j += 256) {
-    const int q = j & 3, r = (j >> 2) & 31, h = (j >> 7) & 1, gq = j >> 8;
-    const int gl = gq * 4 + q, g = g0 + gl;
-    if (g >= npair) continue;                                   // (whole groups: npair % 4 == 0)
-    const int c2l = gl / khw, t = gl - c2l * khw;
-    packed[(((long)mt * (npair / 4) + (g0 >> 2) + gq) * 64 + h * 32 + r) * 4 + q] = pk_lds[r * P + (2 * c2l + h) * khw + t];
-  }
-}
-
 // the register-fed order of the four parity-class sub-kernels of a stride-2 data gradient in one launch
 struct PackGroup {
   float* dst[CONV_GROUP_MAX];
@@ -1563,20 +1534,9 @@ static int conv_pack_impl(deepim_ctx* ctx, float* packed_w, const float* w, int 
   if (orders & 1)
     hipLaunchKernelGGL(pack_conv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cout, K,
                        nchunk, total, v, kh * kw);
-  if (orders & 2) {
-    const int khw = kh * kw, npair = nchunk * (KT / 2);
-    const int NC2 = khw <= 9 ? 16 : 4;                       // 2·NC2·khw floats per filter in LDS: <= 392 (7x7)
-    if (!v.on && khw <= 49 && (NC2 * khw) % 4 == 0) {
-      // tiles over all npair (padding included: zero-filled), 32 filters x NC2 channel pairs each
-      const int ytiles = di_div_up(npair, NC2 * khw);
-      const size_t lds = (size_t)32 * (2 * NC2 * khw + 1) * sizeof(float);
-      hipLaunchKernelGGL(pack_direct_tiled_kernel, dim3(gran_count(Cout) * 2, ytiles), dim3(256), lds, ctx->stream, packed_w + total, w,
-                         Cout, Cin, khw, npair, NC2);
-    } else {
-      hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
-                         Cin, khw, npair, total, v);
-    }
-  }
+  if (orders & 2)
+    hipLaunchKernelGGL(pack_direct_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + total, w, Cout,
+                       Cin, kh * kw, nchunk * (KT / 2), total, v);
   if (orders & 4) {
     DI_REQUIRE(!v.on, "conv_pack: the NC8 order is not built for data-gradient views");
     hipLaunchKernelGGL(pack_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w + 2 * total, w, Cout,
