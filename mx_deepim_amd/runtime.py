@@ -83,6 +83,9 @@ class _Lib:
                     "%s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(make -C mx_deepim_amd/csrc). There is no CPU fallback." % LIB_PATH
                 )
+            # multi-process GPU work (RCCL between ranks) needs dmabuf IPC on this driver stack: without it hipIpcGetMemHandle fails
+            # with "invalid argument". Must be in the environment before the HIP runtime starts; an explicit setting wins.
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             self._dll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
             self._protos = parse_header()
             for name, (res, argtypes, _) in self._protos.items():
