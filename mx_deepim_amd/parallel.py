@@ -172,6 +172,7 @@ class Rendezvous(object):
         self.addr = addr or env.get("MASTER_ADDR", "127.0.0.1")
         # MASTER_PORT itself belongs to the launcher's own store; the job's rendezvous sits one above it
         self.port = int(env.get("DEEPIM_RDZV_PORT", int(env.get("MASTER_PORT", "29500")) + 1)) if port is None else int(port)
+        self.port0 = self.port
         self.timeout = float(timeout)
         single_node = int(env.get("LOCAL_WORLD_SIZE", "0")) == self.world or _is_loopback(self.addr)
         if single_node:
@@ -190,19 +191,29 @@ class Rendezvous(object):
         if self.world > 1:
             self._connect()
 
+    def _candidates(self):
+        """Ports the hub may listen on, in order: the configured one (MASTER_PORT + 1 / DEEPIM_RDZV_PORT) and five fallbacks."""
+        return [self.port0 + 97 * k for k in range(6) if self.port0 + 97 * k < 65536]
+
     def _mac(self, *parts):
         return hmac.new(self._key, b"|".join(parts), hashlib.sha256).digest()
 
     def _connect(self):
         if self.rank == 0:
-            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                ls.bind((self.addr, self.port))
-            except OSError as e:
-                ls.close()
-                raise RuntimeError("rendezvous: cannot bind %s:%d (%s) — MASTER_PORT+1 is taken, set DEEPIM_RDZV_PORT to a "
-                                   "free port on every rank" % (self.addr, self.port, e))
+            ls, err = None, None
+            for port in self._candidates():      # MASTER_PORT + 1 may be somebody else's: the spokes scan the same short list
+                ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    ls.bind((self.addr, port))
+                    self.port = port
+                    break
+                except OSError as e:
+                    ls.close()
+                    ls, err = None, e
+            if ls is None:
+                raise RuntimeError("rendezvous: cannot bind any of %s on %s (%s) — set DEEPIM_RDZV_PORT to a free port on every "
+                                   "rank" % (self._candidates(), self.addr, err))
             ls.listen(self.world)
             ls.settimeout(self.timeout)
             self._listener = ls
@@ -228,27 +239,43 @@ class Rendezvous(object):
                 conn.settimeout(self.timeout)
                 self._peers[r] = conn
         else:
-            deadline = time.time() + self.timeout
-            while True:
-                try:
-                    s = socket.create_connection((self.addr, self.port), timeout=5.0)
+            # the hub listens on the first port of the candidate list it could bind: try them in turn until one answers the
+            # challenge with this job's token (a foreign service on a candidate port fails the handshake and is skipped)
+            deadline, last = time.time() + self.timeout, "no candidate port answered"
+            s = None
+            while s is None:
+                for port in self._candidates():
+                    try:
+                        c = socket.create_connection((self.addr, port), timeout=2.0)
+                    except OSError as e:
+                        last = "%s:%d %s" % (self.addr, port, e)
+                        continue
+                    try:
+                        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.settimeout(3.0)
+                        nonce = _recv_exact(c, 16)
+                    except (OSError, ConnectionError) as e:      # silent or short: not a hub of ours, next candidate
+                        c.close()
+                        last = "%s:%d sent no challenge (%s: a foreign service?)" % (self.addr, port, type(e).__name__)
+                        continue
+                    # it speaks the protocol: from here on a refusal is an answer, not a reason to keep scanning
+                    mine, rk = os.urandom(16), struct.pack("<I", self.rank)
+                    try:
+                        c.settimeout(self.timeout)
+                        c.sendall(rk + mine + self._mac(b"spoke", nonce, rk))
+                        proof = _recv_exact(c, 32)
+                    except (OSError, ConnectionError):
+                        c.close()
+                        raise RuntimeError("rendezvous: the hub rejected rank %d (token mismatch or duplicate rank)" % self.rank)
+                    if not hmac.compare_digest(proof, self._mac(b"hub", mine)):
+                        c.close()
+                        raise RuntimeError("rendezvous: %s:%d is not this job's hub (token mismatch)" % (self.addr, port))
+                    s, self.port = c, port
                     break
-                except OSError:
+                if s is None:
                     if time.time() > deadline:
-                        raise RuntimeError("rendezvous: rank %d could not reach %s:%d" % (self.rank, self.addr, self.port))
+                        raise RuntimeError("rendezvous: rank %d could not join the hub — %s" % (self.rank, last))
                     time.sleep(0.05)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.settimeout(self.timeout)
-            nonce = _recv_exact(s, 16)
-            mine, rk = os.urandom(16), struct.pack("<I", self.rank)
-            s.sendall(rk + mine + self._mac(b"spoke", nonce, rk))
-            try:
-                proof = _recv_exact(s, 32)
-            except ConnectionError:
-                raise RuntimeError("rendezvous: the hub rejected rank %d (token mismatch or duplicate rank)" % self.rank)
-            if not hmac.compare_digest(proof, self._mac(b"hub", mine)):
-                s.close()
-                raise RuntimeError("rendezvous: %s:%d is not this job's hub (token mismatch)" % (self.addr, self.port))
             self._hub = s
 
     def all_gather(self, obj):

@@ -233,6 +233,29 @@ def test_rendezvous_rejects_a_peer_with_the_wrong_token():
     assert res == [(0, [0.0, 1.0]), (1, [0.0, 1.0])], res
 
 
+def test_rendezvous_moves_to_the_next_candidate_port_when_the_first_is_taken():
+    """MASTER_PORT + 1 belongs to somebody else (a listener that never speaks): the hub binds the next port of the candidate list,
+    the spoke skips the silent one and finds it; the exchange then works as usual."""
+    import multiprocessing as mp
+    import socket
+    port = 37000 + os.getpid() % 2000
+    squat = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squat.bind(("127.0.0.1", port))
+    squat.listen(4)
+    try:
+        ctxm = mp.get_context("spawn")
+        q = ctxm.Queue()
+        procs = [ctxm.Process(target=_token_worker, args=(r, port, "job-secret", q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=90), q.get(timeout=90)])
+        for p in procs:
+            p.join(timeout=30)
+        assert res == [(0, [0.0, 1.0]), (1, [0.0, 1.0])], res
+    finally:
+        squat.close()
+
+
 def test_rendezvous_needs_a_token_on_a_routable_address(monkeypatch):
     monkeypatch.delenv("DEEPIM_RDZV_TOKEN", raising=False)
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
