@@ -822,7 +822,11 @@ extern "C" int deepim_sgd_mom_update_multi(deepim_ctx* ctx, const unsigned long 
 extern "C" int deepim_lrelu_bias_backward(deepim_ctx* ctx, float* dz, float* db, const float* dy, const float* add, const float* y,
                                           float slope, int B, int C, size_t hw) {
   DI_DEVICE(ctx);
-  if (C == 0 || B == 0 || hw == 0) return 0;
+  if (C == 0) return 0;
+  if (B == 0 || hw == 0) {   // nothing to walk: the sum over no elements is zero (what deepim_bias_grad gives)
+    DI_CHECK(hipMemsetAsync(db, 0, (size_t)C * sizeof(float), ctx->stream));
+    return 0;
+  }
   int S = (int)max(1L, min((long)di_div_up(1024, C), (long)di_div_up((long)hw, 4096)));
   const long per_slice = (long)di_div_up(di_div_up((long)hw, S), 1024) * 1024;
   S = di_div_up((long)hw, per_slice);

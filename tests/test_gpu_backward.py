@@ -315,6 +315,25 @@ def test_lrelu_bias_backward_equals_the_separate_passes(ctx, shape, with_add):
     np.testing.assert_allclose(db.asnumpy(), db_ref.asnumpy(), rtol=2e-6, atol=1e-6 * np.sqrt(B * H * W))
 
 
+def test_backward_entries_on_an_empty_batch(ctx):
+    """B = 0 (a rank whose shard is empty): the new entries return success, touch nothing they should not, and a bias gradient
+    over no elements is zero."""
+    h = ctx.handle
+    db = ctx.array(np.full((6,), 7.0, np.float32))
+    x = ctx.array(np.zeros((1, 6, 4, 4), np.float32))
+    lib.deepim_lrelu_bias_backward(h, x, db, x, None, x, cf(0.1), 0, 6, 16)
+    np.testing.assert_array_equal(db.asnumpy(), np.zeros(6, np.float32))
+    w = ctx.array(np.ones((8, 8, 3, 3), np.float32))
+    ws = DeviceArray(ctx, (lib.load().deepim_conv_dgrad_packed_size(8, 8, 3, 2, 1) // 4,))
+    keep = ctx.array(np.full((1, 8, 4, 4), 3.0, np.float32))
+    for stride in (1, 2):
+        lib.deepim_conv2d_dgrad(h, keep, x, w, ws, 0, 8, 4, 4, 8, 3, stride, 1, None, None, cf(0.1))
+    dw = ctx.array(np.full((8, 9, 8), 5.0, np.float32))
+    lib.deepim_conv2d_wgrad_tm(h, dw, keep, keep, 0, 8, 4, 4, 8, 3, 3, 1, 1)
+    ctx.sync()
+    assert (keep.asnumpy() == 3.0).all() and (dw.asnumpy() == 5.0).all()
+
+
 def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
     """deepim_sgd_mom_update_multi: one launch over a table of parameters (ragged sizes, weight decay per row) — the same bits as
     one deepim_sgd_mom_update per tensor."""
