@@ -121,6 +121,29 @@ def test_bench_two_ranks_strong_scaling_ragged_dry_run():
     assert abs(d["value"] - 3 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_two_ranks_default_backend_agrees_on_the_rendezvous_fallback():
+    """The driver's own command line (RCCL backend) with two ranks on ONE visible GPU: RCCL refuses the duplicate device at
+    communicator init, every rank learns it over the rendezvous, all fall back to the rendezvous exchange and the line says so —
+    the run still measures. (On a multi-GPU node the same code path keeps RCCL and `parallelism` names ncclAllGather.)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("DEEPIM_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29679", "bench.py", "--gpus", "2", "--steps", "1",
+                        "--warmup", "1", "--batch", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    import ctypes
+    from mx_deepim_amd.runtime import lib
+    ndev = ctypes.c_int(0)
+    lib.load().deepim_device_count(ctypes.byref(ndev))
+    if ndev.value < 2:
+        assert "RCCL unavailable" in d["config"]["parallelism"] and "rendezvous" in d["config"]["parallelism"], d["config"]
+        assert "RCCL unavailable" in r.stderr
+    else:
+        assert "ncclAllGather" in d["config"]["parallelism"], d["config"]
+
+
 def test_rccl_entry_points_world_size_one(ctx):
     """deepim_comm_unique_id / comm_init / allgather_poses / comm_allreduce_f64 / comm_destroy through librccl.so itself
     (dlopen'ed by the library) with a one-rank communicator, plus the communicator-less copy path."""
