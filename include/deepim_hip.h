@@ -64,6 +64,9 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * (and the few-filter stream kernel for Cout <= 4), 0 = the round-2 register-fed kernel; "dgrad_group": 1 (default) = the four
  * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
+/* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
+ * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */
+int deepim_get_option(deepim_ctx* ctx, const char* name, int* value);
 /* Device-side ordering between two contexts (two streams) of ONE GPU: work queued on `waiter` after this call starts only after
  * everything queued on `ctx` before it has finished; the host does not block. Lets independent kernels of one graph (the weight
  * and the data gradient of a layer) share the chip: each context has its own stream and scratch. */

@@ -869,6 +869,10 @@ extern "C" int deepim_lrelu_backward(deepim_ctx* ctx, float* dz, const float* dy
 extern "C" int deepim_bias_grad(deepim_ctx* ctx, float* db, const float* dz, int B, int C, size_t hw) {
   DI_DEVICE(ctx);
   if (C == 0) return 0;
+  if (B == 0 || hw == 0) {   // empty batch / empty maps: the sum over nothing (as deepim_lrelu_bias_backward does)
+    DI_CHECK(hipMemsetAsync(db, 0, (size_t)C * sizeof(float), ctx->stream));
+    return 0;
+  }
   // slices of whole 1024-element runs, enough blocks for ~4 per CU; fixed by the geometry (deterministic)
   int S = (int)max(1L, min((long)di_div_up(1024, C), (long)di_div_up((long)hw, 4096)));
   const long per_slice = (long)di_div_up(di_div_up((long)hw, S), 1024) * 1024;
@@ -981,7 +985,11 @@ extern "C" int deepim_weight_grad_to_natural(deepim_ctx* ctx, float* dw, const f
 static int conv2d_wgrad_impl(deepim_ctx* ctx, float* dw, float* db, const float* x, const float* dz, int B, int Cin, int H, int W,
                              int Cout, int kh, int kw, int stride, int pad, bool tap_major) {
   DI_DEVICE(ctx);
-  if (B == 0) return 0;
+  if (B == 0) {   // a rank with an empty shard: the gradients are zero, not whatever the buffers held (update() applies them)
+    if (dw) DI_CHECK(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * kh * kw * sizeof(float), ctx->stream));
+    if (db) DI_CHECK(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), ctx->stream));
+    return 0;
+  }
   WgradParams p;
   p.x = x; p.dz = dz;
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;

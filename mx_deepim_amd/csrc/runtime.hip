@@ -143,7 +143,14 @@ extern "C" int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t by
   if (bytes == 0) return 0;
   // small word-aligned copies (poses, head weights, 7-row gradient blocks) as a kernel in stream order: the blit path of
   // hipMemcpyAsync left 8-18 µs gaps around each of them in the training trace
-  if (bytes <= (1u << 20) && ((bytes | (size_t)dst | (size_t)src) & 3) == 0) {
+  // (the kernel dereferences both pointers on ctx's device: only when both allocations live there — a source on another
+  // device, e.g. DeviceArray.copyfrom across contexts, keeps the runtime's peer copy)
+  auto on_device = [&](const void* q) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice && a.device == ctx->device;
+  };
+  if (bytes <= (1u << 20) && ((bytes | (size_t)dst | (size_t)src) & 3) == 0 && (ctx->capturing || (on_device(dst) && on_device(src)))) {   // no pointer queries inside a stream capture
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)dst,
                        (const uint32_t*)src, n);
@@ -184,6 +191,20 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
     return 0;
   }
   deepim_set_error_msg("deepim_set_option: unknown option");
+  return -1;
+}
+// the current value of an option deepim_set_option knows (host code that must follow the context's kernel selection reads it
+// instead of keeping a shadow copy)
+extern "C" int deepim_get_option(deepim_ctx* ctx, const char* name, int* value) {
+  DI_REQUIRE(ctx != nullptr && name != nullptr && value != nullptr, "deepim_get_option: NULL argument");
+  const struct { const char* n; int v; } opts[] = {
+      {"conv_max_split", ctx->conv_max_split}, {"conv_direct", ctx->conv_direct}, {"fc_slices", ctx->fc_slices},
+      {"conv_tail_split", ctx->conv_tail_split}, {"conv_force_plan", ctx->conv_force_plan}, {"conv_tail_slots", ctx->conv_tail_slots},
+      {"conv_tile256", ctx->conv_tile256}, {"conv_autotune", ctx->conv_autotune}, {"dgrad_group", ctx->dgrad_group},
+      {"wgrad_lds", ctx->wgrad_lds}, {"f16_dev_flags", ctx->f16_dev_flags}, {"conv_xcd_swizzle", ctx->conv_xcd_swizzle}};
+  for (const auto& o : opts)
+    if (strcmp(name, o.n) == 0) { *value = o.v; return 0; }
+  deepim_set_error_msg("deepim_get_option: unknown option");
   return -1;
 }
 extern "C" int deepim_sync(deepim_ctx* ctx) {

@@ -174,6 +174,8 @@ class Rendezvous(object):
         self.port = int(env.get("DEEPIM_RDZV_PORT", int(env.get("MASTER_PORT", "29500")) + 1)) if port is None else int(port)
         self.port0 = self.port
         self.timeout = float(timeout)
+        self.handshake_timeout = 2.0     # hub: per-connection limit for the 52-byte hello
+        self.reject_grace = 5.0          # spoke: how long to keep scanning after some hub REFUSED this rank (see _connect)
         single_node = int(env.get("LOCAL_WORLD_SIZE", "0")) == self.world or _is_loopback(self.addr)
         if single_node:
             self.addr = "127.0.0.1"
@@ -221,9 +223,13 @@ class Rendezvous(object):
             while len(self._peers) < self.world - 1:
                 if time.time() > deadline:
                     raise RuntimeError("rendezvous: only %d of %d ranks joined" % (len(self._peers) + 1, self.world))
-                conn, _ = ls.accept()
+                try:
+                    ls.settimeout(max(0.05, min(1.0, deadline - time.time())))
+                    conn, _ = ls.accept()
+                except socket.timeout:
+                    continue                   # the deadline check above words the failure
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(min(self.timeout, 10.0))
+                conn.settimeout(min(self.timeout, self.handshake_timeout))   # a silent stranger stalls the joining ranks this long at most
                 try:            # a stranger (wrong token, bad rank, garbage) is dropped; it cannot take a rank's slot
                     nonce = os.urandom(16)
                     conn.sendall(nonce)
@@ -241,7 +247,12 @@ class Rendezvous(object):
         else:
             # the hub listens on the first port of the candidate list it could bind: try them in turn until one answers the
             # challenge with this job's token (a foreign service on a candidate port fails the handshake and is skipped)
+            # A refusal (wrong token / duplicate rank / failed proof) does not end the scan: when another deepim job of this host
+            # owns port0, THIS job's hub sits on a later candidate and may not even listen yet — so the spoke goes on to the
+            # next candidate and raises only when `reject_grace` seconds after the first refusal (or the deadline) nobody has
+            # taken it.
             deadline, last = time.time() + self.timeout, "no candidate port answered"
+            refused_at, refused = None, None
             s = None
             while s is None:
                 for port in self._candidates():
@@ -258,22 +269,30 @@ class Rendezvous(object):
                         c.close()
                         last = "%s:%d sent no challenge (%s: a foreign service?)" % (self.addr, port, type(e).__name__)
                         continue
-                    # it speaks the protocol: from here on a refusal is an answer, not a reason to keep scanning
+                    # it speaks the protocol
                     mine, rk = os.urandom(16), struct.pack("<I", self.rank)
                     try:
-                        c.settimeout(self.timeout)
+                        c.settimeout(min(self.timeout, 10.0))
                         c.sendall(rk + mine + self._mac(b"spoke", nonce, rk))
                         proof = _recv_exact(c, 32)
                     except (OSError, ConnectionError):
                         c.close()
-                        raise RuntimeError("rendezvous: the hub rejected rank %d (token mismatch or duplicate rank)" % self.rank)
+                        refused = "the hub on %s:%d rejected rank %d (token mismatch or duplicate rank)" % (self.addr, port, self.rank)
+                        refused_at = refused_at or time.time()
+                        continue
                     if not hmac.compare_digest(proof, self._mac(b"hub", mine)):
                         c.close()
-                        raise RuntimeError("rendezvous: %s:%d is not this job's hub (token mismatch)" % (self.addr, port))
+                        refused = "%s:%d is not this job's hub (token mismatch)" % (self.addr, port)
+                        refused_at = refused_at or time.time()
+                        continue
+                    c.settimeout(self.timeout)
                     s, self.port = c, port
                     break
                 if s is None:
-                    if time.time() > deadline:
+                    now = time.time()
+                    if refused_at is not None and now > min(deadline, refused_at + self.reject_grace):
+                        raise RuntimeError("rendezvous: %s" % refused)
+                    if now > deadline:
                         raise RuntimeError("rendezvous: rank %d could not join the hub — %s" % (self.rank, last))
                     time.sleep(0.05)
             self._hub = s

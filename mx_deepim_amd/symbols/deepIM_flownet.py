@@ -608,9 +608,16 @@ def _train_methods():
         w7[0:4].copyfrom(self.params["rot_weight"]); w7[4:7].copyfrom(self.params["trans_weight"])
         self.params["rot_weight"], self.params["trans_weight"] = w7[0:4], w7[4:7]
         self.grad = _Grads(ctx, {name: ctx.zeros(a.shape) for name, a in self.params.items()})
+        self._sgd_table = None     # its rows hold raw pointers of the buffers allocated here: never reuse one across binds
+        # tap-major weight gradients (deepim_conv2d_wgrad_tm) only where that entry applies: Cin % 8 == 0 and the LDS-staged
+        # kernel selected on this context. Everything else (conv1 of the 6- / 10-channel inputs, wgrad_lds = 0) takes
+        # deepim_conv2d_wgrad into the natural buffer and the SGD table reads that one (layout word 0).
+        opt = ctypes.c_int(0)
+        lib.deepim_get_option(ctx.handle, b"wgrad_lds", ctypes.byref(opt))
         for gname, cin, _h, _w, cout, k, _s, _p in self.enc_geom:       # conv layers: (Cout, Cin, k, k)
-            self.grad.tm[gname + "_weight"] = (ctx.zeros((cout, k * k, cin)), cout, cin, k * k)
-        if self.with_decoder:                                            # deconvs: MXNet (cin, cout, 4, 4) = filters cin, channels cout
+            if opt.value and cin % 8 == 0:
+                self.grad.tm[gname + "_weight"] = (ctx.zeros((cout, k * k, cin)), cout, cin, k * k)
+        if self.with_decoder and opt.value:                              # deconvs: MXNet (cin, cout, 4, 4) = filters cin, channels cout
             for gname, cin, cout in (("deconv4", 1026, 256), ("deconv5", 1024, 512)):
                 self.grad.tm[gname + "_weight"] = (ctx.zeros((cin, 16, cout)), cin, cout, 16)
         self.grad["rot_weight"], self.grad["trans_weight"] = dw7[0:4], dw7[4:7]
@@ -830,7 +837,10 @@ def _train_methods():
             lib.deepim_stream_wait(h, side)      # weight gradient of layer li+1 done: gb may be overwritten
             lib.deepim_stream_wait(side, h)      # dz of this layer ready
             src = A["net_input"] if li == 0 else A[self.enc_geom[li - 1][0]]
-            lib.deepim_conv2d_wgrad_tm(side, G.tm[name + "_weight"][0], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)   # tap-major: _Grads
+            if name + "_weight" in G.tm:
+                lib.deepim_conv2d_wgrad_tm(side, G.tm[name + "_weight"][0], src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)   # tap-major: _Grads
+            else:       # Cin % 8 != 0 (6- / 10-channel conv1) or wgrad_lds = 0: natural (Cout, Cin, k, k) gradient
+                lib.deepim_conv2d_wgrad(side, dict.__getitem__(G, name + "_weight"), src, ga, B, cin_, hh_, ww_, cout_, k_, k_, s_, p_)
             if li > 0:
                 self._dgrad(gb, ga, P[name + "_weight"], B, cin_, hh_, ww_, cout_, k_, s_, p_, ho_, wo_)
             ga, gb = gb, ga

@@ -328,10 +328,19 @@ def test_backward_entries_on_an_empty_batch(ctx):
     keep = ctx.array(np.full((1, 8, 4, 4), 3.0, np.float32))
     for stride in (1, 2):
         lib.deepim_conv2d_dgrad(h, keep, x, w, ws, 0, 8, 4, 4, 8, 3, stride, 1, None, None, cf(0.1))
+    # a weight / bias gradient over no samples is zero, not whatever the buffer held (update() would apply it): ADVICE r3
     dw = ctx.array(np.full((8, 9, 8), 5.0, np.float32))
     lib.deepim_conv2d_wgrad_tm(h, dw, keep, keep, 0, 8, 4, 4, 8, 3, 3, 1, 1)
+    dw2, db2 = ctx.array(np.full((8, 8, 3, 3), 5.0, np.float32)), ctx.array(np.full((8,), 5.0, np.float32))
+    lib.deepim_conv2d_wgrad_bias(h, dw2, db2, keep, keep, 0, 8, 4, 4, 8, 3, 3, 1, 1)
     ctx.sync()
-    assert (keep.asnumpy() == 3.0).all() and (dw.asnumpy() == 5.0).all()
+    assert (keep.asnumpy() == 3.0).all()
+    assert not dw.asnumpy().any() and not dw2.asnumpy().any() and not db2.asnumpy().any()
+    # deepim_bias_grad with no elements per channel (hw = 0 used to divide by zero) or no samples
+    for B_, hw_ in ((2, 0), (0, 16)):
+        db3 = ctx.array(np.full((6,), 7.0, np.float32))
+        lib.deepim_bias_grad(h, db3, x, B_, 6, hw_)
+        np.testing.assert_array_equal(db3.asnumpy(), np.zeros(6, np.float32))
 
 
 def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
@@ -362,10 +371,11 @@ def test_sgd_multi_is_bit_identical_to_per_tensor_updates(ctx):
             np.testing.assert_array_equal(m[i].asnumpy(), ref_m[i].asnumpy())
 
 
-def _train_setup(ctx, B, seed, pred_heads):
+def _train_setup(ctx, B, seed, pred_heads, input_mask=True, input_depth=False):
     d = synthetic.make_batch(B, seed=seed, n_frames=1)
     cfg = default_config()
     cfg.network.PRED_FLOW = cfg.network.PRED_MASK = pred_heads
+    cfg.network.INPUT_MASK, cfg.network.INPUT_DEPTH = input_mask, input_depth
     net = deepIM_flownet().get_symbol(cfg, is_train=True)
     params = net.init_weights(cfg, seed=91)
     net.bind_train(ctx, B, params, num_points=3000)
@@ -375,6 +385,8 @@ def _train_setup(ctx, B, seed, pred_heads):
     wts = np.ones((B, 3, 3000), np.float32)
     data_np = {"image_observed": d["image_observed"], "image_rendered": d["image_rendered"][0], "mask_observed": d["mask_observed"],
                "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0]}
+    if input_depth:
+        data_np.update(depth_observed=d["depth_gt_observed"], depth_rendered=d["depth_rendered"][0])
     label_np = {"mask_gt_observed": gt, "point_cloud_model": d["point_cloud_model"], "point_cloud_weights": wts,
                 "point_cloud_observed": pco}
     if pred_heads:   # flow labels the way the data layer makes them (lib/pair_matching/data_pair.py:get_pair_flow, on the device)
@@ -422,6 +434,67 @@ def test_training_iteration_of_the_pose_branch_matches_oracle(ctx):
         np.testing.assert_allclose(net.params[k].asnumpy(), w_ref, rtol=1e-4, atol=1e-7)
     loss2 = net.forward_train(data, label).asnumpy()[0]
     assert np.isfinite(loss2) and loss2 != loss
+
+
+@pytest.mark.parametrize("input_mask,input_depth", [(False, False), (True, True)])
+def test_training_iteration_with_6_and_10_input_channels(ctx, input_mask, input_depth):
+    """INPUT_MASK = False (C_in = 6) and INPUT_DEPTH + INPUT_MASK (C_in = 10): conv1's weight gradient cannot take the tap-major
+    LDS entry (C_in % 8 != 0) — bind_train registers the natural buffer for it and backward() calls deepim_conv2d_wgrad (ADVICE r3:
+    this raised). Gradients against the oracle, then an SGD step that really moves conv1."""
+    B = 1
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 913, False, input_mask, input_depth)
+    assert net.cin == (10 if input_depth else 6) and "flow_conv1_weight" not in net.grad.tm and "conv2_weight" in net.grad.tm
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    try:
+        loss = net.forward_train(data, label).asnumpy()[0]
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    grads = net.backward()
+    t = cfg.train_iter
+    odata = dict(data_np)
+    if not input_mask:
+        odata["mask_observed"] = odata["mask_rendered"] = None      # oracle/zoom.py: ZoomImage computes the factor
+    ref_loss, g_ref, fwd = opipe.train_pose_iteration(params, odata, label_np, d["K"], MEANS_REV, cfg.dataset.trans_means,
+                                                      cfg.dataset.trans_stds, cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE,
+                                                      cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR)
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), fwd["net_input"])
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    for name in sorted(g_ref):
+        close(grads[name].asnumpy(), g_ref[name], 2e-4)
+    before = net.params["flow_conv1_weight"].asnumpy()
+    net.update(lr=1e-2, wd=cfg.TRAIN.wd, momentum=cfg.TRAIN.momentum)
+    w_ref, _ = onet.sgd_mom_update(before, np.zeros_like(before), g_ref["flow_conv1_weight"], 1e-2, cfg.TRAIN.wd, cfg.TRAIN.momentum)
+    np.testing.assert_allclose(net.params["flow_conv1_weight"].asnumpy(), w_ref, rtol=1e-4, atol=1e-7)
+
+
+def test_rebind_and_register_fed_wgrad_switch(ctx):
+    """(a) bind_train twice on one net object: update() must write the NEW parameters (its pointer table is rebuilt, ADVICE r3 —
+    the cached table pointed at the freed buffers of the first bind). (b) wgrad_lds = 0, the documented A/B switch: the training
+    step runs on the register-fed kernels with natural-layout gradients and agrees with the default path."""
+    B = 1
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 915, False)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    net.forward_train(data, label)
+    g1 = {k: v.asnumpy() for k, v in net.backward().items()}
+    net.update(lr=1e-2, wd=cfg.TRAIN.wd, momentum=cfg.TRAIN.momentum)
+    w_after_1 = net.params["conv3_weight"].asnumpy()
+    assert not np.array_equal(w_after_1, params["conv3_weight"])
+    lib.deepim_set_option(ctx.handle, b"wgrad_lds", 0)
+    try:
+        net.bind_train(ctx, B, params, num_points=3000)        # second bind: new params / mom / grad buffers
+        assert not net.grad.tm
+        np.testing.assert_array_equal(net.params["conv3_weight"].asnumpy(), params["conv3_weight"])
+        net.forward_train(data, label)
+        g2 = {k: v.asnumpy() for k, v in net.backward().items()}
+        for k in sorted(g1):
+            close(g2[k], g1[k].astype(np.float64), 2e-5)
+        net.update(lr=1e-2, wd=cfg.TRAIN.wd, momentum=cfg.TRAIN.momentum)
+        np.testing.assert_allclose(net.params["conv3_weight"].asnumpy(), w_after_1, rtol=1e-4, atol=1e-7)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"wgrad_lds", 1)
 
 
 def test_backward_on_two_streams_is_bit_identical(ctx):

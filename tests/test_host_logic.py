@@ -256,6 +256,43 @@ def test_rendezvous_moves_to_the_next_candidate_port_when_the_first_is_taken():
         squat.close()
 
 
+def _foreign_hub(port, q):
+    try:
+        parallel.Rendezvous(0, 2, "127.0.0.1", port, timeout=8.0, token="somebody-elses-job")
+        q.put("joined")
+    except Exception as e:      # noqa: BLE001 — its rank 1 never comes: times out, which is what the test expects
+        q.put(type(e).__name__)
+
+
+def test_rendezvous_skips_another_jobs_hub_on_the_first_port():
+    """Another deepim job of this host owns MASTER_PORT + 1 and speaks the protocol: its hub refuses our spoke (wrong token). The
+    spoke must go on to the next candidate port — where this job's hub had to move — instead of aborting on the refusal
+    (ADVICE r3), and the foreign hub must not be blocked by our stray connection."""
+    import multiprocessing as mp
+    import socket
+    import time
+    port = 39000 + os.getpid() % 2000
+    ctxm = mp.get_context("spawn")
+    qf, q = ctxm.Queue(), ctxm.Queue()
+    foreign = ctxm.Process(target=_foreign_hub, args=(port, qf))
+    foreign.start()
+    for _ in range(200):                      # wait until the foreign hub listens
+        try:
+            socket.create_connection(("127.0.0.1", port), timeout=0.2).close()
+            break
+        except OSError:
+            time.sleep(0.05)
+    procs = [ctxm.Process(target=_token_worker, args=(r, port, "job-secret", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90), q.get(timeout=90)])
+    for p in procs:
+        p.join(timeout=30)
+    assert res == [(0, [0.0, 1.0]), (1, [0.0, 1.0])], res
+    assert qf.get(timeout=30) == "RuntimeError"          # the foreign hub just timed out waiting for ITS rank 1
+    foreign.join(timeout=30)
+
+
 def test_rendezvous_needs_a_token_on_a_routable_address(monkeypatch):
     monkeypatch.delenv("DEEPIM_RDZV_TOKEN", raising=False)
     monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
