@@ -96,6 +96,10 @@ int deepim_comm_destroy(deepim_ctx* ctx);
 int deepim_allgather_poses(deepim_ctx* ctx, float* all_poses, const float* poses, int B);
 /* in-place all-reduce of n device doubles on the context stream: op 0 = max, 1 = sum (bench.py's max-over-ranks time) */
 int deepim_comm_allreduce_f64(deepim_ctx* ctx, double* buf, int n, int op);
+/* What this process bound, as text: "backend=rccl|none;rccl_ranks=N;rccl_version=V;librccl_path=…;libamdhip64_path=…" — the
+ * rank count is ncclCommCount of the context's communicator (0 without one), the paths are the files the ncclAllGather / hipMalloc
+ * symbols in use live in (dladdr). Reporting only (bench.py's `comm` block); no reference counterpart. */
+int deepim_comm_info(deepim_ctx* ctx, char* buf, int n);
 
 /* ------------------------------------------------ F-group: depth warp / flow -- */
 /* B2 drop-in. Same symbol, argument list and host-pointer contract as

@@ -21,6 +21,8 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;             // optional (reporting only)
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 RcclApi g_rccl;
 
@@ -48,6 +50,8 @@ int load_rccl() {
   DI_SYM(AllReduce, "ncclAllReduce");
   DI_SYM(GetErrorString, "ncclGetErrorString");
 #undef DI_SYM
+  *(void**)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
+  *(void**)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
   g_rccl.handle = h;
   return 0;
 }
@@ -119,5 +123,27 @@ extern "C" int deepim_comm_allreduce_f64(deepim_ctx* ctx, double* buf, int n, in
   DI_REQUIRE(n >= 0 && (op == 0 || op == 1), "comm_allreduce: bad arguments");
   if (n == 0 || !ctx->comm) return 0;
   DI_RCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  return 0;
+}
+
+// What this process actually bound ("nothing records which librccl / libamdhip64 a rank bound"): a text record
+//   backend=rccl|none;rccl_ranks=<ncclCommCount of this context's communicator, 0 without one>;rccl_version=<ncclGetVersion>;
+//   librccl_path=<file the ncclAllGather symbol in use lives in>;libamdhip64_path=<file the HIP runtime symbols in use live in>
+// written into buf (NUL-terminated, truncated to n). bench.py puts it into the `comm` block of its JSON line.
+extern "C" int deepim_comm_info(deepim_ctx* ctx, char* buf, int n) {
+  DI_REQUIRE(buf != nullptr && n > 0, "comm_info: no buffer");
+  int version = 0, ranks = 0;
+  const char* rccl_path = "";
+  Dl_info di;
+  if (g_rccl.handle) {
+    if (g_rccl.GetVersion) g_rccl.GetVersion(&version);
+    if (dladdr((void*)g_rccl.AllGather, &di) && di.dli_fname) rccl_path = di.dli_fname;
+    if (ctx && ctx->comm && g_rccl.CommCount) g_rccl.CommCount((ncclComm_t)ctx->comm, &ranks);
+  }
+  const char* hip_path = "";
+  Dl_info dh;
+  if (dladdr((void*)&hipGetDeviceCount, &dh) && dh.dli_fname) hip_path = dh.dli_fname;
+  snprintf(buf, (size_t)n, "backend=%s;rccl_ranks=%d;rccl_version=%d;librccl_path=%s;libamdhip64_path=%s",
+           (ctx && ctx->comm) ? "rccl" : "none", ranks, version, rccl_path, hip_path);
   return 0;
 }

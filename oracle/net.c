@@ -78,6 +78,58 @@ void oracle_conv2d(float* out, const float* in, const float* w, const float* bia
   oracle_conv2d_order(out, in, w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, 0);
 }
 
+/* The same convolution — every output the same float32 fmaf chain over (ci,ky,kx) as oracle_conv2d, hence bit-identical
+ * (tests/test_oracle_thirdparty.py) — laid out for the host cores instead of for readability: a task is one output row of a
+ * block of 8 output channels (B x Cout/8 x Ho tasks: thousands, whatever the layer), the accumulators live as [wo][8] so that
+ * the eight channels of a pixel are one AVX2 register (broadcast input value x 8 weights: vectorises for stride 1 and 2
+ * alike), and an input row is read once per 8 channels instead of once per channel. bench.py's `cpu_baseline` times THIS
+ * build (the stated baseline should use the cores it names); the checker stays oracle_conv2d_order. */
+void oracle_conv2d_blocked(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H, int W,
+                           int Cout, int kh, int kw, int stride, int pad, float slope) {
+  enum { CB = 8, WMAX = 1024 };
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  if (Wo > WMAX) { oracle_conv2d_order(out, in, w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, 0); return; }
+  const int khw = kh * kw, NCB = (Cout + CB - 1) / CB;
+#pragma omp parallel for collapse(3) schedule(dynamic, 4)
+  for (int n = 0; n < B; ++n)
+    for (int cb = 0; cb < NCB; ++cb)
+      for (int ho = 0; ho < Ho; ++ho) {
+        float acc[WMAX][CB] __attribute__((aligned(32)));
+        const int co0 = cb * CB, nc = Cout - co0 < CB ? Cout - co0 : CB;
+        memset(acc, 0, sizeof(float) * CB * (size_t)Wo);
+        for (int ci = 0; ci < Cin; ++ci)
+          for (int ky = 0; ky < kh; ++ky) {
+            const int hi = ho * stride - pad + ky;
+            if (hi < 0 || hi >= H) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+              float wv[CB] __attribute__((aligned(32)));
+              for (int c = 0; c < CB; ++c) wv[c] = c < nc ? w[((size_t)(co0 + c) * Cin + ci) * khw + ky * kw + kx] : 0.f;
+              int wo_lo = 0, wo_hi = Wo;
+              while (wo_lo < Wo && wo_lo * stride - pad + kx < 0) ++wo_lo;
+              while (wo_hi > wo_lo && (wo_hi - 1) * stride - pad + kx >= W) --wo_hi;
+              const float* row = in + (((size_t)n * Cin + ci) * H + hi) * W - pad + kx;
+              for (int wo = wo_lo; wo < wo_hi; ++wo) {
+                const float x = row[(size_t)wo * stride];
+                for (int c = 0; c < CB; ++c) acc[wo][c] = fmaf(wv[c], x, acc[wo][c]);
+              }
+            }
+          }
+        for (int c = 0; c < nc; ++c) {
+          const float bv = bias ? bias[co0 + c] : 0.f;
+          float* orow = out + (((size_t)n * Cout + co0 + c) * Ho + ho) * Wo;
+          for (int wo = 0; wo < Wo; ++wo) orow[wo] = lrelu(acc[wo][c] + bv, slope);
+        }
+      }
+}
+
+int oracle_omp_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 /* MXNet Deconvolution k4 s2 p0, w (Cin,Cout,4,4), cropped at (crop_y,crop_x) to (Ho,Wo). */
 void oracle_deconv4x4s2_crop(float* out, const float* in, const float* w, const float* bias, int B, int Cin, int H,
                              int W, int Cout, int Ho, int Wo, int crop_y, int crop_x, float slope) {

@@ -33,6 +33,15 @@ def _c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=f32)
 
 
+# bench.py's cpu_baseline sets this: canonical-order convolutions then run on the cache-blocked OpenMP build
+# (oracle_conv2d_blocked: the same fmaf chain per output, bit-identical, laid out for the host cores)
+BLOCKED = False
+
+
+def omp_threads():
+    return int(_lib().oracle_omp_threads())
+
+
 def conv2d(x, w, b, stride, pad, slope=1.0, pair_order=False):
     """pair_order: False/0 = (ci, ky, kx); True/1 = (ci/2, ky, kx, ci%2); 2 = (ci/8, ky, kx, s, h), channel 8(ci/8)+s+4h
     — the accumulation orders of the three MI355X conv kernels, see net.c."""
@@ -42,6 +51,9 @@ def conv2d(x, w, b, stride, pad, slope=1.0, pair_order=False):
     assert not pair_order or Cin % (8 if int(pair_order) == 2 else 2) == 0
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     out = np.empty((B, Cout, Ho, Wo), f32)
+    if BLOCKED and not pair_order:
+        _lib().oracle_conv2d_blocked(_p(out), _p(x), _p(w), _p(b), B, Cin, H, W, Cout, kh, kw, stride, pad, ctypes.c_float(slope))
+        return out
     _lib().oracle_conv2d_order(_p(out), _p(x), _p(w), _p(b), B, Cin, H, W, Cout, kh, kw, stride, pad, ctypes.c_float(slope),
                                int(pair_order))
     return out

@@ -9,7 +9,7 @@ bench.py times) against the CPU oracle:
             mask / flow heads).  Bars: flow ≤ 1e-4, mask flips < 1e-4 of the pixels, se3 ≤ 1e-4.
   configs 3 and 4 run twice: on the default fp32 kernels and with network.X3_CONV (split-fp16 convs) — the same bars.
   config 5  ModelNet RGB-D: INPUT_DEPTH=True (C_in = 10 → padded to 16 in the fp16 NHWC layout), conv stack on the
-            fp16 matrix cores.  Bars (fp16 cannot meet 1e-4): conv6_1 ≤ 5e-3, se3 ≤ 5e-3, pose ≤ 2e-3 against the oracle's
+            fp16 matrix cores.  Bars (fp16 cannot meet 1e-4): conv6_1 ≤ 2e-3, se3 ≤ 1e-3, pose ≤ 1e-4 against the oracle's
             fp16 emulation (fp16-rounded operands/outputs, fp32 accumulate).
 """
 import numpy as np
@@ -184,9 +184,9 @@ def test_config5_rgbd_input_fp16_conv_path(ctx):
     np.testing.assert_array_equal(net.act["zoom_factor"].asnumpy(), emu["zoom_factor"])
     assert np.abs(emu["net_input"][:, 6:8]).max() > 0                                   # the depth channels carry data
     c = net.act["conv6_1"].asnumpy()
-    assert np.abs(c - emu["conv6_1"]).max() <= 5e-3 * np.abs(emu["conv6_1"]).max()
-    assert rel(net.act["se3"].asnumpy(), emu["se3"]) < 5e-3
-    assert rel(pose, emu["pose_est"]) < 2e-3
+    assert np.abs(c - emu["conv6_1"]).max() <= 2e-3 * np.abs(emu["conv6_1"]).max()
+    assert rel(net.act["se3"].asnumpy(), emu["se3"]) < 1e-3
+    assert rel(pose, emu["pose_est"]) < 1e-4
 
 
 def test_config5_rgbd_input_split_fp16_meets_the_fp32_bar(ctx):

@@ -30,7 +30,8 @@ def test_bench_line_single_gpu():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["unit"] == "pose-refinement iters/sec" and d["dtype"] == "f32" and d["scaling"] == "weak"
+    assert d["unit"] == "pose-refinement iters/sec" and d["dtype"] == "f32" and d["scaling"] == "strong"
+    assert d["comm"]["backend"] == "none" and d["comm"]["rccl_ranks"] == 0 and "libamdhip64" in d["comm"]["libamdhip64_path"]
     assert abs(d["value"] - 2 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
@@ -58,7 +59,7 @@ def test_bench_reports_parity_of_the_timed_configuration(extra, bar):
 
 def test_bench_parity_heads_and_config5_modes():
     """The same field for `--heads` (config 4 mode: + flow <= 1e-4, mask flips <= 1e-4 of the pixels) and for config 5 as
-    written (`--fp16 --depth`: RGB-D input, against the oracle's fp16 emulation, bars 2e-3 / 5e-3)."""
+    written (`--fp16 --depth`: RGB-D input, against the oracle's fp16 emulation, bars 1e-4 / 1e-3)."""
     for extra in (["--heads", "--batch", "4"], ["--fp16", "--depth", "--batch", "8"]):
         r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
                             "--verify", "1"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
@@ -109,9 +110,20 @@ def _run_two_ranks(port, extra):
 
 
 def test_bench_two_ranks_weak_scaling_dry_run():
-    d = _run_two_ranks(29671, ["--batch", "2"])
+    d = _run_two_ranks(29671, ["--weak", "--batch", "2"])
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 2 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["comm"]["backend"] == "tcp-host-requested" and d["comm"]["rccl_ranks"] == 0 and d["comm"]["allgather_us"] > 0
+
+
+def test_bench_two_ranks_default_is_strong_scaling_of_the_global_batch():
+    """What the driver passes is `--gpus N` only: the batch is then GLOBAL (here --batch 4 → 2 per rank), strong scaling, and the
+    default run appends the weak-scaling figure (--batch per GPU) to other_configs."""
+    d = _run_two_ranks(29673, ["--batch", "4"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 4 and d["config"]["shard_counts"] == [2, 2]
+    assert abs(d["value"] - 4 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and "bs4" in d["metric"]
+    w = d["other_configs"]["weak_scaling_batch4_per_gpu"]
+    assert w["scaling"] == "weak" and w["global_batch"] == 8 and w["value"] > 0
 
 
 def test_bench_two_ranks_strong_scaling_ragged_dry_run():
@@ -123,24 +135,34 @@ def test_bench_two_ranks_strong_scaling_ragged_dry_run():
 
 def test_bench_two_ranks_default_backend_agrees_on_the_rendezvous_fallback():
     """The driver's own command line (RCCL backend) with two ranks on ONE visible GPU: RCCL refuses the duplicate device at
-    communicator init, every rank learns it over the rendezvous, all fall back to the rendezvous exchange and the line says so —
-    the run still measures. (On a multi-GPU node the same code path keeps RCCL and `parallelism` names ncclAllGather.)"""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    env.pop("DEEPIM_BENCH_BACKEND", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29679", "bench.py", "--gpus", "2", "--steps", "1",
-                        "--warmup", "1", "--batch", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    communicator init and every rank learns it over the rendezvous. Without --allow-comm-fallback the run REFUSES (exit code 3 on
+    every rank, no JSON line: a TCP number must not pass for an xGMI one); with it all ranks fall back to the rendezvous exchange
+    and the line says so, machine-readably (`comm.backend`). (On a multi-GPU node the same code path keeps RCCL.)"""
     import ctypes
     from mx_deepim_amd.runtime import lib
     ndev = ctypes.c_int(0)
     lib.load().deepim_device_count(ctypes.byref(ndev))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("DEEPIM_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29679", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4", "--no-other-configs"]
     if ndev.value < 2:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.stdout[-1500:], r.stderr[-1500:])
+        assert "RCCL unavailable" in r.stderr and "--allow-comm-fallback" in r.stderr
+        cmd[cmd.index("29679")] = "29683"
+        cmd.append("--allow-comm-fallback")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["shard_counts"] == [2, 2]
+    if ndev.value < 2:
+        assert d["comm"]["backend"] == "tcp-fallback" and d["comm"]["rccl_ranks"] == 0 and "RCCL unavailable" in d["comm"]["note"]
         assert "RCCL unavailable" in d["config"]["parallelism"] and "rendezvous" in d["config"]["parallelism"], d["config"]
         assert "RCCL unavailable" in r.stderr
     else:
+        assert d["comm"]["backend"] == "rccl" and d["comm"]["rccl_ranks"] == 2 and d["comm"]["allgather_us"] > 0
+        assert "librccl" in d["comm"]["librccl_path"] and d["comm"]["all_ranks_same_libraries"]
         assert "ncclAllGather" in d["config"]["parallelism"], d["config"]
 
 
@@ -168,5 +190,11 @@ def test_rccl_entry_points_world_size_one(ctx):
         np.testing.assert_array_equal(t.asnumpy(), [1.25, -3.0])
         with __import__("pytest").raises(RuntimeError):
             lib.deepim_comm_init(ctx.handle, 0, 1, uid)             # already initialised
+        # what this process bound: RCCL's own rank count, its version and the files the symbols in use live in
+        buf = ctypes.create_string_buffer(2048)
+        lib.deepim_comm_info(ctx.handle, buf, 2048)
+        rec = dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+        assert rec["backend"] == "rccl" and rec["rccl_ranks"] == "1" and int(rec["rccl_version"]) > 20000, rec
+        assert "librccl" in rec["librccl_path"] and "libamdhip64" in rec["libamdhip64_path"], rec
     finally:
         lib.deepim_comm_destroy(ctx.handle)

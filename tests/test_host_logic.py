@@ -300,7 +300,7 @@ def test_rendezvous_needs_a_token_on_a_routable_address(monkeypatch):
         parallel.Rendezvous(1, 2, "10.1.2.3", 29999, timeout=1.0)
 
 
-@pytest.mark.parametrize("global_batch,counts", [(32, [4] * 8), (13, [2, 2, 2, 2, 2, 1, 1, 1])])
+@pytest.mark.parametrize("global_batch,counts", [(None, [4] * 8), (32, [4] * 8), (13, [2, 2, 2, 2, 2, 1, 1, 1])])
 def test_eight_rank_launch_rehearsal(global_batch, counts):
     """The driver's 8-GPU command line, without GPUs: `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8
     --global-batch G --dry-run` — bench.py's own rank/env handling, rendezvous, RCCL-id broadcast, shard bounds, padded
@@ -310,10 +310,14 @@ def test_eight_rank_launch_rehearsal(global_batch, counts):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 36000 + os.getpid() % 2000 + global_batch
+    # global_batch None = what the DRIVER passes (`--gpus 8` and nothing else about the batch): the default must be BASELINE
+    # configs[2] as written — a global batch of 32 sharded 4 per GPU, strong scaling
+    port = 36000 + os.getpid() % 2000 + (global_batch or 57)
+    extra = [] if global_batch is None else ["--global-batch", str(global_batch)]
+    global_batch = global_batch or 32
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--global-batch", str(global_batch), "--dry-run"], cwd=root, capture_output=True, text=True, timeout=900,
+                        "--dry-run"] + extra, cwd=root, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -324,3 +328,47 @@ def test_eight_rank_launch_rehearsal(global_batch, counts):
     assert d["config"]["pairs_per_gpu"] == counts[0]
     assert abs(d["value"] - global_batch * 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert ("bs%d" % global_batch) in d["metric"]
+    # the machine-readable exchange record (a dry run has no RCCL: says so, names the HIP runtime every rank would bind)
+    c = d["comm"]
+    assert c["backend"] == "host-dry-run" and c["rccl_ranks"] == 0 and c["ranks_reporting"] == 8 and c["allgather_us"] is None
+    assert "libamdhip64" in (c["libamdhip64_path"] or "")
+
+
+def test_weak_scaling_is_opt_in():
+    """`--weak`: --batch pairs PER rank (the pre-round-4 default), labelled weak."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 38100 + os.getpid() % 1500
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--weak", "--batch", "3", "--dry-run"], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 6 and d["config"]["shard_counts"] == [3, 3] and "bs3" in d["metric"]
+
+
+def test_cpu_baseline_follows_the_stated_protocol():
+    """bench.py's `cpu_baseline` (BASELINE.md section 3): one untimed warm-up pair-iteration, then the timed ones, value = 1 / median;
+    the record names the threads used, nproc and OMP_NUM_THREADS. (Two timed runs here; the bench takes >= 5.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from mx_deepim_amd import synthetic
+    from mx_deepim_amd.config import default_config
+    from mx_deepim_amd.symbols import deepIM_flownet
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    params = net.init_weights(cfg, seed=5)
+    batch = synthetic.make_batch(2, seed=7, n_frames=1)
+    r = bench.cpu_baseline(params, cfg, batch, budget_s=0.0, min_runs=2, max_runs=2)
+    sp = r["seconds_per_iteration"]
+    assert r["kind"] == "port" and r["cores"] >= 1 and r["nproc"] == os.cpu_count() and "omp_num_threads" in r
+    assert abs(r["value"] - 1.0 / sp["median"]) < 1e-9 * r["value"] and sp["min"] <= sp["median"] <= sp["max"]
+    assert "1 untimed warm-up" in r["protocol"] and "2 timed" in r["protocol"]
+    from oracle import net as onet
+    assert onet.BLOCKED is False            # the timing switch is reset: the checker stays the checker

@@ -85,6 +85,27 @@ def test_conv_order_switch_matches_torch_and_itself():
     np.testing.assert_array_equal(onet.conv2d(xi, wi, None, 1, 1, 1.0), onet.conv2d(xi, wi, None, 1, 1, 1.0, pair_order=True))
 
 
+@pytest.mark.parametrize("case", [(2, 8, 33, 41, 64, 7, 2, 3), (1, 13, 16, 20, 21, 5, 2, 2), (2, 16, 12, 14, 24, 3, 1, 1),
+                                  (1, 64, 30, 40, 128, 5, 2, 2), (1, 5, 9, 11, 3, 3, 1, 1)])
+def test_blocked_conv_build_is_bit_identical_to_the_checker(case):
+    """oracle_conv2d_blocked — the cache-blocked OpenMP build bench.py's `cpu_baseline` times — runs, per output, the same
+    float32 fmaf chain over (ci,ky,kx) as the checker oracle_conv2d: equal bit for bit, ragged channel blocks and borders
+    included."""
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    want = onet.conv2d(x, w, b, s, p, 0.1)
+    onet.BLOCKED = True
+    try:
+        got = onet.conv2d(x, w, b, s, p, 0.1)
+    finally:
+        onet.BLOCKED = False
+    np.testing.assert_array_equal(got, want)
+    assert onet.omp_threads() >= 1
+
+
 def test_oracle_backward_matches_torch_autograd():
     """oracle/net.c conv / FC backward and the LeakyReLU / SGD helpers against torch autograd / torch.optim.SGD-style math."""
     torch = pytest.importorskip("torch")
