@@ -714,7 +714,8 @@ def other_configs(left=lambda: 1e9):
 
     def training():
         # SURVEY 8f-4 (module.backward + sgd of the reference's training loop) at the per-GPU share of config 4, tools/bench_train.py
-        for name, extra in (("training_iteration_heads_batch4", ["4", "heads", "json"]), ("training_iteration_pose_branch_batch4", ["4", "json"])):
+        for name, extra in (("training_iteration_heads_batch4", ["4", "heads", "json"]), ("training_iteration_pose_branch_batch4", ["4", "json"]),
+                            ("training_step_x4_batch4", ["4", "heads", "step4", "json"])):
             if left() < 30:
                 res[name] = {"skipped": "extras budget spent"}
                 continue

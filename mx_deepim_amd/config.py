@@ -41,6 +41,7 @@ def default_config():
         ROT_COORD="CAMERA",
         REGRESSOR_NUM=1,
         STANDARD_FLOW_REP=False,
+        TRAIN_ITER=True, TRAIN_ITER_SIZE=4,   # yaml :57-58 — refinement iterations inside one training step (module.py:1131-1137)
         X3_CONV=False,     # split-fp16 conv path: fp32-grade accuracy (≈1e-6) on the fp16 matrix cores (not a reference key)
         FP16_CONV=False,   # BASELINE config 5: fp16 conv path (not a reference key; the reference is fp32 only)
     )

@@ -31,47 +31,75 @@ class batchUpdaterPyMulti(object):
         self.Kinv = np.ascontiguousarray(np.linalg.inv(self.K))   # float32, as np.linalg.inv(np.matrix(K)) gives
         self._rc = ROT_COORD_CODE[self.rot_coord.lower()]
 
-    def forward(self, data_batch, preds, big_cfg=None):
+    def workspace(self, ctx, B):
+        """Preallocated outputs for `forward(..., out=ws)`: a resident training step (deepIM_flownet.train_step) updates its batch
+        TRAIN_ITER_SIZE - 1 times per step and must not allocate inside the loop. The buffers are rewritten by every call — the
+        previous iteration's forward/backward has consumed them by then (module.py:1131-1137 runs the updater after update())."""
+        H, W = self.height, self.width
+        ws = {"se3": ctx.empty((B, 7)), "src_pose": ctx.empty((B, 3, 4)), "image_rendered": ctx.empty((B, 3, H, W)),
+              "depth_rendered": ctx.empty((B, 1, H, W)), "rot": ctx.empty((B, 4)), "trans": ctx.empty((B, 3))}
+        if self.big_cfg.network.PRED_FLOW:
+            ws.update(KT=ctx.empty((B, 3, 4)), flow=ctx.empty((B, 2, H, W)), valid=ctx.empty((B, 1, H, W)),
+                      flow_weights=ctx.empty((B, 2, H, W)))
+        if self.big_cfg.network.INPUT_MASK:
+            ws["mask_rendered"] = ctx.empty((B, 1, H, W))
+        return ws
+
+    def forward(self, data_batch, preds, big_cfg=None, out=None):
         """data_batch: dict name -> DeviceArray with src_pose, tgt_pose (B,3,4) [, depth_gt_observed (B,1,H,W),
-        class_index]; preds: dict with rot_est (B,4), trans_est (B,3) (or se3 (B,7)). Returns the updated batch."""
+        class_index]; preds: dict with rot_est (B,4), trans_est (B,3) (or se3 (B,7)). Returns the updated batch.
+        `out`: a `workspace()` whose buffers receive the results instead of fresh allocations."""
         cfg = big_cfg or self.big_cfg
         src_pose, tgt_pose = data_batch["src_pose"], data_batch["tgt_pose"]
         ctx, h = src_pose.context, src_pose.context.handle
         B, H, W = src_pose.shape[0], self.height, self.width
+        out = out or {}
+
+        def buf(name, shape):
+            return out[name] if name in out else ctx.empty(shape)
         if "se3" in preds:
             se3 = preds["se3"]
         else:
-            se3 = ctx.empty((B, 7))
+            se3 = buf("se3", (B, 7))
             lib.deepim_copy_channels(h, se3, 7, 0, preds["rot_est"], 4, B, 1)
             lib.deepim_copy_channels(h, se3, 7, 4, preds["trans_est"], 3, B, 1)
-        # 1. refined pose
-        refined_pose = ctx.empty((B, 3, 4))
+        # 1. refined pose (in place when src_pose already is the workspace buffer: the kernel reads a pose before it writes it)
+        refined_pose = buf("src_pose", (B, 3, 4))
         lib.deepim_rt_transform(h, refined_pose, None, src_pose, se3, self.T_means, self.T_stds, self._rc, B)
         # 2. re-render at the refined pose (outside the path)
-        if self.render_machine is not None:
+        fused_mask = None
+        if self.render_machine is not None and "image_rendered" in out:
+            image_rendered, depth_rendered = out["image_rendered"], out["depth_rendered"]
+            fused_mask = out.get("mask_rendered") if cfg.network.INPUT_MASK else None
+            self.render_machine.render_batch(data_batch.get("class_index"), refined_pose, out=(image_rendered, depth_rendered),
+                                             mask_rendered=fused_mask, mask_thresh=0.2)
+        elif self.render_machine is not None:
             image_rendered, depth_rendered = self.render_machine.render_batch(data_batch.get("class_index"), refined_pose)
         else:
             image_rendered, depth_rendered = data_batch["next_image_rendered"], data_batch["next_depth_rendered"]
         # 3. residual delta = new labels
-        rot, trans = ctx.empty((B, 4)), ctx.empty((B, 3))
+        rot, trans = buf("rot", (B, 4)), buf("trans", (B, 3))
         lib.deepim_calc_rt_delta(h, rot, trans, refined_pose, tgt_pose, self.T_means, self.T_stds, self._rc, B)
         update_package = {"image_rendered": image_rendered, "depth_rendered": depth_rendered, "src_pose": refined_pose,
                           "rot": rot, "trans": trans}
         # 4./5. K·T and ground-truth flow rendered → observed
         if cfg.network.PRED_FLOW:
-            KT = ctx.empty((B, 3, 4))
+            KT = buf("KT", (B, 3, 4))
             lib.deepim_calc_KT(h, KT, refined_pose, tgt_pose, self.K, B)
-            flow, valid = ctx.empty((B, 2, H, W)), ctx.empty((B, 1, H, W))
+            flow, valid = buf("flow", (B, 2, H, W)), buf("valid", (B, 1, H, W))
             lib.deepim_flow_forward(h, flow, valid, depth_rendered, data_batch["depth_gt_observed"], KT, self.Kinv, B, H, W)
-            flow_weights = ctx.empty((B, 2, H, W))          # np.tile(valid, [1, 2, 1, 1])
+            flow_weights = buf("flow_weights", (B, 2, H, W))          # np.tile(valid, [1, 2, 1, 1])
             lib.deepim_copy_channels(h, flow_weights, 2, 0, valid, 1, B, H * W)
             lib.deepim_copy_channels(h, flow_weights, 2, 1, valid, 1, B, H * W)
             update_package["flow"] = flow
             update_package["flow_weights"] = flow_weights
         # 6. rendered mask
         if cfg.network.INPUT_MASK:
-            mask = ctx.empty((B, 1, H, W))
-            lib.deepim_depth_to_mask(h, mask, depth_rendered, ctypes.c_float(0.2), B * H * W)
+            if fused_mask is not None:          # written by the render pass itself (depth > 0.2 in its resolve kernel)
+                mask = fused_mask
+            else:
+                mask = buf("mask_rendered", (B, 1, H, W))
+                lib.deepim_depth_to_mask(h, mask, depth_rendered, ctypes.c_float(0.2), B * H * W)
             update_package["mask_rendered"] = mask
         return self.update_data_batch(data_batch, update_package)
 

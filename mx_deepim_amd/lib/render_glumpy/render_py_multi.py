@@ -131,12 +131,13 @@ class Render_Py(object):
             lib.deepim_render_update_forward(self.ctx.handle, image, depth, mask_rendered, mask_box,
                                              ctypes.c_float(mask_thresh), *tail)
 
-    def render_batch(self, class_index, poses, K=None):
+    def render_batch(self, class_index, poses, K=None, out=None, mask_rendered=None, mask_thresh=0.2):
         """poses (B,3,4) device; class_index: scalar, host sequence of B class ids, or None (= class 0).
-        Samples of the same class in consecutive runs are drawn by one launch group."""
+        Samples of the same class in consecutive runs are drawn by one launch group. `out` = (image, depth) preallocated device
+        tensors; `mask_rendered` (B,1,H,W): also written, = depth > mask_thresh, by the same pass."""
         B = poses.shape[0]
-        image = self.ctx.empty((B, 3, self.height, self.width))
-        depth = self.ctx.empty((B, 1, self.height, self.width))
+        image, depth = out if out is not None else (self.ctx.empty((B, 3, self.height, self.width)),
+                                                    self.ctx.empty((B, 1, self.height, self.width)))
         if class_index is None:
             ids = np.zeros(B, np.int64)
         else:
@@ -147,7 +148,8 @@ class Render_Py(object):
             b1 = b0 + 1
             while b1 < B and ids[b1] == ids[b0]:
                 b1 += 1
-            self.render_into(image[b0:b1], depth[b0:b1], ids[b0], poses[b0:b1], K=K)
+            self.render_into(image[b0:b1], depth[b0:b1], ids[b0], poses[b0:b1], K=K,
+                             mask_rendered=None if mask_rendered is None else mask_rendered[b0:b1], mask_thresh=mask_thresh)
             b0 = b1
         return image, depth
 

@@ -608,6 +608,7 @@ def _train_methods():
         w7[0:4].copyfrom(self.params["rot_weight"]); w7[4:7].copyfrom(self.params["trans_weight"])
         self.params["rot_weight"], self.params["trans_weight"] = w7[0:4], w7[4:7]
         self.grad = _Grads(ctx, {name: ctx.zeros(a.shape) for name, a in self.params.items()})
+        self._upd_ws = None        # train_step's batch-updater workspace is sized for the bound batch
         self._sgd_table = None     # its rows hold raw pointers of the buffers allocated here: never reuse one across binds
         # tap-major weight gradients (deepim_conv2d_wgrad_tm) only where that entry applies: Cin % 8 == 0 and the LDS-staged
         # kernel selected on this context. Everything else (conv1 of the 6- / 10-channel inputs, wgrad_lds = 0) takes
@@ -887,6 +888,38 @@ def _train_methods():
         if self.B > self.FC6_PLAIN_MAX_BATCH:      # small batches read fc6's raw weights (_fc6)
             lib.deepim_fc_pack_weights(h, self.packed["fc6"], self.params["fc6_weight"], 256, 1024 * 8 * 10)
 
+    def train_step(self, data, label, updater, iters=None, lr=None, wd=None, momentum=None, on_iter=None):
+        """ONE training step as the reference runs it (deepim/core/module.py:1131-1137 with network.TRAIN_ITER_SIZE = 4, yaml
+        :57-58): for every refinement iteration forward_backward → preds (rot_est, trans_est) → update (SGD + re-pack), and between
+        iterations `interBatchUpdater.forward(data_batch, preds)` (lib/pair_matching/batch_updater_py_multi.py:91-328): pose ←
+        RT_transform(src_pose, preds), re-render at it, new rot / trans labels (calc_RT_delta), K·T + lib/flow_c flow labels and
+        weights, mask_rendered = depth > 0.2 — all resident, nothing allocated inside the loop, no host round trip.
+        data must also carry tgt_pose [, depth_gt_observed with PRED_FLOW, class_index]; `updater` = batchUpdaterPyMulti with a
+        device render machine. `on_iter(it, data, label)` is called after each iteration's update (tests, timers).
+        Returns (data, label) of the last iteration."""
+        t = self.cfg.TRAIN
+        iters = int(iters or self.cfg.network.TRAIN_ITER_SIZE)
+        lr = t.lr if lr is None else lr
+        wd = t.wd if wd is None else wd
+        momentum = t.momentum if momentum is None else momentum
+        if getattr(self, "_upd_ws", None) is None or self._upd_ws[0] is not updater:
+            self._upd_ws = (updater, updater.workspace(self.ctx, self.B))
+        A = self.act
+        for it in range(iters):
+            self.forward_train(data, label)
+            self.backward()
+            preds = {"rot_est": A["rot_norm"], "trans_est": A["trans_est"]}     # get_outputs() before update(), as :1133-1134
+            self.update(lr, wd, momentum)
+            if on_iter is not None:
+                on_iter(it, data, label)
+            if it != iters - 1:
+                batch = dict(label)
+                batch.update(data)
+                new = updater.forward(batch, preds, self.cfg, out=self._upd_ws[1])
+                data = {k: new[k] for k in data}
+                label = {k: new[k] for k in label}
+        return data, label
+
     def _train_pack_orders(self):
         """layer → the ONE packed operand order its forward convolution reads in the training graph (NCHW activations,
         deepim_conv_weight_order): the per-step re-pack writes only that one."""
@@ -899,7 +932,7 @@ def _train_methods():
 
     return dict(bind_train=bind_train, forward_train=forward_train, _dgrad=_dgrad,
                 _small_conv_backward=_small_conv_backward, _head_conv_backward=_head_conv_backward,
-                _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update,
+                _deconv_backward=_deconv_backward, _decoder_backward=_decoder_backward, backward=backward, update=update, train_step=train_step,
                 _train_pack_orders=_train_pack_orders)
 
 

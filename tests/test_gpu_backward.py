@@ -669,3 +669,99 @@ def test_training_with_heads_reduces_all_three_losses(ctx):
         last = losses()
     assert all(np.isfinite(last))
     assert last[0] < first[0] and last[1] < first[1] and last[2] < first[2], (first, last)
+
+
+def test_train_step_chains_iterations_through_the_batch_updater(ctx):
+    """The reference's training step (module.py:1131-1137, TRAIN_ITER_SIZE iterations with batchUpdaterPyMulti.forward between
+    them) composed on the device: `net.train_step`. B = 2, decoder + flow + mask heads, two chained iterations:
+      * iteration 1 = forward_train / backward / update (checked against the oracle elsewhere in this file);
+      * the update between them, against the oracle composition fed the GPU's own predictions: refined pose = RT_transform
+        (<= 1e-6), rot / trans labels = calc_RT_delta (<= 1e-5), re-rendered depth bit-exact and colour <= 1e-3 against
+        oracle/render.py, mask_rendered = depth > 0.2 bit-exact, flow labels and weights = lib/flow_c on the new depth (flags flip
+        on < 1e-4 of the pixels: K·T may differ in the last ulp; flow <= 1e-4 elsewhere);
+      * iteration 2 — forward + backward on the UPDATED batch with the UPDATED weights — against the oracle's training
+        iteration on exactly that batch and those weights: net input bit-exact, losses <= 1e-4, all 42 gradients <= 2e-4."""
+    from oracle import flow as oflow
+    from oracle import render as orender
+    from oracle import se3 as ose3
+    from mx_deepim_amd.lib.pair_matching.batch_updater_py_multi import batchUpdaterPyMulti
+    from mx_deepim_amd.lib.render_glumpy.render_py_multi import Render_Py
+    B, H, W = 2, 480, 640
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 77, True)
+    assert cfg.network.TRAIN_ITER_SIZE == 4        # yaml :58
+    mesh = synthetic.ellipsoid_mesh([0.05, 0.04, 0.035], 24, 48)
+    mesh.pop("uv")
+    K = d["K"]
+    rm = Render_Py("unused", ["obj"], K, W, H, meshes={"obj": mesh}, ctx=ctx, pixel_means=MEANS_REV.copy())
+    upd = batchUpdaterPyMulti(cfg, H, W, render_machine=rm)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    data.update(tgt_pose=ctx.array(d["pose_tgt"]), depth_gt_observed=ctx.array(d["depth_gt_observed"]))
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    snaps = []
+
+    def on_iter(it, dat, lab):       # after update(): the batch this iteration ran on, its predictions, the weights it leaves
+        snaps.append({"data": {k: v.asnumpy() for k, v in dat.items()}, "label": {k: v.asnumpy() for k, v in lab.items()},
+                      "rot_est": net.act["rot_norm"].asnumpy(), "trans_est": net.act["trans_est"].asnumpy(),
+                      "net_input": net.act["net_input"].asnumpy(), "pm_loss": float(net.act["pm_loss_sum"].asnumpy()[0]),
+                      "flow_loss": float(net.act["flow_loss_sum"].asnumpy()[0]),
+                      "grads": {k: v.asnumpy() for k, v in net.grad.items()} if it == 1 else None,
+                      "params_before": params_before[0]})
+        params_before[0] = {k: v.asnumpy() for k, v in net.params.items()}
+
+    params_before = [{k: np.array(v) for k, v in params.items()}]
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)     # forward convs as single canonical chains: LeakyReLU kinks line up
+    try:
+        net.train_step(data, label, upd, iters=2, lr=1e-3, on_iter=on_iter)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    s0, s1 = snaps
+    # ---- the update between the iterations, from the GPU's own predictions
+    mu, sd = cfg.dataset.trans_means, cfg.dataset.trans_stds
+    src0 = s0["data"]["src_pose"]
+    ref_pose = np.stack([ose3.RT_transform(src0[b], s0["rot_est"][b], s0["trans_est"][b], mu, sd, "CAMERA") for b in range(B)])
+    pose1 = s1["data"]["src_pose"]
+    np.testing.assert_allclose(pose1, ref_pose, rtol=1e-6, atol=1e-7)
+    assert np.abs(pose1 - src0).max() > 1e-5                      # the pose really moved
+    dep1 = s1["data"].get("depth_rendered")
+    if dep1 is None:                                              # INPUT_DEPTH off: the depth is not a data entry; read the workspace
+        dep1 = net._upd_ws[1]["depth_rendered"].asnumpy()
+    for b in range(B):
+        ri, rd = orender.render(mesh["vertices"], mesh["colors"], mesh["faces"], pose1[b], K, H, W, pixel_means=MEANS_REV)
+        np.testing.assert_array_equal(dep1[b, 0], rd)
+        np.testing.assert_allclose(s1["data"]["image_rendered"][b], ri, atol=1e-3)
+    np.testing.assert_array_equal(s1["data"]["mask_rendered"], (dep1 > 0.2).astype(np.float32))
+    KT = oflow.calc_KT(pose1, d["pose_tgt"], K)
+    rf, rv = oflow.gpu_flow(dep1, d["depth_gt_observed"], KT, np.linalg.inv(K).astype(np.float32))
+    gv = s1["label"]["flow_weights"]
+    assert np.mean(gv[:, :1] != rv) < 1e-4
+    np.testing.assert_array_equal(gv[:, 0], gv[:, 1])
+    same = np.broadcast_to(gv[:, :1] == rv, rf.shape)
+    np.testing.assert_allclose(s1["label"]["flow"][same], rf[same], rtol=1e-4, atol=1e-4)
+    assert np.count_nonzero(gv) > 1000
+    # what the updater must NOT touch (training keeps them: data_pair.py's rectangle update is the TEST loop's)
+    for k in ("image_observed", "mask_observed"):
+        np.testing.assert_array_equal(s1["data"][k], s0["data"][k])
+    for k in ("mask_gt_observed", "point_cloud_model", "point_cloud_observed", "point_cloud_weights"):
+        np.testing.assert_array_equal(s1["label"][k], s0["label"][k])
+    # the weights moved between the iterations
+    assert not np.array_equal(s1["params_before"]["conv3_weight"], s0["params_before"]["conv3_weight"])
+    # ---- iteration 2 against the oracle on the same batch and weights
+    t = cfg.train_iter
+    odata = {k: s1["data"][k] for k in ("image_observed", "image_rendered", "mask_observed", "mask_rendered", "src_pose")}
+    ref_loss, g_ref, fwd = opipe.train_iteration(s1["params_before"], odata, s1["label"], K, MEANS_REV, mu, sd, cfg.network.ROT_COORD,
+                                                 t.LW_PM, t.NUM_3D_SAMPLE, cfg.dataset.NORMALIZE_3D_POINT, t.SE3_PM_LOSS_TYPE,
+                                                 t.SE3_PM_SL1_SCALAR, pred_flow=True, pred_mask=True, lw_flow=t.LW_FLOW,
+                                                 lw_mask=t.LW_MASK, normalize_flow=cfg.dataset.NORMALIZE_FLOW)
+    np.testing.assert_array_equal(s1["net_input"], fwd["net_input"])
+    assert abs(s1["pm_loss"] - ref_loss) <= 1e-4 * abs(ref_loss)
+    assert abs(s1["flow_loss"] - fwd["flow_loss_sum"]) <= 1e-4 * abs(fwd["flow_loss_sum"])
+    assert set(s1["grads"]) == set(g_ref)
+    for name in sorted(g_ref):
+        if name.endswith("upsampling_weight"):
+            assert not s1["grads"][name].any()
+            continue
+        close(s1["grads"][name], g_ref[name], 2e-4)
+    # and the full step (TRAIN_ITER_SIZE = 4 iterations) runs resident: no allocation inside after the first call, finite losses
+    seen = []
+    net.train_step(data, label, upd, lr=1e-4, on_iter=lambda it, dat, lab: seen.append(float(net.act["pm_loss_sum"].asnumpy()[0])))
+    assert len(seen) == 4 and all(np.isfinite(seen))
