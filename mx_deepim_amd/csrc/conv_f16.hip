@@ -609,6 +609,273 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
   if (X3) x3_report(amax, p.status);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel (round 4): ONE 8-wave block per CU on a 256x256 (Cout % 256 == 0) or 128x512 (conv2) tile, the two waves of
+// every SIMD alternating between a MEMORY segment (6 fragment reads of one k16-step + its share of the LDS-DMA pieces) and a
+// MATRIX segment (the 8 MFMAs of that k-step under s_setprio 1), separated by raw s_barriers — the 8-phase structure of the
+// CDNA4 guide (cdna_hip_programming.md §5 "256² 8-phase template", MI355X_MICROARCH.md "Two waves per SIMD") laid over this
+// convolution's tap-ordered K loop. Waves 4-7 run one barrier behind waves 0-3, so that on every SIMD one wave multiplies while
+// its partner reads and issues; the matrix pipe no longer waits for a wave's own ds_reads (the 4-wave kernel above reads, waits
+// and multiplies in one wave: matrix-pipe busy 40-54 %, profiles/r02_pmc_fp16_dma.md).
+//   stage  = one 32-wide K chunk (2 k16-steps = 2 phases): weights [octet 0..3][row][8 halves] + activations [pixel][4 slots][8]
+//            — the images of the kernel above, so packed weights and the source-side XOR swizzle are shared;
+//   ring   = 4 stages. Stage σ is read in phases 2σ, 2σ+1; its slot held stage σ-4, last read in phase 2σ-7, and may be
+//            re-filled from phase 2σ-5 on (two phases after the last read: the partner group reads one barrier later, and only
+//            the barrier after THAT orders its reads before a DMA — the guide's "restage ≥ 2 phases after the last ds_read").
+//            So the first half of a stage's pieces is issued in phase 2σ-5, the second half in phase 2σ-4, and every wave waits
+//            for its pieces of stage σ in phase 2σ-1 — before that phase's first barrier; the reads follow in phase 2σ, one phase
+//            after the wait, as the guide requires for data another wave's DMA wrote — with `s_waitcnt vmcnt(NP + H1)`: the
+//            pieces of stage σ+1 (NP) and the first half of stage σ+2 (H1) stay in flight across the barriers (3.5 - 4 phases
+//            ≈ 1000 MFMA cycles of latency cover). Never vmcnt(0) inside the loop.
+//   fp16 only (the x3 epilogue staging does not fit beside a 128 KB ring); final / partial tiles leave through the LDS-staged
+//   epilogues of the kernel above.
+template <int WGM, int WGN>
+__global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
+  constexpr int TM = 4, TN = 2, NW = 8, NSTAGE = 4;
+  constexpr int BM = WGM * 128, BN = WGN * 64;
+  constexpr int NPA = BM / (16 * NW), NPB = BN / (16 * NW), NP = NPA + NPB, H1 = (NP + 1) / 2;
+  constexpr int STAGE = (BM + BN) * 4;     // h8 per stage
+  static_assert(WGM * WGN == NW && NPA >= 1 && NPB >= 1 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) h8 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WGN) * 128, wn0 = (wave % WGN) * 64;
+  int vid;
+  {
+    const int total = p.n_full > 0 ? p.n_full : p.gx * p.gy * p.ksplit, bid = blockIdx.x;
+    const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+    vid = bid < total ? xcd * qn + min(xcd, rn) + (bid >> 3) : bid;
+  }
+  int bx, mb, split, c_begin, c_end, tail_slot = -1;
+  if (p.n_full > 0 && vid >= p.n_full) {
+    const int R = p.gx * p.gy - p.n_full, t = vid - p.n_full;
+    const int tile = p.n_full + t % R, ts = t / R;
+    bx = tile % p.gx; mb = tile / p.gx; split = 0;
+    tail_slot = ts * R + (tile - p.n_full);
+    c_begin = ts * p.tail_cps * 2; c_end = min(p.nchunk, (ts + 1) * p.tail_cps) * 2;
+  } else {
+    bx = vid % p.gx; mb = (vid / p.gx) % p.gy; split = vid / (p.gx * p.gy);
+    c_begin = split * p.chunks_per_split * 2; c_end = min(p.nchunk, (split + 1) * p.chunks_per_split) * 2;
+  }
+  const long n0 = (long)bx * BN;
+
+  unsigned voff[NPB];
+  unsigned long long ninv64[NPB];
+  unsigned lane_off[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int P = (wave * NPB + i) * 16 + (lane >> 2);
+    const long pix = n0 + P;
+    voff[i] = 0x80000000u;
+    unsigned long long m64 = 0;
+    if (pix < p.npix) {
+      const int hw = p.Ho * p.Wo;
+      const int n = (int)(pix / hw);
+      const int rr = (int)(pix - (long)n * hw);
+      const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      voff[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
+      m64 = tap_mask64(hi0, wi0, p.H, p.W);
+    }
+    ninv64[i] = ~m64;
+    lane_off[i] = (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.wp + (long)mb * p.nchunk * (HOCT * BM)), 0, (int)((long)p.nchunk * HOCT * BM * 16), 0x00020000);
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const unsigned w_voff = (unsigned)((wave * NPA) * 1024 + lane * 16);
+
+#define DMA(ldsaddr, voffset, rsrc)                                                                      \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                 \
+               :: "s"(ldsaddr), "v"(voffset), "s"(rsrc) : "memory")
+  const int kw_ = p.stride_kw & 0xffff, kh_ = p.stride_kw >> 16;
+  int ic = c_begin;                                   // next chunk32 (= stage) to issue
+  int i_half, i_kx, i_ky, i_cg;
+  {
+    const int kc = c_begin >> 1, ntaps = kh_ * kw_;
+    const int tap = kc % ntaps;
+    i_half = c_begin & 1; i_cg = kc / ntaps; i_ky = tap / kw_; i_kx = tap - i_ky * kw_;
+  }
+  unsigned i_sbase = 0, i_toff = 0, i_wbase = 0;
+  int i_tbit = 0;
+  auto issue_begin = [&]() {
+    i_sbase = lds0 + (unsigned)((ic - c_begin) & (NSTAGE - 1)) * (STAGE * 16);
+    i_toff = (unsigned)(((i_ky * p.W + i_kx) * p.Cin + i_cg * 64 + i_half * 32) * 2);
+    i_tbit = i_ky * 8 + i_kx;
+    i_wbase = (unsigned)min(ic, c_end - 1) * (unsigned)(BM * 64);
+  };
+  auto issue_piece = [&](int q) {
+    if (q < NPA) {
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * NPA + q) * 1024));
+      DMA(la, w_voff + (unsigned)q * 1024u + i_wbase, rsrc_w);
+    } else {
+      const int i = q - NPA;
+      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)(BM * 64) + (unsigned)((wave * NPB + i) * 1024));
+      const unsigned inv = (unsigned)(ninv64[i] >> i_tbit);
+      DMA(la, ((inv << 31) | voff[i]) + i_toff + lane_off[i], rsrc_in);
+    }
+  };
+  auto issue_end = [&]() {
+    if (ic < c_end - 1) {                             // past the end: keep re-issuing the last chunk (its ring slot is free)
+      i_half ^= 1;
+      if (i_half == 0) {
+        if (++i_kx == kw_) {
+          i_kx = 0;
+          if (++i_ky == kh_) { i_ky = 0; ++i_cg; }
+        }
+      }
+    }
+    ++ic;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: stages 0 and 1 whole, the first half of stage 2 (what phases -5 … -1 of the steady state would have issued)
+  for (int pre = 0; pre < 2; ++pre) {
+    issue_begin();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_piece(q);
+    issue_end();
+  }
+  issue_begin();
+#pragma unroll
+  for (int q = 0; q < H1; ++q) issue_piece(q);
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory");      // stage 0 has landed (this wave's pieces)
+  asm volatile("s_barrier" ::: "memory");                              // … everybody's
+  if (wave >= 4) asm volatile("s_barrier" ::: "memory");               // the younger half runs one barrier behind
+
+  const int lrow = lane >> 5, lcol = lane & 31;
+  const int sw = (lcol >> 2) & 3;
+  const int nst = c_end - c_begin;
+  for (int s = 0; s < nst; ++s) {
+    const h8* as = smem + (s & (NSTAGE - 1)) * STAGE + lrow * BM + wm0 + lcol;
+    const h8* bs = smem + (s & (NSTAGE - 1)) * STAGE + BM * 4 + (wn0 + lcol) * 4;
+    h8 af[TM], bf[TN];
+    // ---- phase 2s (even): k16-step 0 of stage s; the second half of stage s+2 is issued
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + (lrow ^ sw)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = H1; q < NP; ++q) issue_piece(q);
+    issue_end();
+    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 2s+1 (odd): k16-step 1; the first half of stage s+3 is issued; stage s+1 is waited for
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = as[2 * BM + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + ((2 + lrow) ^ sw)];
+    __builtin_amdgcn_sched_barrier(0);
+    issue_begin();
+#pragma unroll
+    for (int q = 0; q < H1; ++q) issue_piece(q);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+  }
+  if (wave < 4) asm volatile("s_barrier" ::: "memory");                // the older half catches the barrier count up
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef DMA
+
+  if (tail_slot >= 0 || p.partial) {
+    // raw fp32 partial sums through LDS staging (see conv_f16_dma_kernel): a pixel's 128 channels of this wave = 512 contiguous bytes
+    constexpr int PITCH = 512 + 16;
+    static_assert(NW * 32 * PITCH <= (NSTAGE * STAGE * 16 > 135168 ? NSTAGE * STAGE * 16 : 135168), "staging area");
+    __syncthreads();
+    char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
+    float* dst;
+    size_t row_floats;
+    if (tail_slot >= 0) { dst = p.tail_partial + (long)tail_slot * (BM * BN) + (long)wn0 * BM + wm0; row_floats = BM; }
+    else { dst = p.partial + ((long)split * p.npix + n0 + wn0) * p.Cout + mb * BM + wm0; row_floats = p.Cout; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(stage + lcol * PITCH + (i * 32 + 8 * g + 4 * lrow) * 4) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int px = k * 2 + (lane >> 5), chunk = lane & 31;
+        const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * PITCH + chunk * 16);
+        const long op = n0 + wn0 + j * 32 + px;
+        const bool ok = tail_slot >= 0 || op < p.npix;          // Cout % 128 == 0 on this kernel
+        if (ok) *reinterpret_cast<i32x4*>(dst + (size_t)(j * 32 + px) * row_floats + chunk * 4) = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
+  {
+    // final output: bias + LeakyReLU in fp32, staged through LDS so that a wave writes each pixel's 256-byte run of its 128
+    // channels as 16-byte pieces (see conv_f16_dma_kernel)
+    constexpr int RUN = 256, PITCH = RUN + 16, CPP = RUN / 16, PPI = 64 / CPP;
+    __syncthreads();
+    char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
+    const int cw0 = mb * BM + wm0;
+    const size_t rec_bytes = (size_t)p.Cout * 2;
+    const size_t run_off = (size_t)cw0 * 2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = i * 32 + 8 * g + 4 * lrow;
+          const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bias_q[4] = {bq.x, bq.y, bq.z, bq.w};
+          h4 vh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][4 * g + r] + bias_q[r];
+            x = x > 0.f ? x : x * p.slope;
+            vh[r] = (_Float16)x;
+          }
+          *reinterpret_cast<h4*>(stage + lcol * PITCH + cl * 2) = vh;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int k = 0; k < 32 / PPI; ++k) {
+        const int px = k * PPI + lane / CPP, chunk = lane % CPP;
+        const i32x4 d = *reinterpret_cast<const i32x4*>(stage + px * PITCH + chunk * 16);
+        const long op = n0 + wn0 + j * 32 + px;
+        if (op < p.npix)
+          *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(p.out) + (size_t)op * rec_bytes + run_off + chunk * 16) = d;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 // X3 split-K second pass: Σ_s partial (fixed order) → real units → bias → LeakyReLU → split16 record
 __global__ __launch_bounds__(256) void splitk_x3_reduce_kernel(_Float16* __restrict__ out, const float* __restrict__ partial,
                                                                const float* __restrict__ bias, long total4, int S, int Cout,
@@ -1254,11 +1521,11 @@ namespace {
 //   tail split ts:       floor(blocks / 256) · nchunk + ceil(R·ts / 256) · ceil(nchunk / ts) + reduce(R·ts),  R = blocks mod 256
 // reduce(n) = c0 + c1·n·(BM·BN/16384): fp32 partial tiles written and read once; deterministic, no timing involved.
 template <bool X3>
-int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1) {
+int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, float c1, bool pp = false) {
   const int blocks = p.gx * p.gy;
-  const bool w8 = BM == 256 && BN == 256 && (ctx->f16_dev_flags & DI_F16_W8) != 0;   // dev: one 8-wave block per CU on a 256x256 tile
-  const bool tn2 = (BM == 256 && BN == 128) || (BM == 128 && BN == 256);       // 128x64 wave tiles, two blocks per CU
-  const int slots = tn2 ? 512 : 256;
+  const bool w8 = !pp && BM == 256 && BN == 256 && (ctx->f16_dev_flags & DI_F16_W8) != 0;   // dev: one 8-wave block per CU on a 256x256 tile
+  const bool tn2 = !pp && ((BM == 256 && BN == 128) || (BM == 128 && BN == 256));       // 128x64 wave tiles, two blocks per CU
+  const int slots = tn2 ? 512 : 256;            // resident blocks on the chip (the ping-pong kernel: one 8-wave block per CU)
   int ks = 1, ts = 0;
   if (ctx->conv_max_split != 1) {
     float best = 1e30f;
@@ -1311,11 +1578,20 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 135168));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
     fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
-  if (BM == 128 && tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
+  if (pp) {
+    if constexpr (!X3) {
+      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4>), dim3(grid), dim3(512), 135168, ctx->stream, p);
+      else hipLaunchKernelGGL((conv_f16_pp_kernel<1, 8>), dim3(grid), dim3(512), 163840, ctx->stream, p);
+    } else {
+      DI_REQUIRE(false, "conv2d_x3: no ping-pong kernel");
+    }
+  } else if (BM == 128 && tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<1, 4, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
   else if (w8) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 4, 4, X3, 2>), dim3(grid), dim3(512), 131072, ctx->stream, p);
   else if (tn2) hipLaunchKernelGGL((conv_f16_dma_kernel<2, 2, 3, X3, 2>), dim3(grid), dim3(256), 73728, ctx->stream, p);
   else if constexpr (!X3) {   // 128x128 wave tiles, one block per CU (DEEPIM_F16_TN4=1; plain fp16 only)
@@ -1375,9 +1651,22 @@ extern "C" int deepim_conv2d_f16_forward(deepim_ctx* ctx, void* out_nhwc_f16, co
   }
   p.tab = tab;
   const bool ut = ((Cin_pad >> 3) & 7) == 0;
-  const int BM = f16_bm(Cout), BN = f16_bn(Cout, ut && !(ctx->f16_dev_flags & DI_F16_NO_DMA), ctx->f16_dev_flags);
-  p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
+  const int BM = f16_bm(Cout);
+  int BN = f16_bn(Cout, ut && !(ctx->f16_dev_flags & DI_F16_NO_DMA), ctx->f16_dev_flags);
   p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.tail_partial = nullptr; p.acc_scale = p.out_scale = 1.f; p.status = ctx->status;
+  // Ping-pong kernel (one 8-wave block per CU, 256x256 / 128x512 tiles): the layers whose tile count fills the chip — at
+  // least DI_F16_PP_MIN_TILES tiles, i.e. conv2 … conv4_1 at B = 32. Smaller grids keep the 4-wave kernel on 256x128 tiles (two
+  // blocks per CU: twice the blocks for the same split factor). Fixed by the geometry: the same plan on every rank.
+  if (ut && BM >= 128 && (Cout % 128) == 0 && !(ctx->f16_dev_flags & (DI_F16_NO_DMA | DI_F16_NO_PP | DI_F16_TN4 | DI_F16_W8))) {
+    const int bn_pp = BM == 256 ? 256 : 512;
+    const long tiles_pp = (long)di_div_up(p.npix, bn_pp) * di_div_up(Cout, BM);
+    if (tiles_pp >= DI_F16_PP_MIN_TILES) {
+      BN = bn_pp;
+      p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
+      return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f, true);
+    }
+  }
+  p.gx = di_div_up(p.npix, BN); p.gy = di_div_up(Cout, BM);
   if (ut && BM >= 128 && !(ctx->f16_dev_flags & DI_F16_NO_DMA)) return launch_f16_dma<false>(ctx, p, BM, BN, 1.5f, 0.009f);
   const int blocks = p.gx * p.gy;
   // one 256-thread block per CU (the LDS double buffer and the 256 accumulator registers leave room for one): split K when

@@ -51,6 +51,37 @@ def test_conv_f16_matches_emulation(ctx, case):
     assert np.mean(got != ref) < 0.02
 
 
+@pytest.mark.parametrize("case", [(3, 64, 120, 160, 256, 3, 1, 1),      # 225 tiles of 256x256, K = 18 stages
+                                  (6, 64, 240, 320, 128, 5, 2, 2),      # conv2's geometry: 225 tiles of 128x512 (Cout = 128)
+                                  (1, 128, 231, 233, 512, 3, 1, 1),     # two M tiles, ragged last pixel tile, odd frame
+                                  (13, 128, 120, 160, 256, 5, 2, 2),    # conv3's geometry: stride 2, 5x5, 100 stages
+                                  (4, 64, 120, 160, 256, 3, 1, 1)])     # 300 tiles: 256 whole + a tail split of 44
+def test_conv_f16_pingpong_kernel(ctx, case):
+    """conv_f16_pp_kernel (round 4: one 8-wave block per CU, the two waves of a SIMD alternating between fragment reads + LDS-DMA
+    issue and the MFMAs, 4-stage ring with counted vmcnt) on grids of >= 200 tiles: against the fp16 emulation (<= 1 fp16 ulp),
+    and — with K splitting off, so that both kernels add a pixel's products in the same order — BIT-IDENTICAL to the 4-wave
+    kernel of round 3 (f16_dev_flags bit 16 selects it). Three repeats: a DMA / barrier ordering slip shows as rare wrong tiles."""
+    B, cin, H, W, cout, k, s, p = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = _conv_f16(ctx, x, w, b, s, p, 0.1)
+    ref = opipe.q16(onet.conv2d(opipe.q16(x), opipe.q16(w), b, s, p, 0.1))
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.maximum(1.0, np.abs(ref)).max()
+    assert np.mean(got != ref) < 0.02
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
+    try:
+        new = [_conv_f16(ctx, x, w, b, s, p, 0.1) for _ in range(3)]
+        lib.deepim_set_option(ctx.handle, b"f16_dev_flags", 16)
+        old = _conv_f16(ctx, x, w, b, s, p, 0.1)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"f16_dev_flags", 0)
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    for n_ in new:
+        np.testing.assert_array_equal(n_, old)
+
+
 def test_layout_round_trip(ctx):
     rng = np.random.default_rng(1)
     x = rng.standard_normal((2, 5, 7, 9)).astype(np.float32)
