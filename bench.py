@@ -327,10 +327,25 @@ class Loop(object):
         self.pose_init = ctx.array(batch["src_pose"][0])
         self.pose_cur = ctx.empty((B, 3, 4))
         # closed loop (tester.py:420-455): re-render at the refined pose on the device between iterations
-        mesh = dict(synthetic.ellipsoid_mesh([0.05, 0.04, 0.035]), texture=synthetic.procedural_texture())
+        axes = [0.05, 0.04, 0.035]
+        mesh = dict(synthetic.ellipsoid_mesh(axes), texture=synthetic.procedural_texture())
         mesh.pop("colors")
-        self.render_machine = Render_Py("synthetic", ["ellipsoid"], batch["K"], 640, 480, 0.25, 6.0,
-                                        meshes={"ellipsoid": mesh}, ctx=ctx, pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
+        self.light = None
+        if args.lit:
+            # BASELINE config 5 (ModelNet): the reference's loop draws through Render_Py_Light_ModelNet_Multi — per-fragment diffuse
+            # term, light at 0.5·(0,1,1) + (t_x, −t_y, −t_z), per-render light colour U(0.9, 1.1) (tester.py:114-172); the colours
+            # of every (iteration, pair) are drawn once, before the timed region, and stay on the device
+            from mx_deepim_amd.lib.render_glumpy.render_py_light_modelnet_multi import Render_Py_Light_ModelNet_Multi
+            nrm = mesh["vertices"] / (np.asarray(axes, np.float32) ** 2)
+            mesh["normals"] = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+            self.render_machine = Render_Py_Light_ModelNet_Multi(["ellipsoid"], None, batch["K"], 640, 480, 0.25, 6.0,
+                                                                 brightness_ratios=[0.7], meshes=[mesh], ctx=ctx,
+                                                                 pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
+            rl = np.random.default_rng(77 + rank)
+            self.light = [ctx.array(rl.uniform(0.9, 1.1, (B, 3)).astype(np.float32)) for _ in range(max(1, NIT - 1))]
+        else:
+            self.render_machine = Render_Py("synthetic", ["ellipsoid"], batch["K"], 640, 480, 0.25, 6.0,
+                                            meshes={"ellipsoid": mesh}, ctx=ctx, pixel_means=synthetic.PIXEL_MEANS[::-1].copy())
         self.rbuf = {"image_rendered": ctx.empty((B, 3, 480, 640)), "depth_rendered": ctx.empty((B, 1, 480, 640)),
                      "mask_rendered": ctx.empty((B, 1, 480, 640)), "mask_observed": ctx.empty((B, 1, 480, 640))}
         # all-gather buffers: every rank contributes Bmax poses (ragged strong-scaling shards pad to the largest block)
@@ -396,7 +411,8 @@ class Loop(object):
             if it < NIT - 1 and not args.prestaged:
                 if rtimers:
                     rtimers[it].start()
-                data = update_test_batch(self.cfg, data, self.render_machine, pose_cur, out=self.rbuf)
+                data = update_test_batch(self.cfg, data, self.render_machine, pose_cur, out=self.rbuf,
+                                         light_intensity=self.light[it] if self.light else None)
                 if rtimers:
                     rtimers[it].stop()
 
@@ -483,6 +499,9 @@ def main():
                     "on the device between iterations (the pre-rasteriser behaviour of this bench)")
     ap.add_argument("--depth", action="store_true", help="BASELINE config 5 input as written: RGB-D pairs, network.INPUT_DEPTH "
                     "(ZoomDepth of observed + rendered depth inside the timed front end, C_in = 10)")
+    ap.add_argument("--lit", choices=("auto", "on", "off"), default="auto", help="re-render between the iterations with the lit render "
+                    "machine of the reference's ModelNet loops (render_py_light_modelnet_multi.py: per-fragment diffuse term); auto = on "
+                    "for BASELINE config 5 as written (--fp16 --depth), off otherwise (LINEMOD loops draw unlit texture)")
     ap.add_argument("--graph", choices=("on", "off"), default="off", help="replay the encoder's launches (10 convs + split-K "
                     "second passes + layout passes) from one captured hipGraph instead of issuing them one by one. Measured "
                     "(profiles/r03_fp16_config5.md): no gain at B = 8 / B = 4 — the kernel trace shows no idle gaps between the "
@@ -499,6 +518,7 @@ def main():
     ap.add_argument("--extras-budget", type=float, default=200.0, help="wall-clock budget in seconds for everything after the "
                     "timed region (parity, CPU baseline, other configs); what does not fit is reported as skipped")
     args = ap.parse_args()
+    args.lit = args.lit == "on" or (args.lit == "auto" and args.fp16 and args.depth)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -618,7 +638,8 @@ def main():
                            NIT, "full test graph incl. decoder + mask/flow heads" if args.heads else "FAST_TEST graph",
                            "RGB-D, 10-ch input incl. ZoomDepth" if args.depth else "8-ch input",
                            "pre-staged rendered frames (render excluded)" if args.prestaged else
-                           "closed loop: on-device re-render + mask update between iterations"),
+                           "closed loop: on-device re-render (%s) + mask update between iterations" % (
+                               "lit ModelNet render machine" if args.lit else "unlit texture, LINEMOD render machine")),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT, "shard_counts": counts,
                        "encoder_launch": "hipGraph replay" if use_graph else "direct launches",
                        "parallelism": ("pairs sharded across %d GPU(s) in contiguous blocks, one process per GPU, one ncclAllGather (RCCL) "

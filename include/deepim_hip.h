@@ -581,6 +581,21 @@ int deepim_render_update_forward(deepim_ctx* ctx, float* image, float* depth, fl
                                  int tex_h, int tex_w, const float* poses, const float* K_host,
                                  const float* pixel_means_host, int V, int F, int B, int H, int W,
                                  float znear, float zfar);
+/* The draw of the ModelNet loops (BASELINE config 5): lib/render_glumpy/render_py_light_modelnet_multi.py:36-80,170-188 — the
+ * same rasterisation with the per-fragment diffuse term of its shader, in OpenGL camera coordinates (y, z of the pose flipped):
+ *   brightness = clamp(n·(L − p) / (|n|·|L − p|), 0, 1),  colour = texture·((1 − r) + r·brightness)·intensity,
+ *   read back as round(clamp(colour, 0, 1)·255) (the reference reads uint8, :162-166);  p, n = the fragment's interpolated
+ *   position / normal under the pose;  L = light_offset + (t_x, −t_y, −t_z) of the sample's pose, as the render closures of
+ *   deepim/core/tester.py:146-172 and lib/pair_matching/batch_updater_py_multi.py:185-228 set it (offset 0.5·(0,1,1)).
+ * normals (V,3) device; light_offset_host 3 floats; light_intensity (B,3) device or NULL (= 1,1,1; the reference draws
+ * U(0.9,1.1) per sample); brightness_ratio r (0.7 there). mask_rendered / mask_box may be NULL (see deepim_render_update_forward).
+ * OpenGL itself cannot run here: restated, PARITY UNPINNED like the unlit draw (tests: oracle/render.py). */
+int deepim_render_lit_forward(deepim_ctx* ctx, float* image, float* depth, float* mask_rendered /*or NULL*/,
+                              float* mask_box /*or NULL*/, float mask_thresh, const float* vertices,
+                              const float* vertex_attr, const float* normals, const int32_t* faces, const float* texture,
+                              int tex_h, int tex_w, const float* poses, const float* K_host, const float* pixel_means_host,
+                              const float* light_offset_host, const float* light_intensity /*device (B,3) or NULL*/,
+                              float brightness_ratio, int V, int F, int B, int H, int W, float znear, float zfar);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,21 @@ __device__ __forceinline__ float tex_bilinear(const float* __restrict__ tex, int
   return top + (bot - top) * fy;
 }
 
+// Lit fragment stage of the ModelNet loop (lib/render_glumpy/render_py_light_modelnet_multi.py:36-80, light set-up
+// deepim/core/tester.py:146-172 = batch_updater_py_multi.py:185-228). All of it in OpenGL camera coordinates (y, z flipped):
+//   position = u_view·u_model·v_position,  normal = (u_view·u_model)^-T·(v_normal, 1) — whose 4-vector normalisation cancels in
+//   the next line —  brightness = clamp(n·(L − position) / (|L − position|·|n|), 0, 1),
+//   colour = texture·((1 − r) + r·brightness)·intensity, read back as round(clamp(colour, 0, 1)·255) (:162-166: uint8).
+// L = light_offset + (t_x, −t_y, −t_z) of the sample's pose. verts == nullptr: the unlit stage of render_py_multi.py.
+struct LitParams {
+  const float* verts;      // (V,3) model-space positions (v_position)
+  const float* normals;    // (V,3) per-vertex normals (v_normal)
+  const float* poses;      // (B,3,4)
+  const float* intensity;  // (B,3) device, or nullptr = (1,1,1)
+  Vec3 light_offset;       // 0.5·(0,1,1) in the reference's loops
+  float ratio;             // brightness_ratio (0.7)
+};
+
 // attr: per-vertex attributes — 3 floats RGB (0..255) when tex == nullptr, else 2 floats uv
 __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image, float* __restrict__ depth,
                                                       const unsigned long long* __restrict__ zbuf,
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
                                                       const float* __restrict__ attr, const float* __restrict__ tex,
                                                       int TH, int TW, Vec3 means, int V, int H, int W, float znear,
                                                       float* __restrict__ mask, float mask_thresh,
-                                                      int* __restrict__ box_words) {
+                                                      int* __restrict__ box_words, LitParams lit) {
   const int b = blockIdx.y;
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const long plane = (long)H * W;
@@ -155,6 +170,37 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
       const float v = ((q0 * attr[ia * 2 + 1] + q1 * attr[ib * 2 + 1]) + q2 * attr[ic * 2 + 1]) / qs;
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = tex_bilinear(tex, TH, TW, c, u, v);
+    }
+    if (lit.verts != nullptr) {
+      const float* P = lit.poses + b * 12;
+      float mp[3], mn[3];      // perspective-correct model-space position and normal of the fragment (GL varyings)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        mp[c] = ((q0 * lit.verts[ia * 3 + c] + q1 * lit.verts[ib * 3 + c]) + q2 * lit.verts[ic * 3 + c]) / qs;
+        mn[c] = ((q0 * lit.normals[ia * 3 + c] + q1 * lit.normals[ib * 3 + c]) + q2 * lit.normals[ic * 3 + c]) / qs;
+      }
+      float pos[3], nrm[3], s2l[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float sgn = r == 0 ? 1.f : -1.f;     // yz_flip of _get_view_mtx
+        pos[r] = sgn * ((((P[r * 4] * mp[0] + P[r * 4 + 1] * mp[1]) + P[r * 4 + 2] * mp[2])) + P[r * 4 + 3]);
+        nrm[r] = sgn * ((P[r * 4] * mn[0] + P[r * 4 + 1] * mn[1]) + P[r * 4 + 2] * mn[2]);
+        s2l[r] = (lit.light_offset.v[r] + sgn * P[r * 4 + 3]) - pos[r];
+      }
+      const float dotp = (nrm[0] * s2l[0] + nrm[1] * s2l[1]) + nrm[2] * s2l[2];
+      const float ls = sqrtf((s2l[0] * s2l[0] + s2l[1] * s2l[1]) + s2l[2] * s2l[2]);
+      const float ln = sqrtf((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+      float br = dotp / (ls * ln);
+      br = fmaxf(fminf(br, 1.f), 0.f);             // max(min(x, 1), 0): a NaN (degenerate normal) becomes 0, as in GLSL on most drivers
+      if (!(br == br)) br = 0.f;
+      const float shade = (1.f - lit.ratio) + lit.ratio * br;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float inten = lit.intensity ? lit.intensity[b * 3 + c] : 1.f;
+        float col = (rgb[c] / 255.f) * (shade * inten);
+        col = fminf(fmaxf(col, 0.f), 1.f);
+        rgb[c] = rintf(col * 255.f);               // np.round(rgb * 255).astype(uint8)
+      }
     }
   }
   if (inside) {
@@ -187,7 +233,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
 static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask, float* mask_box, float mask_thresh,
                        const float* vertices, const float* vertex_attr, const int32_t* faces, const float* texture,
                        int tex_h, int tex_w, const float* poses, const float* K_host, const float* pixel_means_host,
-                       int V, int F, int B, int H, int W, float znear, float zfar) {
+                       int V, int F, int B, int H, int W, float znear, float zfar, const float* normals = nullptr,
+                       const float* light_offset_host = nullptr, const float* light_intensity = nullptr, float ratio = 0.f) {
   if (B == 0) return 0;
   DI_REQUIRE(V > 0 && F > 0 && H > 0 && W > 0, "render: empty mesh or image");
   DI_REQUIRE(znear > 0.f && zfar > znear, "render: need 0 < zNear < zFar");
@@ -204,6 +251,11 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
   Vec3 means = {{0, 0, 0}};
   if (pixel_means_host) for (int i = 0; i < 3; ++i) means.v[i] = pixel_means_host[i];
   int* words = mask_box ? ctx->box_words : nullptr;
+  LitParams lit = {nullptr, nullptr, poses, light_intensity, {{0, 0, 0}}, ratio};
+  if (normals != nullptr) {
+    lit.verts = vertices; lit.normals = normals;
+    if (light_offset_host) for (int i = 0; i < 3; ++i) lit.light_offset.v[i] = light_offset_host[i];
+  }
   DI_CHECK(hipMemsetAsync(zbuf, 0xff, zbytes, ctx->stream));
   hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V,
                      words);
@@ -211,7 +263,7 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
                      F, H, W, znear, zfar);
   hipLaunchKernelGGL(resolve_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, image, depth, zbuf,
                      pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear, mask, mask_thresh,
-                     words);
+                     words, lit);
   DI_LAUNCH_CHECK();
   if (mask_box) return deepim_mask_box_fill(ctx, mask_box, words, B, H, W);
   return 0;
@@ -237,4 +289,21 @@ extern "C" int deepim_render_update_forward(deepim_ctx* ctx, float* image, float
   DI_REQUIRE(mask_rendered != nullptr, "render_update: mask_rendered is NULL");
   return render_impl(ctx, image, depth, mask_rendered, mask_box, mask_thresh, vertices, vertex_attr, faces, texture, tex_h,
                      tex_w, poses, K_host, pixel_means_host, V, F, B, H, W, znear, zfar);
+}
+
+// The same passes with the lit fragment stage of the ModelNet render machine (render_py_light_modelnet_multi.py:36-80,170-188;
+// the render closures of tester.py:146-184 and batch_updater_py_multi.py:185-228): see LitParams above.
+extern "C" int deepim_render_lit_forward(deepim_ctx* ctx, float* image, float* depth, float* mask_rendered, float* mask_box,
+                                         float mask_thresh, const float* vertices, const float* vertex_attr,
+                                         const float* normals, const int32_t* faces, const float* texture, int tex_h,
+                                         int tex_w, const float* poses, const float* K_host, const float* pixel_means_host,
+                                         const float* light_offset_host, const float* light_intensity,
+                                         float brightness_ratio, int V, int F, int B, int H, int W, float znear, float zfar) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(normals != nullptr && light_offset_host != nullptr, "render_lit: normals and light offset are required");
+  DI_REQUIRE(brightness_ratio >= 0.f && brightness_ratio <= 1.f, "render_lit: brightness_ratio in [0, 1]");
+  DI_REQUIRE(mask_box == nullptr || mask_rendered != nullptr, "render_lit: mask_box needs mask_rendered");
+  return render_impl(ctx, image, depth, mask_rendered, mask_box, mask_thresh, vertices, vertex_attr, faces, texture, tex_h, tex_w,
+                     poses, K_host, pixel_means_host, V, F, B, H, W, znear, zfar, normals, light_offset_host, light_intensity,
+                     brightness_ratio);
 }

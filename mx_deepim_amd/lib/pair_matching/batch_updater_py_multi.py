@@ -72,9 +72,11 @@ class batchUpdaterPyMulti(object):
             image_rendered, depth_rendered = out["image_rendered"], out["depth_rendered"]
             fused_mask = out.get("mask_rendered") if cfg.network.INPUT_MASK else None
             self.render_machine.render_batch(data_batch.get("class_index"), refined_pose, out=(image_rendered, depth_rendered),
-                                             mask_rendered=fused_mask, mask_thresh=0.2)
+                                             mask_rendered=fused_mask, mask_thresh=0.2,
+                                             light_intensity=data_batch.get("light_intensity"))
         elif self.render_machine is not None:
-            image_rendered, depth_rendered = self.render_machine.render_batch(data_batch.get("class_index"), refined_pose)
+            image_rendered, depth_rendered = self.render_machine.render_batch(data_batch.get("class_index"), refined_pose,
+                                                                              light_intensity=data_batch.get("light_intensity"))
         else:
             image_rendered, depth_rendered = data_batch["next_image_rendered"], data_batch["next_depth_rendered"]
         # 3. residual delta = new labels
@@ -110,11 +112,13 @@ class batchUpdaterPyMulti(object):
         return new_batch
 
 
-def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None, out=None):
+def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None, out=None, light_intensity=None):
     """Test-loop update between refinement iterations — mirror of deepim/core/tester.py:420-455 +
     lib/pair_matching/data_pair.py:62-132 (`update_data_batch`): re-render at the refined pose, mask_rendered =
     depth > 0.2, and (TEST.UPDATE_MASK == "box_rendered") mask_observed = rectangle of the new rendered mask. All on the
-    device; `out` may carry preallocated image_rendered / depth_rendered / mask_rendered / mask_observed arrays."""
+    device; `out` may carry preallocated image_rendered / depth_rendered / mask_rendered / mask_observed arrays.
+    With the lit ModelNet render machine (tester.py:114-172) `light_intensity` = device (B,3) per-sample light colour (the
+    reference draws U(0.9, 1.1) per render; None = 1.0)."""
     ctx = refined_pose.context
     B, H, W = refined_pose.shape[0], render_machine.height, render_machine.width
     out = out or {}
@@ -142,7 +146,8 @@ def update_test_batch(cfg, data, render_machine, refined_pose, class_index=None,
             b1 += 1
         render_machine.render_into(image[b0:b1], depth[b0:b1], ids[b0], refined_pose[b0:b1],
                                    mask_rendered=None if mask is None else mask[b0:b1],
-                                   mask_box=None if box is None else box[b0:b1], mask_thresh=0.2)
+                                   mask_box=None if box is None else box[b0:b1], mask_thresh=0.2,
+                                   light_intensity=None if light_intensity is None else light_intensity[b0:b1])
         b0 = b1
     new["image_rendered"], new["src_pose"] = image, refined_pose
     if cfg.network.INPUT_DEPTH:

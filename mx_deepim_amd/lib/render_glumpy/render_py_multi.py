@@ -114,9 +114,10 @@ class Render_Py(object):
 
     # -- device API ----------------------------------------------------------------------------------------------
     def render_into(self, image, depth, cls_idx, poses, K=None, pixel_means="default", mask_rendered=None, mask_box=None,
-                    mask_thresh=0.2):
+                    mask_thresh=0.2, light_intensity=None):
         """image (n,3,H,W), depth (n,1,H,W), poses (n,3,4): all device arrays; one mesh. With `mask_rendered` (n,1,H,W)
-        the same pass also writes depth > mask_thresh, and with `mask_box` its box_rendered rectangle."""
+        the same pass also writes depth > mask_thresh, and with `mask_box` its box_rendered rectangle. (`light_intensity` belongs
+        to the lit ModelNet machine, render_py_light_modelnet_multi.py; this unlit draw ignores it.)"""
         m = self.mesh_list[int(cls_idx)]
         K = self.K if K is None else np.ascontiguousarray(K, dtype=np.float32).reshape(3, 3)
         means = self.pixel_means if isinstance(pixel_means, str) else pixel_means
@@ -131,7 +132,7 @@ class Render_Py(object):
             lib.deepim_render_update_forward(self.ctx.handle, image, depth, mask_rendered, mask_box,
                                              ctypes.c_float(mask_thresh), *tail)
 
-    def render_batch(self, class_index, poses, K=None, out=None, mask_rendered=None, mask_thresh=0.2):
+    def render_batch(self, class_index, poses, K=None, out=None, mask_rendered=None, mask_thresh=0.2, light_intensity=None):
         """poses (B,3,4) device; class_index: scalar, host sequence of B class ids, or None (= class 0).
         Samples of the same class in consecutive runs are drawn by one launch group. `out` = (image, depth) preallocated device
         tensors; `mask_rendered` (B,1,H,W): also written, = depth > mask_thresh, by the same pass."""
@@ -149,7 +150,8 @@ class Render_Py(object):
             while b1 < B and ids[b1] == ids[b0]:
                 b1 += 1
             self.render_into(image[b0:b1], depth[b0:b1], ids[b0], poses[b0:b1], K=K,
-                             mask_rendered=None if mask_rendered is None else mask_rendered[b0:b1], mask_thresh=mask_thresh)
+                             mask_rendered=None if mask_rendered is None else mask_rendered[b0:b1], mask_thresh=mask_thresh,
+                             light_intensity=None if light_intensity is None else light_intensity[b0:b1])
             b0 = b1
         return image, depth
 

@@ -52,9 +52,36 @@ def _tex_bilinear(tex, u, v):
     return (top + (bot - top) * fy[..., None]).astype(f32)
 
 
-def render(vertices, vertex_attr, faces, pose, K, H, W, znear=0.25, zfar=6.0, texture=None, pixel_means=None):
-    """One pose of one mesh -> (image (3,H,W) RGB − means, depth (H,W)), float32."""
+def _lit(col, mp, mn, pose, light_offset, intensity, ratio):
+    """Fragment stage of lib/render_glumpy/render_py_light_modelnet_multi.py:36-80 in float32, operation order of
+    csrc/render.hip: col (...,3) texture colour on 0..255, mp / mn (...,3) interpolated model-space position / normal."""
+    P = np.asarray(pose, f32)
+    sgn = np.array([1, -1, -1], f32)                     # yz_flip of _get_view_mtx (:202-208)
+    pos = np.stack([sgn[r] * ((((P[r, 0] * mp[..., 0] + P[r, 1] * mp[..., 1]) + P[r, 2] * mp[..., 2])) + P[r, 3])
+                    for r in range(3)], -1).astype(f32)
+    nrm = np.stack([sgn[r] * ((P[r, 0] * mn[..., 0] + P[r, 1] * mn[..., 1]) + P[r, 2] * mn[..., 2]) for r in range(3)], -1).astype(f32)
+    L = (np.asarray(light_offset, f32) + sgn * P[:, 3]).astype(f32)     # tester.py:161-165
+    s2l = (L - pos).astype(f32)
+    dotp = (nrm[..., 0] * s2l[..., 0] + nrm[..., 1] * s2l[..., 1]) + nrm[..., 2] * s2l[..., 2]
+    ls = np.sqrt((s2l[..., 0] * s2l[..., 0] + s2l[..., 1] * s2l[..., 1]) + s2l[..., 2] * s2l[..., 2]).astype(f32)
+    ln = np.sqrt((nrm[..., 0] * nrm[..., 0] + nrm[..., 1] * nrm[..., 1]) + nrm[..., 2] * nrm[..., 2]).astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        br = (dotp / (ls * ln)).astype(f32)
+    br = np.where(np.isnan(br), f32(0), np.maximum(np.minimum(br, f32(1)), f32(0))).astype(f32)
+    shade = ((f32(1) - f32(ratio)) + f32(ratio) * br).astype(f32)
+    inten = np.ones(3, f32) if intensity is None else np.asarray(intensity, f32)
+    c = (col / f32(255)) * (shade[..., None] * inten)
+    c = np.minimum(np.maximum(c, f32(0)), f32(1)).astype(f32)
+    return np.rint(c * f32(255)).astype(f32)             # np.round(rgb * 255).astype(uint8), :165
+
+
+def render(vertices, vertex_attr, faces, pose, K, H, W, znear=0.25, zfar=6.0, texture=None, pixel_means=None, normals=None,
+           light_offset=None, light_intensity=None, brightness_ratio=0.7):
+    """One pose of one mesh -> (image (3,H,W) RGB − means, depth (H,W)), float32. With `normals` (V,3) + `light_offset` the lit
+    fragment stage of the ModelNet render machine (`_lit`)."""
     u, v, Z = project(np.asarray(vertices), np.asarray(pose), np.asarray(K))
+    verts32 = np.asarray(vertices, dtype=f32)
+    nrm32 = None if normals is None else np.asarray(normals, dtype=f32)
     attr = np.asarray(vertex_attr, dtype=f32)
     tex = None if texture is None else np.asarray(texture, dtype=f32)
     zbuf = np.full((H, W), np.inf, dtype=f32)
@@ -98,6 +125,10 @@ def render(vertices, vertex_attr, faces, pose, K, H, W, znear=0.25, zfar=6.0, te
                 tu = ((q0 * attr[ia, 0] + q1 * attr[ib, 0]) + q2 * attr[ic, 0]) / qs
                 tv = ((q0 * attr[ia, 1] + q1 * attr[ib, 1]) + q2 * attr[ic, 1]) / qs
                 col = _tex_bilinear(tex, tu.astype(f32), tv.astype(f32))
+            if nrm32 is not None:
+                mp = ((q0[..., None] * verts32[ia] + q1[..., None] * verts32[ib]) + q2[..., None] * verts32[ic]) / qs[..., None]
+                mn = ((q0[..., None] * nrm32[ia] + q1[..., None] * nrm32[ib]) + q2[..., None] * nrm32[ic]) / qs[..., None]
+                col = _lit(col.astype(f32), mp.astype(f32), mn.astype(f32), pose, light_offset, light_intensity, brightness_ratio)
         sub_z = zbuf[y0:y1 + 1, x0:x1 + 1]
         sub_c = rgb[y0:y1 + 1, x0:x1 + 1]
         win = inside & (z > znear) & (z < zfar) & (z < sub_z)   # strict <: first triangle wins exact ties

@@ -61,3 +61,38 @@ def test_obj_and_texture_readers(tmp_path):
     Image.fromarray(arr).save(str(tmp_path / "texture_map.png"))
     tex = load_texture(str(tmp_path / "texture_map.png"))
     np.testing.assert_array_equal(tex, arr[::-1].astype(np.float32))
+
+
+def test_lit_fragment_stage_against_the_closed_form_on_a_sphere():
+    """render_py_light_modelnet_multi.py:36-80 restated in oracle/render.py: on a sphere the interpolated normal is the radial
+    direction, so every covered pixel's grey level has a closed form — texture·((1 − r) + r·max(0, n·(L − p)/|L − p|))·intensity
+    with p the ray/sphere hit point, L = 0.5·(0,1,1) + (t_x, −t_y, −t_z) in OpenGL camera coordinates (tester.py:146-165)."""
+    R_ = 0.05
+    mesh = synthetic.ellipsoid_mesh([R_, R_, R_], 96, 192)
+    normals = mesh["vertices"] / np.linalg.norm(mesh["vertices"], axis=1, keepdims=True)
+    tex = np.full((4, 4, 3), 220.0, np.float32)
+    t = np.array([0.03, -0.02, 0.55], np.float32)
+    a = 0.4
+    Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+    pose = np.concatenate([Rm, t[:, None]], 1).astype(np.float32)
+    inten = np.array([1.05, 0.95, 1.0], np.float32)
+    img, dep = orender.render(mesh["vertices"], mesh["uv"], mesh["faces"], pose, K, 480, 640, texture=tex, normals=normals,
+                              light_offset=[0.0, 0.5, 0.5], light_intensity=inten, brightness_ratio=0.7)
+    ys, xs = np.nonzero(dep > 0)
+    assert len(ys) > 3000
+    Kd = K.astype(np.float64)
+    ray = np.stack([(xs - Kd[0, 2]) / Kd[0, 0], (ys - Kd[1, 2]) / Kd[1, 1], np.ones(len(xs))], -1)
+    p_cv = ray * dep[ys, xs][:, None]                                   # camera-space hit point (OpenCV axes)
+    flip = np.array([1.0, -1.0, -1.0])
+    p_gl, c_gl = p_cv * flip, t.astype(np.float64) * flip
+    n_gl = (p_gl - c_gl) / np.linalg.norm(p_gl - c_gl, axis=1, keepdims=True)
+    L = np.array([0.0, 0.5, 0.5]) + c_gl
+    s2l = L - p_gl
+    br = np.clip((n_gl * s2l).sum(1) / np.linalg.norm(s2l, axis=1), 0, 1)
+    want = 220.0 * ((0.3 + 0.7 * br)[:, None] * inten[None])
+    got = img[:, ys, xs].T
+    inner = np.linalg.norm(p_gl - c_gl, axis=1) > 0                      # all
+    err = np.abs(got - np.clip(want, 0, 255))
+    assert np.median(err) <= 1.0 and np.percentile(err, 99) <= 4.0, (np.median(err), err.max())   # tessellated silhouette + rounding
+    assert got.min() >= 0 and got.max() <= 255 and np.all(got == np.rint(got))                    # uint8 read-back
+    assert br.max() > 0.95 and br.min() == 0.0                                                    # lit and unlit side both in view
