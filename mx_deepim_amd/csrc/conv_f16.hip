@@ -629,6 +629,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
 //            ≈ 1000 MFMA cycles of latency cover). Never vmcnt(0) inside the loop.
 //   fp16 only (the x3 epilogue staging does not fit beside a 128 KB ring); final / partial tiles leave through the LDS-staged
 //   epilogues of the kernel above.
+// Dev builds only (tools/build_variants_f16.sh → variants/lib_<name>.so, never the shipped library): ablation bits and a
+// per-phase timeline of the ping-pong kernel. DI_PP_ABL: 1 = no DMA issue inside the loop, 2 = no activation pieces, 4 = every
+// piece re-reads one resident address range (issue cost without the bandwidth), 8 = no fragment reads, 16 = no MFMAs (results
+// are wrong by construction: timing only). DI_PP_TRACE: waves 0 and 4 of tile 0 stamp s_memtime at four points of every phase
+// into LDS and dump them to the buffer registered with deepim_dev_pp_trace().
+#ifndef DI_PP_ABL
+#define DI_PP_ABL 0
+#endif
+#ifndef DI_PP_TRACE
+#define DI_PP_TRACE 0
+#endif
+#if DI_PP_TRACE
+__device__ unsigned long long* g_pp_trace = nullptr;
+constexpr int PP_TRACE_PHASES = 160;
+#endif
+
 template <int WGM, int WGN>
 __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
   constexpr int TM = 4, TN = 2, NW = 8, NSTAGE = 4;
@@ -706,15 +722,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
     i_tbit = i_ky * 8 + i_kx;
     i_wbase = (unsigned)min(ic, c_end - 1) * (unsigned)(BM * 64);
   };
+  bool in_loop = false;
   auto issue_piece = [&](int q) {
+    if ((DI_PP_ABL & 1) && in_loop) return;
     if (q < NPA) {
       const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * NPA + q) * 1024));
-      DMA(la, w_voff + (unsigned)q * 1024u + i_wbase, rsrc_w);
+      DMA(la, w_voff + (unsigned)q * 1024u + ((DI_PP_ABL & 4) ? 0u : i_wbase), rsrc_w);
     } else {
+      if ((DI_PP_ABL & 2) && in_loop) return;
       const int i = q - NPA;
       const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)(BM * 64) + (unsigned)((wave * NPB + i) * 1024));
-      const unsigned inv = (unsigned)(ninv64[i] >> i_tbit);
-      DMA(la, ((inv << 31) | voff[i]) + i_toff + lane_off[i], rsrc_in);
+      const unsigned inv = (unsigned)(ninv64[i] >> ((DI_PP_ABL & 4) ? 9 : i_tbit));
+      DMA(la, ((inv << 31) | voff[i]) + ((DI_PP_ABL & 4) ? 0u : i_toff) + lane_off[i], rsrc_in);
     }
   };
   auto issue_end = [&]() {
@@ -755,55 +774,84 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
   const int lrow = lane >> 5, lcol = lane & 31;
   const int sw = (lcol >> 2) & 3;
   const int nst = c_end - c_begin;
+  in_loop = true;
+#if DI_PP_TRACE
+  // timeline: [phase][wave 0 | wave 4][4 stamps] of 64-bit s_memtime in the LDS behind the ring / staging area
+  unsigned long long* tr = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 135168);
+  const bool tracing = vid == 0 && (wave & 3) == 0;
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+#define PP_STAMP(x) if (tracing) x = __builtin_amdgcn_s_memtime()
+#define PP_FLUSH(ph)                                                                                                  \
+  if (tracing) {                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    t_d = __builtin_amdgcn_s_memtime();                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    if (lane == 0 && (ph) < PP_TRACE_PHASES) {                                                                        \
+      unsigned long long* r_ = tr + ((ph) * 2 + (wave >> 2)) * 4;                                                     \
+      r_[0] = t_a; r_[1] = t_b; r_[2] = t_c; r_[3] = t_d;                                                             \
+    }                                                                                                                 \
+  }
+#else
+#define PP_STAMP(x)
+#define PP_FLUSH(ph)
+#endif
+  h8 af[TM], bf[TN];
+  if (DI_PP_ABL & 8) {   // fragments read once: the loop then runs without ds_reads
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = smem[lrow * BM + wm0 + lcol + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = smem[BM * 4 + (wn0 + lcol) * 4 + j * 128 + (lrow ^ sw)];
+  }
+  // one phase = the memory segment (fragment reads of k16-step T, ISSUE, optional counted wait), barrier, the matrix segment, barrier
+#define PP_PHASE(T, PH, ISSUE, WAIT)                                                                                  \
+  {                                                                                                                   \
+    PP_STAMP(t_a);                                                                                                    \
+    if (!(DI_PP_ABL & 8)) {                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = as[(T) * 2 * BM + i * 32];                               \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + (((T) * 2 + lrow) ^ sw)];                   \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    ISSUE;                                                                                                            \
+    WAIT;                                                                                                             \
+    PP_STAMP(t_b);                                                                                                    \
+    asm volatile("s_barrier" ::: "memory");                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    PP_STAMP(t_c);                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    if (!(DI_PP_ABL & 16)) {                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);                       \
+    } else {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));                                  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf[j]));                                  \
+    }                                                                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    PP_FLUSH(PH);                                                                                                     \
+    asm volatile("s_barrier" ::: "memory");                                                                           \
+  }
   for (int s = 0; s < nst; ++s) {
     const h8* as = smem + (s & (NSTAGE - 1)) * STAGE + lrow * BM + wm0 + lcol;
     const h8* bs = smem + (s & (NSTAGE - 1)) * STAGE + BM * 4 + (wn0 + lcol) * 4;
-    h8 af[TM], bf[TN];
-    // ---- phase 2s (even): k16-step 0 of stage s; the second half of stage s+2 is issued
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = as[i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + (lrow ^ sw)];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = H1; q < NP; ++q) issue_piece(q);
-    issue_end();
-    asm volatile("s_barrier" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 2s+1 (odd): k16-step 1; the first half of stage s+3 is issued; stage s+1 is waited for
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = as[2 * BM + i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + ((2 + lrow) ^ sw)];
-    __builtin_amdgcn_sched_barrier(0);
-    issue_begin();
-#pragma unroll
-    for (int q = 0; q < H1; ++q) issue_piece(q);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory");
-    asm volatile("s_barrier" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
+    // phase 2s (even): k16-step 0 of stage s; the second half of stage s+2 is issued
+    PP_PHASE(0, 2 * s, { _Pragma("unroll") for (int q = H1; q < NP; ++q) issue_piece(q); issue_end(); }, {})
+    // phase 2s+1 (odd): k16-step 1; the first half of stage s+3 is issued; this wave's pieces of stage s+1 are waited for
+    PP_PHASE(1, 2 * s + 1, { issue_begin(); _Pragma("unroll") for (int q = 0; q < H1; ++q) issue_piece(q); },
+             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory"))
   }
+#undef PP_PHASE
   if (wave < 4) asm volatile("s_barrier" ::: "memory");                // the older half catches the barrier count up
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef DMA
+#if DI_PP_TRACE
+  if (vid == 0 && g_pp_trace != nullptr) {
+    __syncthreads();
+    for (int i = tid; i < PP_TRACE_PHASES * 8; i += 512) g_pp_trace[i] = tr[i];
+    __syncthreads();
+  }
+#endif
 
   if (tail_slot >= 0 || p.partial) {
     // raw fp32 partial sums through LDS staging (see conv_f16_dma_kernel): a pixel's 128 channels of this wave = 512 contiguous bytes
@@ -1578,7 +1626,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 135168));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 135168 + (DI_PP_TRACE ? 16384 : 0)));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
@@ -1586,7 +1634,7 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
   if (pp) {
     if constexpr (!X3) {
-      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4>), dim3(grid), dim3(512), 135168, ctx->stream, p);
+      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4>), dim3(grid), dim3(512), 135168 + (DI_PP_TRACE ? 16384 : 0), ctx->stream, p);
       else hipLaunchKernelGGL((conv_f16_pp_kernel<1, 8>), dim3(grid), dim3(512), 163840, ctx->stream, p);
     } else {
       DI_REQUIRE(false, "conv2d_x3: no ping-pong kernel");
@@ -1944,3 +1992,11 @@ static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in
   DI_LAUNCH_CHECK();
   return 0;
 }
+
+#if DI_PP_TRACE
+// dev builds only: register the device buffer (PP_TRACE_PHASES x 2 waves x 4 stamps, 64-bit) the traced tile dumps its timeline to
+extern "C" int deepim_dev_pp_trace(void* buf) {
+  unsigned long long* b = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &b, sizeof(b));
+}
+#endif
