@@ -529,6 +529,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
     const int cw0 = mb * BM + wm0;                                     // first channel of this wave's tile
     const size_t rec_bytes = (size_t)p.Cout * (X3 ? 4 : 2);            // bytes per output pixel
     const size_t run_off = X3 ? (size_t)(cw0 >> 4) * 64 : (size_t)cw0 * 2;
+    // the wave tile's 16 bias quads in ONE batch of loads, before the tile is staged: loaded quad by quad inside the loop below
+    // (where every quad is fenced off to keep the register count down) each load's L2 latency was paid in sequence — 64 dependent
+    // round trips, ~10 of a tile's ~15 thousand epilogue cycles (profiles/r04_fp16_pingpong.md)
+    float4 bias_r[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias_r[i][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + i * 32 + 8 * g + 4 * lrow) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -536,8 +545,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int cl = i * 32 + 8 * g + 4 * lrow;                    // channel within the wave tile
-          const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float bias_q[4] = {bq.x, bq.y, bq.z, bq.w};
+          const float bias_q[4] = {bias_r[i][g].x, bias_r[i][g].y, bias_r[i][g].z, bias_r[i][g].w};
           h4 vh, vl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -611,29 +619,34 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Ping-pong kernel (round 4): ONE 8-wave block per CU on a 256x256 (Cout % 256 == 0) or 128x512 (conv2) tile, the two waves of
-// every SIMD alternating between a MEMORY segment (6 fragment reads of one k16-step + its share of the LDS-DMA pieces) and a
-// MATRIX segment (the 8 MFMAs of that k-step under s_setprio 1), separated by raw s_barriers — the 8-phase structure of the
-// CDNA4 guide (cdna_hip_programming.md §5 "256² 8-phase template", MI355X_MICROARCH.md "Two waves per SIMD") laid over this
-// convolution's tap-ordered K loop. Waves 4-7 run one barrier behind waves 0-3, so that on every SIMD one wave multiplies while
-// its partner reads and issues; the matrix pipe no longer waits for a wave's own ds_reads (the 4-wave kernel above reads, waits
-// and multiplies in one wave: matrix-pipe busy 40-54 %, profiles/r02_pmc_fp16_dma.md).
-//   stage  = one 32-wide K chunk (2 k16-steps = 2 phases): weights [octet 0..3][row][8 halves] + activations [pixel][4 slots][8]
-//            — the images of the kernel above, so packed weights and the source-side XOR swizzle are shared;
-//   ring   = 4 stages. Stage σ is read in phases 2σ, 2σ+1; its slot held stage σ-4, last read in phase 2σ-7, and may be
-//            re-filled from phase 2σ-5 on (two phases after the last read: the partner group reads one barrier later, and only
-//            the barrier after THAT orders its reads before a DMA — the guide's "restage ≥ 2 phases after the last ds_read").
-//            So the first half of a stage's pieces is issued in phase 2σ-5, the second half in phase 2σ-4, and every wave waits
-//            for its pieces of stage σ in phase 2σ-1 — before that phase's first barrier; the reads follow in phase 2σ, one phase
-//            after the wait, as the guide requires for data another wave's DMA wrote — with `s_waitcnt vmcnt(NP + H1)`: the
-//            pieces of stage σ+1 (NP) and the first half of stage σ+2 (H1) stay in flight across the barriers (3.5 - 4 phases
-//            ≈ 1000 MFMA cycles of latency cover). Never vmcnt(0) inside the loop.
-//   fp16 only (the x3 epilogue staging does not fit beside a 128 KB ring); final / partial tiles leave through the LDS-staged
-//   epilogues of the kernel above.
-// Dev builds only (tools/build_variants_f16.sh → variants/lib_<name>.so, never the shipped library): ablation bits and a
-// per-phase timeline of the ping-pong kernel. DI_PP_ABL: 1 = no DMA issue inside the loop, 2 = no activation pieces, 4 = every
-// piece re-reads one resident address range (issue cost without the bandwidth), 8 = no fragment reads, 16 = no MFMAs (results
-// are wrong by construction: timing only). DI_PP_TRACE: waves 0 and 4 of tile 0 stamp s_memtime at four points of every phase
-// into LDS and dump them to the buffer registered with deepim_dev_pp_trace().
+// every SIMD alternating between a MEMORY segment (the 12 fragment reads of one 32-wide K stage + all of a stage's LDS-DMA
+// pieces + the counted wait) and a MATRIX segment (that stage's 16 MFMAs under s_setprio 1), separated by raw s_barriers — the
+// phase structure of the CDNA4 guide's 8-wave kernels (cdna_hip_programming.md §5 "256² 8-phase template", MI355X_MICROARCH.md
+// "Two waves per SIMD") laid over this convolution's tap-ordered K loop. Waves 4-7 run one barrier behind waves 0-3, so that on
+// every SIMD one wave multiplies while its partner reads and issues (the 4-wave kernel above reads, waits and multiplies in one
+// wave: matrix pipe busy 40-54 %, profiles/r02_pmc_fp16_dma.md).
+//   stage  = one 32-wide K chunk: weights [octet 0..3][row][8 halves] + activations [pixel][4 slots][8] — the images of the
+//            kernel above, so packed weights and the source-side XOR swizzle are shared.
+//   ring   = NSTAGE stages, LA = NSTAGE − 2 issued ahead: phase P reads stage P, issues stage P + LA into the slot of stage
+//            P − 2 — last read TWO phases ago: the partner half reads one barrier later, and only the barrier after that orders
+//            its reads before a DMA (the guide's "restage >= 2 phases after the last ds_read") — and waits, before its first
+//            barrier, until at most (LA − 1)·NP pieces are outstanding: stage P + 1 has landed and is read one phase later, as
+//            the guide requires for data another wave's DMA wrote. Never vmcnt(0) inside the loop.
+//   memory segment stripped to ds_reads + DMA (a first form with a k16-step per phase and the tap counters / address arithmetic
+//            inside the segment measured 220-390 cycles per segment against the partner's 296 — one wave issues an instruction
+//            only every ~5 cycles — profiles/r04_fp16_pingpong.md): everything the NEXT phase's pieces need (ring slot, tap
+//            offset and validity shift from the per-chunk tap table by ONE scalar load, M0 values, soffsets, the activation
+//            pieces' voffsets with the padding bit, the fragment read bases) is computed inside the matrix segment, between the
+//            MFMAs, where issue slots are free; the pieces of one operand share one M0 write and differ by the instruction's
+//            immediate offset, which advances the LDS and the memory address together (the activation voffsets are pre-biased by
+//            −i·1024).
+//   fp16 only (the x3 epilogue staging does not fit beside the ring); final / partial tiles leave through the LDS-staged
+//   epilogues of the kernel above. Same products in the same order as the 4-wave kernel: bit-identical results (tests).
+// Dev builds only (tools/build_variants_f16.sh → variants/lib_<name>.so, never the shipped library): ablation bits and a timeline
+// of the ping-pong kernel. DI_PP_ABL: 1 = no DMA issue inside the loop, 8 = no fragment reads, 16 = no MFMAs (results are wrong by
+// construction: timing only), 64 = pieces issued before the fragment reads. DI_PP_TRACE: the eight waves of tile 0 stamp s_memtime
+// at kernel entry, loop begin / end, kernel end and at the start of every phase (one stamp per phase, written to LDS one phase
+// later: no extra waits) and dump them to the buffer registered with deepim_dev_pp_trace() (tools/pp_trace.py).
 #ifndef DI_PP_ABL
 #define DI_PP_ABL 0
 #endif
@@ -642,16 +655,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, TN == 2 ? 2 : 1) void conv_f16_dma_
 #endif
 #if DI_PP_TRACE
 __device__ unsigned long long* g_pp_trace = nullptr;
-constexpr int PP_TRACE_PHASES = 160;
 #endif
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, int NSTAGE>
 __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
-  constexpr int TM = 4, TN = 2, NW = 8, NSTAGE = 4;
+#if DI_PP_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int TM = 4, TN = 2, NW = 8, LA = NSTAGE - 2;
   constexpr int BM = WGM * 128, BN = WGN * 64;
-  constexpr int NPA = BM / (16 * NW), NPB = BN / (16 * NW), NP = NPA + NPB, H1 = (NP + 1) / 2;
+  constexpr int NPA = BM / (16 * NW), NPB = BN / (16 * NW), NP = NPA + NPB;
   constexpr int STAGE = (BM + BN) * 4;     // h8 per stage
-  static_assert(WGM * WGN == NW && NPA >= 1 && NPB >= 1 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
+  constexpr unsigned STAGE_B = STAGE * 16u;
+  constexpr unsigned BIAS = 4096u;         // descriptor base shifted down so that the pre-biased activation voffsets stay >= 0
+  static_assert(WGM * WGN == NW && NPA >= 1 && NPB >= 1 && NPA <= 4 && NPB <= 4 && NSTAGE >= 4 && NSTAGE * STAGE * 16 <= 160 * 1024, "tile shape");
   extern __shared__ __attribute__((aligned(16))) h8 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -675,14 +692,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
   }
   const long n0 = (long)bx * BN;
 
-  unsigned voff[NPB];
+  // activation pieces: piece i of wave w fills pixels (w·NPB + i)·16 … +15 of a stage, lane = (pixel l >> 2, slot l & 3)
+  unsigned voffl[NPB];                 // pixel origin + this lane's (swizzled) 16-byte slot − i·1024 + BIAS
   unsigned long long ninv64[NPB];
-  unsigned lane_off[NPB];
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int P = (wave * NPB + i) * 16 + (lane >> 2);
     const long pix = n0 + P;
-    voff[i] = 0x80000000u;
+    voffl[i] = 0x80000000u;
     unsigned long long m64 = 0;
     if (pix < p.npix) {
       const int hw = p.Ho * p.Wo;
@@ -690,63 +707,61 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
       const int rr = (int)(pix - (long)n * hw);
       const int ho = rr / p.Wo, wo = rr - ho * p.Wo;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      voff[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes);
+      voffl[i] = (unsigned)(((n * p.H + hi0) * p.W + wi0) * p.Cin * 2 + p.pad_bytes) + (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 16) +
+                 BIAS - (unsigned)i * 1024u;
       m64 = tap_mask64(hi0, wi0, p.H, p.W);
     }
     ninv64[i] = ~m64;
-    lane_off[i] = (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 16);
   }
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)p.in - p.pad_bytes), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes), 0x00020000);
+      (void*)((const char*)p.in - p.pad_bytes - BIAS), 0, (int)(p.in_bytes + (unsigned)p.pad_bytes + BIAS), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.wp + (long)mb * p.nchunk * (HOCT * BM)), 0, (int)((long)p.nchunk * HOCT * BM * 16), 0x00020000);
   const unsigned lds0 = (unsigned)(size_t)smem;
   const unsigned w_voff = (unsigned)((wave * NPA) * 1024 + lane * 16);
+  const unsigned ldsA = lds0 + (unsigned)(wave * NPA) * 1024u, ldsB = lds0 + (unsigned)(BM * 64) + (unsigned)(wave * NPB) * 1024u;
 
-#define DMA(ldsaddr, voffset, rsrc)                                                                      \
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"                 \
-               :: "s"(ldsaddr), "v"(voffset), "s"(rsrc) : "memory")
-  const int kw_ = p.stride_kw & 0xffff, kh_ = p.stride_kw >> 16;
-  int ic = c_begin;                                   // next chunk32 (= stage) to issue
-  int i_half, i_kx, i_ky, i_cg;
-  {
-    const int kc = c_begin >> 1, ntaps = kh_ * kw_;
-    const int tap = kc % ntaps;
-    i_half = c_begin & 1; i_cg = kc / ntaps; i_ky = tap / kw_; i_kx = tap - i_ky * kw_;
-  }
-  unsigned i_sbase = 0, i_toff = 0, i_wbase = 0;
-  int i_tbit = 0;
-  auto issue_begin = [&]() {
-    i_sbase = lds0 + (unsigned)((ic - c_begin) & (NSTAGE - 1)) * (STAGE * 16);
-    i_toff = (unsigned)(((i_ky * p.W + i_kx) * p.Cin + i_cg * 64 + i_half * 32) * 2);
-    i_tbit = i_ky * 8 + i_kx;
-    i_wbase = (unsigned)min(ic, c_end - 1) * (unsigned)(BM * 64);
+  // all pieces of one stage: one M0 write per operand, the instruction's immediate offset steps LDS and memory address together
+  auto issue_stage = [&](unsigned m0a, unsigned soffa, unsigned m0b, unsigned soffb, const unsigned (&nv)[NPB]) {
+    if constexpr (NPA == 1)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(m0a), "v"(w_voff), "s"(rsrc_w), "s"(soffa) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                   "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds"
+                   :: "s"(m0a), "v"(w_voff), "s"(rsrc_w), "s"(soffa) : "memory");
+    if constexpr (NPB == 2)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %3, %4 offen offset:1024 lds"
+                   :: "s"(m0b), "v"(nv[0]), "v"(nv[1]), "s"(rsrc_in), "s"(soffb) : "memory");
+    else
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"
+                   :: "s"(m0b), "v"(nv[0]), "v"(nv[1]), "v"(nv[NPB == 4 ? 2 : 0]), "v"(nv[NPB == 4 ? 3 : 0]), "s"(rsrc_in), "s"(soffb) : "memory");
   };
-  bool in_loop = false;
-  auto issue_piece = [&](int q) {
-    if ((DI_PP_ABL & 1) && in_loop) return;
-    if (q < NPA) {
-      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)((wave * NPA + q) * 1024));
-      DMA(la, w_voff + (unsigned)q * 1024u + ((DI_PP_ABL & 4) ? 0u : i_wbase), rsrc_w);
-    } else {
-      if ((DI_PP_ABL & 2) && in_loop) return;
-      const int i = q - NPA;
-      const unsigned la = __builtin_amdgcn_readfirstlane(i_sbase + (unsigned)(BM * 64) + (unsigned)((wave * NPB + i) * 1024));
-      const unsigned inv = (unsigned)(ninv64[i] >> ((DI_PP_ABL & 4) ? 9 : i_tbit));
-      DMA(la, ((inv << 31) | voff[i]) + ((DI_PP_ABL & 4) ? 0u : i_toff) + lane_off[i], rsrc_in);
-    }
+  // the scalars of stage `ic` (chunk32 index; past the end the last chunk is re-issued into a free slot): ring slot, weight
+  // soffset, tap table entry {byte offset of (tap, 32-channel half), validity bit}
+  // The table entry comes by a SCALAR load issued from inline asm: a compiler-visible load here would be a vector load (the DMA
+  // statements clobber memory, so the table is not provably invariant) whose compiler-placed wait is vmcnt(0) — draining the
+  // whole DMA ring every phase (cdna_hip_programming.md §5 ".s-level traps" (b)). tab_issue → (≥ one s_waitcnt lgkmcnt(0)
+  // later, stated on the register pair) → stage_prep.
+  const int2* tab_ptr = p.tab;
+  auto tab_issue = [&](int ic, unsigned long long& te) {
+    const unsigned off = (unsigned)min(ic, c_end - 1) * 32u;                          // tab[cc * 4], 8-byte entries
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(te) : "s"(tab_ptr), "s"(off) : "memory");
   };
-  auto issue_end = [&]() {
-    if (ic < c_end - 1) {                             // past the end: keep re-issuing the last chunk (its ring slot is free)
-      i_half ^= 1;
-      if (i_half == 0) {
-        if (++i_kx == kw_) {
-          i_kx = 0;
-          if (++i_ky == kh_) { i_ky = 0; ++i_cg; }
-        }
-      }
-    }
-    ++ic;
+  auto tab_wait = [&](unsigned long long& te) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(te) :: "memory"); };
+  auto stage_prep = [&](int ic, unsigned long long te, unsigned& m0a, unsigned& soffa, unsigned& m0b, unsigned& soffb, unsigned (&nv)[NPB]) {
+    const int cc = min(ic, c_end - 1);
+    const unsigned slot = (unsigned)(ic - c_begin) % (unsigned)NSTAGE;
+    m0a = ldsA + slot * STAGE_B; m0b = ldsB + slot * STAGE_B;
+    soffa = (unsigned)cc * (unsigned)(BM * 64);
+    soffb = (unsigned)(te & 0xffffffffull);
+    const int tbit = (int)(te >> 32);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) nv[i] = ((unsigned)(ninv64[i] >> tbit) << 31) | voffl[i];
   };
 
   f32x16 acc[TM][TN];
@@ -757,98 +772,129 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // prologue: stages 0 and 1 whole, the first half of stage 2 (what phases -5 … -1 of the steady state would have issued)
-  for (int pre = 0; pre < 2; ++pre) {
-    issue_begin();
+  unsigned m0a, soffa, m0b, soffb, nv[NPB];
+  unsigned long long te;
+  // prologue: stages 0 … LA−1 (what phases −LA … −1 of the steady state would have issued); stage 0 must have landed
 #pragma unroll
-    for (int q = 0; q < NP; ++q) issue_piece(q);
-    issue_end();
+  for (int pre = 0; pre < LA; ++pre) {
+    tab_issue(c_begin + pre, te);
+    tab_wait(te);
+    stage_prep(c_begin + pre, te, m0a, soffa, m0b, soffb, nv);
+    issue_stage(m0a, soffa, m0b, soffb, nv);
   }
-  issue_begin();
-#pragma unroll
-  for (int q = 0; q < H1; ++q) issue_piece(q);
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory");      // stage 0 has landed (this wave's pieces)
-  asm volatile("s_barrier" ::: "memory");                              // … everybody's
+  tab_issue(c_begin + LA, te);
+  tab_wait(te);
+  stage_prep(c_begin + LA, te, m0a, soffa, m0b, soffb, nv);            // what phase 0 issues
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LA - 1) * NP) : "memory");
+  asm volatile("s_barrier" ::: "memory");
   if (wave >= 4) asm volatile("s_barrier" ::: "memory");               // the younger half runs one barrier behind
 
   const int lrow = lane >> 5, lcol = lane & 31;
   const int sw = (lcol >> 2) & 3;
   const int nst = c_end - c_begin;
-  in_loop = true;
+  // fragment read bases of the current phase's slot (advanced inside the matrix segment for the next phase)
+  const unsigned a_lane = (unsigned)(lrow * BM + wm0 + lcol) * 16u;
+  const unsigned b_lane0 = (unsigned)(BM * 4 + (wn0 + lcol) * 4 + (lrow ^ sw)) * 16u;
+  const unsigned b_lane1 = (unsigned)(BM * 4 + (wn0 + lcol) * 4 + ((2 + lrow) ^ sw)) * 16u;
+  const char* lds_c = reinterpret_cast<const char*>(smem);
+  unsigned slot_off = 0;
+  unsigned rd_a = a_lane, rd_b0 = b_lane0, rd_b1 = b_lane1;
 #if DI_PP_TRACE
-  // timeline: [phase][wave 0 | wave 4][4 stamps] of 64-bit s_memtime in the LDS behind the ring / staging area
-  unsigned long long* tr = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 135168);
-  const bool tracing = vid == 0 && (wave & 3) == 0;
-  unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-#define PP_STAMP(x) if (tracing) x = __builtin_amdgcn_s_memtime()
-#define PP_FLUSH(ph)                                                                                                  \
-  if (tracing) {                                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
-    t_d = __builtin_amdgcn_s_memtime();                                                                               \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
-    if (lane == 0 && (ph) < PP_TRACE_PHASES) {                                                                        \
-      unsigned long long* r_ = tr + ((ph) * 2 + (wave >> 2)) * 4;                                                     \
-      r_[0] = t_a; r_[1] = t_b; r_[2] = t_c; r_[3] = t_d;                                                             \
-    }                                                                                                                 \
-  }
-#else
-#define PP_STAMP(x)
-#define PP_FLUSH(ph)
+  // dev timeline, dumped straight to global memory after the loop (global stores inside would disturb the vmcnt counting):
+  // [wave][0 entry, 1 loop begin, 2 loop end, 3 kernel end, 8 + s: start of phase s] — phase stamps kept in LDS behind the ring
+  unsigned long long* trl = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(smem) + 135168);   // NSTAGE = 4 builds only
+  const bool tracing = vid == 0 && g_pp_trace != nullptr && NSTAGE == 4;
+  const unsigned long long tr_t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_a = 0;
 #endif
-  h8 af[TM], bf[TN];
-  if (DI_PP_ABL & 8) {   // fragments read once: the loop then runs without ds_reads
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = smem[lrow * BM + wm0 + lcol + i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = smem[BM * 4 + (wn0 + lcol) * 4 + j * 128 + (lrow ^ sw)];
-  }
-  // one phase = the memory segment (fragment reads of k16-step T, ISSUE, optional counted wait), barrier, the matrix segment, barrier
-#define PP_PHASE(T, PH, ISSUE, WAIT)                                                                                  \
-  {                                                                                                                   \
-    PP_STAMP(t_a);                                                                                                    \
-    if (!(DI_PP_ABL & 8)) {                                                                                           \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = as[(T) * 2 * BM + i * 32];                               \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = bs[j * 128 + (((T) * 2 + lrow) ^ sw)];                   \
-    }                                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    ISSUE;                                                                                                            \
-    WAIT;                                                                                                             \
-    PP_STAMP(t_b);                                                                                                    \
-    asm volatile("s_barrier" ::: "memory");                                                                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    PP_STAMP(t_c);                                                                                                    \
-    __builtin_amdgcn_s_setprio(1);                                                                                    \
-    if (!(DI_PP_ABL & 16)) {                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);                       \
-    } else {                                                                                                          \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));                                  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf[j]));                                  \
-    }                                                                                                                 \
-    __builtin_amdgcn_s_setprio(0);                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                                \
-    PP_FLUSH(PH);                                                                                                     \
-    asm volatile("s_barrier" ::: "memory");                                                                           \
-  }
+  // values computed inside the matrix segment for the next memory segment are pinned there: left alone, the compiler sinks the
+  // arithmetic to its use — back into the memory segment, where every instruction lengthens the hand-over
+#define PP2_PIN(x) asm volatile("" : "+v"(x))
   for (int s = 0; s < nst; ++s) {
-    const h8* as = smem + (s & (NSTAGE - 1)) * STAGE + lrow * BM + wm0 + lcol;
-    const h8* bs = smem + (s & (NSTAGE - 1)) * STAGE + BM * 4 + (wn0 + lcol) * 4;
-    // phase 2s (even): k16-step 0 of stage s; the second half of stage s+2 is issued
-    PP_PHASE(0, 2 * s, { _Pragma("unroll") for (int q = H1; q < NP; ++q) issue_piece(q); issue_end(); }, {})
-    // phase 2s+1 (odd): k16-step 1; the first half of stage s+3 is issued; this wave's pieces of stage s+1 are waited for
-    PP_PHASE(1, 2 * s + 1, { issue_begin(); _Pragma("unroll") for (int q = 0; q < H1; ++q) issue_piece(q); },
-             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP + H1) : "memory"))
+    // ---- memory segment: 12 fragment reads of stage s, the NP pieces of stage s + LA, the counted wait
+    const char* as = lds_c + rd_a;
+    const char* bs0 = lds_c + rd_b0;
+    const char* bs1 = lds_c + rd_b1;
+    h8 af[2][TM], bf[2][TN];
+#if DI_PP_TRACE
+    if (tracing) tr_a = __builtin_amdgcn_s_memtime();        // waited for by the lgkmcnt(0) behind the barrier
+#endif
+#if DI_PP_ABL & 64
+    issue_stage(m0a, soffa, m0b, soffb, nv);      // dev: pieces first, reads second
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(DI_PP_ABL & 8)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const h8*>(as + i * 512);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const h8*>(bs0 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[1][i] = *reinterpret_cast<const h8*>(as + 2 * BM * 16 + i * 512);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[1][j] = *reinterpret_cast<const h8*>(bs1 + j * 2048);
+#else
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { af[0][i] = af[1][i] = *reinterpret_cast<const h8*>(lds_c + a_lane + i * 512); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { bf[0][j] = bf[1][j] = *reinterpret_cast<const h8*>(lds_c + b_lane0 + j * 2048); }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#if !(DI_PP_ABL & 65)
+    issue_stage(m0a, soffa, m0b, soffb, nv);
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LA - 1) * NP) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- matrix segment: 16 MFMAs; between them the scalars and voffsets of the next phase's pieces and read bases
+    __builtin_amdgcn_s_setprio(1);
+#if DI_PP_TRACE
+    if (tracing && lane == 0 && s < 120) trl[wave * 128 + 8 + s] = tr_a;
+#endif
+    tab_issue(c_begin + s + 1 + LA, te);          // lands under the first MFMAs (no LDS operation is outstanding here)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (DI_PP_ABL & 16) asm volatile("" :: "v"(af[0][i]), "v"(bf[0][j]), "v"(af[1][i]), "v"(bf[1][j]));
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);            // the table entry is waited for behind the first eight MFMAs, not before them
+    tab_wait(te);
+    stage_prep(c_begin + s + 1 + LA, te, m0a, soffa, m0b, soffb, nv);
+    slot_off = slot_off + STAGE_B == (unsigned)NSTAGE * STAGE_B ? 0u : slot_off + STAGE_B;
+    rd_a = slot_off + a_lane; rd_b0 = slot_off + b_lane0; rd_b1 = slot_off + b_lane1;
+    PP2_PIN(rd_a); PP2_PIN(rd_b0); PP2_PIN(rd_b1);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) PP2_PIN(nv[i]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (!(DI_PP_ABL & 16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+    // the ~15 scalar / vector instructions above go between the second eight MFMAs, two or three per issue gap
+#pragma unroll
+    for (int g_ = 0; g_ < 8; ++g_) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x4, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
   }
-#undef PP_PHASE
+#undef PP2_PIN
+#if DI_PP_TRACE
+  const unsigned long long tr_t2 = __builtin_amdgcn_s_memtime();
+#endif
   if (wave < 4) asm volatile("s_barrier" ::: "memory");                // the older half catches the barrier count up
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef DMA
 #if DI_PP_TRACE
-  if (vid == 0 && g_pp_trace != nullptr) {
+  if (tracing) {
     __syncthreads();
-    for (int i = tid; i < PP_TRACE_PHASES * 8; i += 512) g_pp_trace[i] = tr[i];
+    if (lane == 0) { trl[wave * 128 + 0] = tr_t0; trl[wave * 128 + 1] = tr_t1; trl[wave * 128 + 2] = tr_t2; }
+    __syncthreads();
+    for (int i = tid; i < 8 * 128; i += 512) if ((i & 127) != 3) g_pp_trace[i] = trl[i];
     __syncthreads();
   }
 #endif
@@ -856,7 +902,6 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
   if (tail_slot >= 0 || p.partial) {
     // raw fp32 partial sums through LDS staging (see conv_f16_dma_kernel): a pixel's 128 channels of this wave = 512 contiguous bytes
     constexpr int PITCH = 512 + 16;
-    static_assert(NW * 32 * PITCH <= (NSTAGE * STAGE * 16 > 135168 ? NSTAGE * STAGE * 16 : 135168), "staging area");
     __syncthreads();
     char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
     float* dst;
@@ -884,14 +929,21 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
     return;
   }
   {
-    // final output: bias + LeakyReLU in fp32, staged through LDS so that a wave writes each pixel's 256-byte run of its 128
-    // channels as 16-byte pieces (see conv_f16_dma_kernel)
     constexpr int RUN = 256, PITCH = RUN + 16, CPP = RUN / 16, PPI = 64 / CPP;
     __syncthreads();
     char* stage = reinterpret_cast<char*>(smem) + wave * (32 * PITCH);
     const int cw0 = mb * BM + wm0;
     const size_t rec_bytes = (size_t)p.Cout * 2;
     const size_t run_off = (size_t)cw0 * 2;
+    // the wave tile's 16 bias quads in ONE batch of loads, before the tile is staged: loaded quad by quad inside the loop below
+    // (where every quad is fenced off to keep the register count down) each load's L2 latency was paid in sequence — 64 dependent
+    // round trips, ~10 of a tile's ~15 thousand epilogue cycles (profiles/r04_fp16_pingpong.md)
+    float4 bias_r[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias_r[i][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + i * 32 + 8 * g + 4 * lrow) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -899,8 +951,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int cl = i * 32 + 8 * g + 4 * lrow;
-          const float4 bq = p.bias ? *reinterpret_cast<const float4*>(p.bias + cw0 + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float bias_q[4] = {bq.x, bq.y, bq.z, bq.w};
+          const float bias_q[4] = {bias_r[i][g].x, bias_r[i][g].y, bias_r[i][g].z, bias_r[i][g].w};
           h4 vh;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -922,6 +973,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16_pp_kernel(ConvF16Params p) {
       }
     }
   }
+#if DI_PP_TRACE
+  if (tracing) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) g_pp_trace[wave * 128 + 3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 // X3 split-K second pass: Σ_s partial (fixed order) → real units → bias → LeakyReLU → split16 record
@@ -1626,16 +1683,23 @@ int launch_f16_dma(deepim_ctx* ctx, ConvF16Params p, int BM, int BN, float c0, f
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<1, 4, 3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_dma_kernel<2, 4, 4, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 135168 + (DI_PP_TRACE ? 16384 : 0)));
-    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+#if DI_PP_TRACE
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 135168 + 8192));
+#endif
+    DI_CHECK(hipFuncSetAttribute((const void*)conv_f16_pp_kernel<1, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
   }
   if (getenv("DEEPIM_CONV_VERBOSE"))
     fprintf(stderr, "[deepim] %s plan B=%d Cin=%d %dx%d Cout=%d: %d tiles of %dx%d, split-K %d, tail split %d (R=%d)\n",
             X3 ? "x3" : "f16", p.B, p.Cin, p.H, p.W, p.Cout, blocks, BM, BN, p.ksplit, p.tail_s, blocks - p.n_full);
   if (pp) {
     if constexpr (!X3) {
-      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4>), dim3(grid), dim3(512), 135168 + (DI_PP_TRACE ? 16384 : 0), ctx->stream, p);
-      else hipLaunchKernelGGL((conv_f16_pp_kernel<1, 8>), dim3(grid), dim3(512), 163840, ctx->stream, p);
+#if DI_PP_TRACE
+      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4, 4>), dim3(grid), dim3(512), 135168 + 8192, ctx->stream, p);
+#else
+      if (BM == 256) hipLaunchKernelGGL((conv_f16_pp_kernel<2, 4, 5>), dim3(grid), dim3(512), 163840, ctx->stream, p);
+#endif
+      else hipLaunchKernelGGL((conv_f16_pp_kernel<1, 8, 4>), dim3(grid), dim3(512), 163840, ctx->stream, p);
     } else {
       DI_REQUIRE(false, "conv2d_x3: no ping-pong kernel");
     }
@@ -1994,7 +2058,7 @@ static int conv1_f16_launch(deepim_ctx* ctx, void* out_nhwc_f16, const float* in
 }
 
 #if DI_PP_TRACE
-// dev builds only: register the device buffer (PP_TRACE_PHASES x 2 waves x 4 stamps, 64-bit) the traced tile dumps its timeline to
+// dev builds only: register the device buffer (8 waves x 128 64-bit stamps) the traced tile dumps its timeline to
 extern "C" int deepim_dev_pp_trace(void* buf) {
   unsigned long long* b = (unsigned long long*)buf;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &b, sizeof(b));

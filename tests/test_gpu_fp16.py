@@ -58,7 +58,7 @@ def test_conv_f16_matches_emulation(ctx, case):
                                   (4, 64, 120, 160, 256, 3, 1, 1)])     # 300 tiles: 256 whole + a tail split of 44
 def test_conv_f16_pingpong_kernel(ctx, case):
     """conv_f16_pp_kernel (round 4: one 8-wave block per CU, the two waves of a SIMD alternating between fragment reads + LDS-DMA
-    issue and the MFMAs, 4-stage ring with counted vmcnt) on grids of >= 200 tiles: against the fp16 emulation (<= 1 fp16 ulp),
+    issue and the MFMAs, 4- / 5-stage ring with counted vmcnt) on grids of >= 200 tiles: against the fp16 emulation (<= 1 fp16 ulp),
     and — with K splitting off, so that both kernels add a pixel's products in the same order — BIT-IDENTICAL to the 4-wave
     kernel of round 3 (f16_dev_flags bit 16 selects it). Three repeats: a DMA / barrier ordering slip shows as rare wrong tiles."""
     B, cin, H, W, cout, k, s, p = case
@@ -72,7 +72,7 @@ def test_conv_f16_pingpong_kernel(ctx, case):
     assert np.mean(got != ref) < 0.02
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     try:
-        new = [_conv_f16(ctx, x, w, b, s, p, 0.1) for _ in range(3)]
+        new = [_conv_f16(ctx, x, w, b, s, p, 0.1) for _ in range(4)]
         lib.deepim_set_option(ctx.handle, b"f16_dev_flags", 16)
         old = _conv_f16(ctx, x, w, b, s, p, 0.1)
     finally:

@@ -1,7 +1,6 @@
-"""Dev probe: per-phase timeline of the ping-pong fp16 kernel (conv_f16_pp_kernel built with -DDI_PP_TRACE=1:
-tools/build_variants_f16.sh trace:"-DDI_PP_TRACE=1"; run with DEEPIM_LIB=variants/lib_trace.so). Waves 0 and 4 of tile 0 stamp
-s_memtime at the start of a phase's memory segment (a), before its first barrier (b: reads issued, DMA pieces issued, counted wait
-done), after the barrier + lgkmcnt(0) (c) and after the last MFMA was issued (d). usage: pp_trace.py [layer index 1..5] [B]"""
+"""Dev probe: timeline of tile 0 of the second ping-pong kernel (build: tools/build_variants_f16.sh trace:"-DDI_PP_TRACE=1", run
+with DEEPIM_LIB=variants/lib_trace.so): per wave the prologue, K loop and epilogue durations and the phase period (one s_memtime per
+phase, written one phase later: no extra waits). usage: pp_trace.py [layer 1..5] [B]"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,8 +22,7 @@ pk = DeviceArray(ctx, (lib.load().deepim_conv_f16_packed_size(cout, cin, k, k) /
 lib.deepim_conv_f16_pack_weights(ctx.handle, pk, wt, cout, cin, cin, k, k)
 ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 out = ctx.empty((B, ho, wo, cout), dtype=np.float16)
-NPH = 160
-tr = ctx.zeros((NPH * 8,), dtype=np.uint64)
+tr = ctx.zeros((8 * 128,), dtype=np.uint64)
 fn = lib.load().deepim_dev_pp_trace
 fn.argtypes = [ctypes.c_void_p]
 assert fn(ctypes.c_void_p(tr.ptr)) == 0
@@ -32,21 +30,18 @@ args = (ctx.handle, out, x, pk, ctx.zeros((cout,)), B, cin, h, w, cout, k, k, s,
 for _ in range(3):
     lib.deepim_conv2d_f16_forward(*args)
 ctx.sync()
-t = tr.asnumpy().reshape(NPH, 2, 4).astype(np.int64)
-nph = min(NPH, 2 * (k * k * cin // 32))
-print("%s: Cin %d %dx%d Cout %d k%d s%d, B = %d; s_memtime ticks (shader clock); wave 0 | wave 4" % (name, cin, h, w, cout, k, s, B))
-print("phase    mem  bar+lgkm  mfma  period |   mem  bar+lgkm  mfma  period")
-rows = []
-for ph in range(4, nph - 4):
-    r = []
-    for wv in range(2):
-        a, b, c, d = t[ph, wv]
-        r += [b - a, c - b, d - c, t[ph + 1, wv, 0] - a]
-    rows.append(r)
-    if ph < 24:
-        print("%5d  %5d  %7d  %5d  %6d | %5d  %7d  %5d  %6d" % tuple([ph] + r))
-rows = np.array(rows)
-print("median %5d  %7d  %5d  %6d | %5d  %7d  %5d  %6d" % tuple(np.median(rows, 0).astype(int)))
-print("mean   %5d  %7d  %5d  %6d | %5d  %7d  %5d  %6d" % tuple(rows.mean(0).astype(int)))
-print("even-phase median (B pieces issued) %s   odd-phase median (A pieces + counted wait) %s" % (
-    np.median(rows[0::2], 0).astype(int).tolist(), np.median(rows[1::2], 0).astype(int).tolist()))
+tm = ctx.timer(); tm.start()
+for _ in range(5):
+    lib.deepim_conv2d_f16_forward(*args)
+tm.stop()
+ms = tm.elapsed_ms() / 5
+t = tr.asnumpy().reshape(8, 128).astype(np.int64)
+nst = min(120, k * k * cin // 32)
+print("%s: Cin %d %dx%d Cout %d k%d s%d, B = %d: %.3f ms per call; %d stages per tile; s_memtime ticks" % (name, cin, h, w, cout, k, s, B, ms, k * k * cin // 32))
+print("wave  prologue     loop  epilogue    total | phase period: median   min   max  (stages 4..%d)" % (nst - 2))
+for wv in range(8):
+    a = t[wv, 8:8 + nst]
+    per = np.diff(a[4:nst - 1])
+    print("%4d  %8d %8d  %8d %8d |                 %6d %5d %5d" % (wv, t[wv, 1] - t[wv, 0], t[wv, 2] - t[wv, 1], t[wv, 3] - t[wv, 2], t[wv, 3] - t[wv, 0],
+                                                                     np.median(per), per.min(), per.max()))
+print("wave 4 starts its phase %d ticks after wave 0 (median)" % np.median(t[4, 12:8 + nst - 2] - t[0, 12:8 + nst - 2]))
