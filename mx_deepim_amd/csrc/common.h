@@ -20,7 +20,10 @@ constexpr int DI_F16_W8 = 2;       // one 8-wave block per CU on a 256x256 tile
 constexpr int DI_F16_NO_TAIL = 4;  // no tail split of the under-filled last round
 constexpr int DI_F16_NO_DMA = 8;   // register-staged kernel instead of the LDS-DMA ring
 constexpr int DI_F16_NO_PP = 16;   // no ping-pong kernel (round 4): every LDS-DMA layer on the 4-wave kernel, as in round 3
-constexpr int DI_F16_PP_MIN_TILES = 200;   // ping-pong kernel only where 256x256 (128x512) tiles fill most of the 256 CUs
+#ifndef DI_PP_MIN_TILES
+#define DI_PP_MIN_TILES 64
+#endif
+constexpr int DI_F16_PP_MIN_TILES = DI_PP_MIN_TILES;   // ping-pong kernel from 64 tiles of 256x256 (128x512) on (measured, profiles/r04_fp16_pingpong.md): with fewer the 4-wave kernel on 256x128 tiles, two blocks per CU
 
 struct ConvTab { int mode, Cin, kh, kw, H, W; void* tab; };  // im2col tap table of one conv geometry
 

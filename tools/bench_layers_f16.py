@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mx_deepim_amd.runtime import Context, DeviceArray, lib
 from mx_deepim_amd.symbols.deepIM_flownet import ENCODER
 ctx = Context.get(0)
+for o in os.environ.get("DEEPIM_OPT", "").split(","):      # e.g. DEEPIM_OPT=conv_max_split=4
+    if "=" in o:
+        lib.deepim_set_option(ctx.handle, o.split("=")[0].encode(), int(o.split("=")[1]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cin0 = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 variants = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "16"])]
