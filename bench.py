@@ -395,8 +395,7 @@ class Loop(object):
             if args.heads:
                 net.decoder()
                 net.heads()
-            net.pose_head()
-            net.pose_update(pose_cur, pose_cur)   # refined pose becomes the next iteration's src_pose
+            net.pose_head_update(pose_cur, pose_cur)   # fc6 → (fc7 → rot/trans → se3 → RT_transform in one launch): the refined pose becomes the next iteration's src_pose
             if tap is not None:
                 tap("out", it, data)
             if self.world > 1:                     # every rank/host gets all refined poses

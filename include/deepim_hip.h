@@ -389,6 +389,16 @@ int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pose_est64, co
 int deepim_calc_rt_delta(deepim_ctx* ctx, float* rot /*B,4*/, float* trans /*B,3*/, const float* pose_src,
                          const float* pose_tgt, const float* T_means_host, const float* T_stds_host,
                          int rot_coord, int B);
+/* The tail of one test-graph refinement iteration in ONE launch: fc7 (FullyConnected 256 → 256 + LeakyReLU,
+ * deepIM_flownet.py:114-116) → rot / trans FullyConnected + inverse ZoomTrans → se3 (:715-726, zoom_trans.py:22-46) →
+ * RT_transform (lib/pair_matching/RT_transform.py:127-151, quaternion form) — the same sums in the same order as
+ * deepim_fc_forward + deepim_pose_head_forward + deepim_rt_transform, hence bit-identical to them. fc7_out (B,256), se3 (B,7),
+ * pose_est (B,3,4; may be pose_src: in-place update), fc6 (B,256); feat must be 256. */
+int deepim_pose_tail_forward(deepim_ctx* ctx, float* fc7_out, float* se3, float* pose_est, const float* fc6,
+                             const float* w_fc7, const float* b_fc7, const float* w_rot, const float* b_rot,
+                             const float* w_trans, const float* b_trans, const float* zoom_factor,
+                             const float* pose_src, const float* T_means_host, const float* T_stds_host, int rot_coord,
+                             int B, int feat, float slope);
 /* RT_transform with an Euler-angle rotation (ROT_TYPE EULER: r.shape[0] == 3 → euler2mat(r0, r1, r2), static xyz axes,
  * RT_transform.py:130-131, :240-307): euler_trans (B,6) = [euler(3) | trans(3)]. */
 int deepim_rt_transform_euler(deepim_ctx* ctx, float* pose_est, double* pose_est64, const float* pose_src,

@@ -41,6 +41,10 @@ struct deepim_ctx {
   void* comm;        // ncclComm_t of this rank (csrc/comm.hip), NULL in a single-GPU process
   int comm_rank, comm_world;
   int* box_words;   // DI_MAX_BOX_SAMPLES x {xmin,xmax,ymin,ymax}: bbox accumulators of mask_box, armed inside every call
+  int* zoom_box;    // DI_MAX_BOX_SAMPLES x 2 maps x {xmin,xmax,ymin,ymax}: bbox accumulators of the zoom-factor computation; armed at
+                    // creation and RE-ARMED BY THEIR CONSUMER (zoom_factor_kernel resets what it read), so a call needs no init launch
+  unsigned long long* zbuf;   // rasteriser z-buffer (key = depth bits << 32 | triangle): all-ones between calls — the resolve pass
+  size_t zbuf_bytes;          // puts every entry back after reading it, so a draw needs no clearing pass (grow-only, cleared on growth)
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
   hipEvent_t sync_event;   // deepim_stream_wait: "everything queued on this stream so far" (created on first use)

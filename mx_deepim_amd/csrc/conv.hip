@@ -707,8 +707,11 @@ __device__ __forceinline__ void conv_direct_body(const ConvParams& p, const int 
 
 // ---------------------------------------------------------------------------------------------------------------
 
+#ifndef DIRECT_OCC1
+#define DIRECT_OCC1 DIRECT_OCC   // conv1's 64x256-tile instance on its own: dev builds try 5 blocks per CU (<= 96 VGPRs)
+#endif
 template <int WMW>
-__global__ __launch_bounds__(256, DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, WMW == 1 ? DIRECT_OCC1 : DIRECT_OCC) void conv_direct_kernel(ConvParams p) {
   conv_direct_body<WMW>(p, blockIdx.x);
 }
 

@@ -10,6 +10,7 @@
 // 8 rows: 43 µs for fc6 at B = 16). Partials are reduced in a fixed order by a second tiny
 // kernel (deterministic, no float atomics) that also applies bias + LeakyReLU.
 #include "common.h"
+#include "pose_head.h"
 
 namespace {
 
@@ -237,26 +238,11 @@ __global__ __launch_bounds__(64) void pose_head_kernel(float* __restrict__ se3, 
                                                        const float* __restrict__ b_trans,
                                                        const float* __restrict__ zoom_factor, int F) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  float acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int k = lane; k < F; k += 64) {
-    const float x = feat[(long)b * F + k];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = fmaf(x, w_rot[r * F + k], acc[r]);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) acc[4 + r] = fmaf(x, w_trans[r * F + k], acc[4 + r]);
-  }
-#pragma unroll
-  for (int r = 0; r < 7; ++r)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+  float o[7];
+  di_pose_head_wave(o, feat + (long)b * F, w_rot, b_rot, w_trans, b_trans, zoom_factor[b * 4 + 0], F, lane);
   if (lane == 0) {
-    const float wx = zoom_factor[b * 4 + 0];
-    float* o = se3 + b * 7;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = acc[r] + b_rot[r];
-    o[4] = (acc[4] + b_trans[0]) * wx;  // ZoomTrans b_inv_zoom=True (zoom_trans.py:34-37)
-    o[5] = (acc[5] + b_trans[1]) * wx;
-    o[6] = acc[6] + b_trans[2];
+    for (int r = 0; r < 7; ++r) se3[b * 7 + r] = o[r];
   }
 }
 

@@ -137,7 +137,7 @@ struct LitParams {
 
 // attr: per-vertex attributes — 3 floats RGB (0..255) when tex == nullptr, else 2 floats uv
 __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image, float* __restrict__ depth,
-                                                      const unsigned long long* __restrict__ zbuf,
+                                                      unsigned long long* __restrict__ zbuf,
                                                       const PV* __restrict__ pv_all, const int* __restrict__ faces,
                                                       const float* __restrict__ attr, const float* __restrict__ tex,
                                                       int TH, int TW, Vec3 means, int V, int H, int W, float znear,
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(float* __restrict__ image,
   const long plane = (long)H * W;
   const bool inside = p < plane;
   const unsigned long long key = inside ? zbuf[(long)b * plane + p] : ~0ull;
+  if (inside && key != ~0ull) zbuf[(long)b * plane + p] = ~0ull;      // the z-buffer leaves the call as it entered it: all-ones
   float rgb[3] = {0.f, 0.f, 0.f};
   float z = 0.f;
   if (key != ~0ull) {
@@ -242,10 +243,21 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
   const size_t zbytes = (size_t)B * H * W * sizeof(unsigned long long);
   const size_t pbytes = (size_t)B * V * sizeof(PV);
   void* scratch;
-  int rc = deepim_scratch(ctx, zbytes + pbytes + 64, &scratch);
+  int rc = deepim_scratch(ctx, pbytes + 64, &scratch);
   if (rc) return rc;
-  unsigned long long* zbuf = (unsigned long long*)scratch;
-  PV* pv = (PV*)((char*)scratch + zbytes);
+  // The z-buffer is the context's own (not the shared scratch): all-ones between calls — the resolve pass resets what the raster
+  // pass touched — so a draw carries no clearing pass (8 B/px of writes and one launch per refinement iteration). Grow-only.
+  if (ctx->zbuf_bytes < zbytes) {
+    DI_REQUIRE(!ctx->capturing, "render: z-buffer growth during graph capture; run the sequence once eagerly first");
+    DI_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->zbuf) DI_CHECK(hipFree(ctx->zbuf));
+    ctx->zbuf = nullptr; ctx->zbuf_bytes = 0;
+    DI_CHECK(hipMalloc((void**)&ctx->zbuf, zbytes));
+    ctx->zbuf_bytes = zbytes;
+    DI_CHECK(hipMemsetAsync(ctx->zbuf, 0xff, zbytes, ctx->stream));
+  }
+  unsigned long long* zbuf = ctx->zbuf;
+  PV* pv = (PV*)scratch;
   Mat3 K;
   for (int i = 0; i < 9; ++i) K.v[i] = K_host[i];
   Vec3 means = {{0, 0, 0}};
@@ -256,7 +268,6 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
     lit.verts = vertices; lit.normals = normals;
     if (light_offset_host) for (int i = 0; i < 3; ++i) lit.light_offset.v[i] = light_offset_host[i];
   }
-  DI_CHECK(hipMemsetAsync(zbuf, 0xff, zbytes, ctx->stream));
   hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V,
                      words);
   hipLaunchKernelGGL(raster_kernel, dim3(di_div_up(F, 256), B), dim3(256), 0, ctx->stream, zbuf, pv, (const int*)faces, V,

@@ -2,6 +2,7 @@
 // hipGraph capture. Replaces the MXNet context/NDArray plumbing the reference's
 // Predictor relies on (deepim/core/tester.py:27-47).
 #include "common.h"
+#include <limits.h>
 
 static thread_local char g_err[512] = "";
 
@@ -51,11 +52,17 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
     return (int)e;
   }
   // status word + the bbox accumulators of deepim_mask_box_forward
-  const size_t box_bytes = (size_t)DI_MAX_BOX_SAMPLES * 4 * sizeof(int);
-  e = hipMalloc((void**)&c->status, 64 + box_bytes);
+  const size_t box_bytes = (size_t)DI_MAX_BOX_SAMPLES * 4 * sizeof(int), zbox_bytes = (size_t)DI_MAX_BOX_SAMPLES * 8 * sizeof(int);
+  c->zbuf = nullptr;
+  c->zbuf_bytes = 0;
+  e = hipMalloc((void**)&c->status, 64 + box_bytes + zbox_bytes);
   if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 64, c->stream);
   if (e == hipSuccess) {
     c->box_words = c->status + 16;
+    c->zoom_box = c->box_words + (size_t)DI_MAX_BOX_SAMPLES * 4;
+    std::vector<int> init((size_t)DI_MAX_BOX_SAMPLES * 8);
+    for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? -1 : INT_MAX;      // {minx,maxx,miny,maxy}: empty boxes
+    e = hipMemcpy(c->zoom_box, init.data(), zbox_bytes, hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     deepim_set_error("hipMalloc(status)", e);
@@ -73,6 +80,7 @@ extern "C" int deepim_destroy(deepim_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->comm) deepim_comm_destroy(ctx);
   for (auto g : ctx->graphs) hipGraphExecDestroy(g);
+  if (ctx->zbuf) hipFree(ctx->zbuf);
   for (auto e : ctx->timer_start) hipEventDestroy(e);
   for (auto e : ctx->timer_stop) hipEventDestroy(e);
   if (ctx->sync_event) hipEventDestroy(ctx->sync_event);

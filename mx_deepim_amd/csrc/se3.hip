@@ -9,6 +9,7 @@
 // full rate on CDNA4; the work is a few hundred flops per pair). Reductions over the
 // N model points use wavefront shuffles + one LDS hop.
 #include "common.h"
+#include "pose_head.h"
 
 namespace {
 
@@ -78,13 +79,9 @@ __device__ void quat2mat_checked_f64(float w, float x, float y, float z, double*
 }
 
 // r_len = 4: se3 rows are [quat(4) | trans(3)] (ROT_TYPE QUAT); r_len = 3: [euler(3) | trans(3)] (ROT_TYPE EULER, :130-131)
-__global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __restrict__ pose_est64,
-                                    const float* __restrict__ pose_src, const float* __restrict__ se3, Vec3d mu,
-                                    Vec3d sd, int rc, int B, int r_len) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float* P = pose_src + b * 12;
-  const float* q = se3 + b * (r_len + 3);
+// one sample: P = its source pose (12 floats), q = its se3 row [rotation(r_len) | translation(3)]
+__device__ void rt_transform_one(float* __restrict__ pose_est, double* __restrict__ pose_est64, const float* P, const float* q,
+                                 const Vec3d& mu, const Vec3d& sd, int rc, int b, int r_len) {
   const float* t = q + r_len;
   double Rd[9];
   if (r_len == 3) {
@@ -118,6 +115,68 @@ __global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __rest
   for (int i = 0; i < 12; ++i) {
     pose_est[b * 12 + i] = (float)out[i];
     if (pose_est64) pose_est64[b * 12 + i] = out[i];
+  }
+}
+
+__global__ void rt_transform_kernel(float* __restrict__ pose_est, double* __restrict__ pose_est64,
+                                    const float* __restrict__ pose_src, const float* __restrict__ se3, Vec3d mu,
+                                    Vec3d sd, int rc, int B, int r_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float P[12], q[7];
+  for (int i = 0; i < 12; ++i) P[i] = pose_src[b * 12 + i];      // copied first: pose_est may be pose_src (in-place update)
+  for (int i = 0; i < r_len + 3; ++i) q[i] = se3[b * (r_len + 3) + i];
+  rt_transform_one(pose_est, pose_est64, P, q, mu, sd, rc, b, r_len);
+}
+
+// The tail of a test-graph refinement iteration in ONE launch (one 1024-thread block per sample): fc7 (256 → 256, LeakyReLU)
+// → rot / trans FullyConnected + inverse ZoomTrans → se3 → RT_transform — what deepim_fc_forward (two kernels) +
+// deepim_pose_head_forward + deepim_rt_transform run as four dependent 4-5 µs launches (at the per-GPU share of config 3, B = 4,
+// that tail was 1.5 % of the iteration). Same sums in the same order, so bit-identical to the four launches:
+//   fc7: the order of fc_partial_kernel / fc_finalize_kernel for I = 256 (one K slice): lane l multiplies k = 4l … 4l+3 in a
+//   fmaf chain from 0, the 64 lane sums are added by the xor butterfly 32 → 1 (fp addition is commutative, so the reduce-scatter
+//   form there and the all-reduce form here give the same value), then + bias, LeakyReLU;
+//   pose head: di_pose_head_wave (csrc/pose_head.h); RT_transform: rt_transform_one above.
+__global__ __launch_bounds__(1024) void pose_tail_kernel(float* __restrict__ fc7_out, float* __restrict__ se3, float* __restrict__ pose_est,
+                                                         const float* __restrict__ fc6, const float* __restrict__ w7,
+                                                         const float* __restrict__ b7, const float* __restrict__ w_rot,
+                                                         const float* __restrict__ b_rot, const float* __restrict__ w_trans,
+                                                         const float* __restrict__ b_trans, const float* __restrict__ zoom_factor,
+                                                         const float* __restrict__ pose_src, Vec3d mu, Vec3d sd, int rc, float slope) {
+  // 16 waves per sample, 16 fc7 outputs per wave: every wave issues its 16 weight rows (1 KB each, one dwordx4 per lane) in ONE
+  // batch — with few blocks on the chip the kernel is pure load latency, so the loads must not queue behind one another
+  __shared__ float f7[256];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 xv = *reinterpret_cast<const float4*>(fc6 + (long)b * 256 + lane * 4);
+  float4 wv[16];
+#pragma unroll
+  for (int oo = 0; oo < 16; ++oo) wv[oo] = *reinterpret_cast<const float4*>(w7 + (long)(wave * 16 + oo) * 256 + lane * 4);
+  const float bias = (lane < 16 && b7) ? b7[wave * 16 + lane] : 0.f;
+  float keep = 0.f;
+#pragma unroll
+  for (int oo = 0; oo < 16; ++oo) {
+    float a = 0.f;
+    a = fmaf(xv.x, wv[oo].x, a); a = fmaf(xv.y, wv[oo].y, a); a = fmaf(xv.z, wv[oo].z, a); a = fmaf(xv.w, wv[oo].w, a);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == oo) keep = a;        // lane oo keeps output oo of this wave
+  }
+  if (lane < 16) {
+    float v = keep + bias;
+    v = v > 0.f ? v : v * slope;
+    f7[wave * 16 + lane] = v;
+    fc7_out[(long)b * 256 + wave * 16 + lane] = v;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float q[7], P[12];
+    di_pose_head_wave(q, f7, w_rot, b_rot, w_trans, b_trans, zoom_factor[b * 4 + 0], 256, lane);
+    if (lane == 0) {
+      for (int i = 0; i < 12; ++i) P[i] = pose_src[b * 12 + i];
+#pragma unroll
+      for (int r = 0; r < 7; ++r) se3[b * 7 + r] = q[r];
+      rt_transform_one(pose_est, nullptr, P, q, mu, sd, rc, b, 4);
+    }
   }
 }
 
@@ -556,6 +615,24 @@ extern "C" int deepim_rt_transform(deepim_ctx* ctx, float* pose_est, double* pos
   DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "rt_transform: unknown rot_coord");
   hipLaunchKernelGGL(rt_transform_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, pose_est, pose_est64,
                      pose_src, se3, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord, B, 4);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int deepim_pose_tail_forward(deepim_ctx* ctx, float* fc7_out, float* se3, float* pose_est, const float* fc6,
+                                        const float* w_fc7, const float* b_fc7, const float* w_rot, const float* b_rot,
+                                        const float* w_trans, const float* b_trans, const float* zoom_factor,
+                                        const float* pose_src, const float* T_means_host, const float* T_stds_host, int rot_coord,
+                                        int B, int feat, float slope) {
+  DI_DEVICE(ctx);
+  if (B == 0) return 0;
+  DI_REQUIRE(feat == 256, "pose_tail: built for the network's 256-wide fc6 / fc7 (deepIM_flownet.py:112-116)");
+  DI_REQUIRE(rot_coord >= 0 && rot_coord <= 3, "pose_tail: unknown rot_coord");
+  DI_REQUIRE(fc7_out && se3 && pose_est && fc6 && w_fc7 && w_rot && w_trans && b_rot && b_trans && zoom_factor && pose_src,
+             "pose_tail: NULL argument");
+  hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(1024), 0, ctx->stream, fc7_out, se3, pose_est, fc6, w_fc7, b_fc7, w_rot, b_rot,
+                     w_trans, b_trans, zoom_factor, pose_src, vec3d_from(T_means_host, 0.0), vec3d_from(T_stds_host, 1.0), rot_coord,
+                     slope);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -85,13 +85,20 @@ __global__ __launch_bounds__(256) void bbox_kernel(int* __restrict__ box, const 
 // reference's own lines): K·t and the centre cx = c0/c2 are float32; everything after that mixes the
 // float32 scalar with Python ints / int64 box edges and is therefore float64 — distances, crop, and
 // tx = cx / W * 2 - 1 — rounded once when stored to the float32 zoom_factor.
+// rearm: the accumulators are the context's persistent ones — put them back to "empty" once read, so that the NEXT zoom-factor
+// computation needs no init launch (they are armed at context creation; every consumer re-arms exactly what it read)
 __global__ void zoom_factor_kernel(float* __restrict__ zoom_factor, int* __restrict__ status,
-                                   const int* __restrict__ box, const float* __restrict__ src_pose, Mat3 K, int B,
-                                   int H, int W) {
+                                   int* __restrict__ box, const float* __restrict__ src_pose, Mat3 K, int B,
+                                   int H, int W, int rearm) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int* real = box + (b * 2 + 0) * 4;
-  const int* rend = box + (b * 2 + 1) * 4;
+  int real[4], rend[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { real[i] = box[(b * 2 + 0) * 4 + i]; rend[i] = box[(b * 2 + 1) * 4 + i]; }
+  if (rearm) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) box[b * 8 + i] = (i & 1) ? -1 : INT_MAX;
+  }
   float* zf = zoom_factor + b * 4;
   if (real[1] < 0) {  // reference raises ValueError (np.min of empty) — flag it
     const float nanv = __int_as_float(0x7fc00000);
@@ -545,18 +552,24 @@ Mat3 mat3_from(const float* h) { Mat3 m; for (int i = 0; i < 9; ++i) m.v[i] = h[
 // boxes + factor; scratch layout: [B*2*4 int boxes]; status word lives in ctx->status
 int compute_zoom_factor(deepim_ctx* ctx, float* zoom_factor, const float* map0, const float* map1, int mode0, int mode1,
                         const float* means3, const float* src_pose, const float* K_host, int B, int H, int W) {
-  void* scratch;
-  int rc = deepim_scratch(ctx, (size_t)(B * 8) * sizeof(int), &scratch);
-  if (rc) return rc;
-  int* box = (int*)scratch;
+  // up to DI_MAX_BOX_SAMPLES pairs the accumulators are the context's persistent, self-re-arming ones (no init launch: one of the
+  // ~4 µs launches per refinement iteration that carry no work); larger batches arm a scratch copy as before
+  const bool persistent = B <= DI_MAX_BOX_SAMPLES;
+  int* box = ctx->zoom_box;
+  if (!persistent) {
+    void* scratch;
+    int rc = deepim_scratch(ctx, (size_t)(B * 8) * sizeof(int), &scratch);
+    if (rc) return rc;
+    box = (int*)scratch;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(di_div_up(B * 8, 256)), dim3(256), 0, ctx->stream, box, B * 8);
+  }
   int* status = ctx->status;
   Vec3 means = {{0, 0, 0}};
   if (means3) for (int i = 0; i < 3; ++i) means.v[i] = means3[i];
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(di_div_up(B * 8, 256)), dim3(256), 0, ctx->stream, box, B * 8);
   dim3 grid(di_div_up(H, BB_ROWS), B, 2);
   hipLaunchKernelGGL(bbox_kernel, grid, dim3(256), 0, ctx->stream, box, map0, map1, mode0, mode1, means, H, W);
   hipLaunchKernelGGL(zoom_factor_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, zoom_factor, status, box,
-                     src_pose, mat3_from(K_host), B, H, W);
+                     src_pose, mat3_from(K_host), B, H, W, persistent ? 1 : 0);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -523,6 +523,18 @@ class deepIM_flownet(object):
         lib.deepim_pose_head_forward(h, A["se3"], A["fc7"], P["rot_weight"], P["rot_bias"], P["trans_weight"],
                                      P["trans_bias"], A["zoom_factor"], B, 256)
 
+    def pose_head_update(self, src_pose, pose_out=None):
+        """pose_head() + pose_update() with everything behind fc6 in ONE launch (deepim_pose_tail_forward: fc7 → rot / trans +
+        inverse ZoomTrans → se3 → RT_transform); bit-identical to the separate calls, fills the same activations (fc6, fc7,
+        se3) and returns the refined poses. `pose_out` may be `src_pose` (in-place update, as the refinement loop does)."""
+        A, P, h, B = self.act, self.params, self.ctx.handle, self.B
+        out = A["pose_est"] if pose_out is None else pose_out
+        self._fc6(A["conv6_1"].reshape((B, -1)))
+        lib.deepim_pose_tail_forward(h, A["fc7"], A["se3"], out, A["fc6"], P["fc7_weight"], P["fc7_bias"], P["rot_weight"],
+                                     P["rot_bias"], P["trans_weight"], P["trans_bias"], A["zoom_factor"], src_pose, self.T_means,
+                                     self.T_stds, self.rot_coord, B, 256, ctypes.c_float(SLOPE))
+        return out
+
     def decoder(self):
         """FlowNetS refinement (deepIM_flownet.py:120-167)."""
         A, h, B = self.act, self.ctx.handle, self.B
@@ -588,8 +600,12 @@ class deepIM_flownet(object):
     def refine_iteration(self, data, pose_out=None):
         """One pose-refinement iteration for the bound batch: zoom → network → inverse ZoomTrans →
         RT_transform.  `data["src_pose"]` is the current estimate; returns the refined (B,3,4) poses."""
-        self.forward(data)
-        return self.pose_update(data["src_pose"], pose_out)
+        self.zoom(data)
+        self.encoder()
+        if self.with_decoder:
+            self.decoder()
+            self.heads()
+        return self.pose_head_update(data["src_pose"], pose_out)
 
 
 # ------------------------------------------------------------------------------------------------- training ----

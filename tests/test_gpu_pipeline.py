@@ -168,3 +168,44 @@ def test_opt_in_conv1_from_channel_blocked_net_input(ctx, small_batch):
     np.testing.assert_array_equal(net.activation_nchw("flow_conv1").asnumpy(), ref["flow_conv1"])
     np.testing.assert_array_equal(net.act["conv6_1"].asnumpy(), ref["conv6_1"])
     assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_fused_pose_tail_is_bit_identical_to_the_separate_launches(ctx, B):
+    """deepim_pose_tail_forward (fc7 → rot / trans + inverse ZoomTrans → se3 → RT_transform in ONE launch, round 4) against
+    deepim_fc_forward + deepim_pose_head_forward + deepim_rt_transform on the same inputs: fc7, se3 and the refined poses equal
+    bit for bit in all four rot_coords, also when the poses are updated in place (pose_out = src_pose, as the loop does)."""
+    import ctypes
+    rng = np.random.default_rng(40 + B)
+    cf = ctypes.c_float
+    fc6 = rng.standard_normal((B, 256)).astype(np.float32)
+    w7 = (rng.standard_normal((256, 256)) / 16).astype(np.float32)
+    b7 = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    w_rot = (rng.standard_normal((4, 256)) * 0.05).astype(np.float32)
+    b_rot = np.array([1.0, 0.01, -0.02, 0.03], np.float32)
+    w_tr = (rng.standard_normal((3, 256)) * 0.01).astype(np.float32)
+    b_tr = (rng.standard_normal(3) * 0.01).astype(np.float32)
+    zf = np.concatenate([rng.uniform(0.3, 0.9, (B, 1)).repeat(2, 1), rng.uniform(-0.2, 0.2, (B, 2))], 1).astype(np.float32)
+    poses = np.stack([synthetic.sample_pose_pair(rng)[1] for _ in range(B)]).astype(np.float32)
+    mu, sd = np.array([0.01, -0.02, 0.03], np.float32), np.array([0.9, 1.1, 1.05], np.float32)
+    d = {k: ctx.array(v) for k, v in dict(fc6=fc6, w7=w7, b7=b7, w_rot=w_rot, b_rot=b_rot, w_tr=w_tr, b_tr=b_tr, zf=zf).items()}
+    h = ctx.handle
+    for rc in range(4):
+        src = ctx.array(poses)
+        f7a, se3a, posea = ctx.empty((B, 256)), ctx.empty((B, 7)), ctx.empty((B, 3, 4))
+        lib.deepim_fc_forward(h, f7a, d["fc6"], d["w7"], d["b7"], B, 256, 256, cf(0.1))
+        lib.deepim_pose_head_forward(h, se3a, f7a, d["w_rot"], d["b_rot"], d["w_tr"], d["b_tr"], d["zf"], B, 256)
+        lib.deepim_rt_transform(h, posea, None, src, se3a, mu, sd, rc, B)
+        f7b, se3b, poseb = ctx.empty((B, 256)), ctx.empty((B, 7)), ctx.empty((B, 3, 4))
+        lib.deepim_pose_tail_forward(h, f7b, se3b, poseb, d["fc6"], d["w7"], d["b7"], d["w_rot"], d["b_rot"], d["w_tr"], d["b_tr"],
+                                     d["zf"], src, mu, sd, rc, B, 256, cf(0.1))
+        np.testing.assert_array_equal(f7b.asnumpy(), f7a.asnumpy())
+        np.testing.assert_array_equal(se3b.asnumpy(), se3a.asnumpy())
+        np.testing.assert_array_equal(poseb.asnumpy(), posea.asnumpy())
+        assert np.abs(poseb.asnumpy() - poses).max() > 1e-4
+        lib.deepim_pose_tail_forward(h, f7b, se3b, src, d["fc6"], d["w7"], d["b7"], d["w_rot"], d["b_rot"], d["w_tr"], d["b_tr"],
+                                     d["zf"], src, mu, sd, rc, B, 256, cf(0.1))            # in place
+        np.testing.assert_array_equal(src.asnumpy(), posea.asnumpy())
+    with pytest.raises(RuntimeError):
+        lib.deepim_pose_tail_forward(h, f7b, se3b, poseb, d["fc6"], d["w7"], d["b7"], d["w_rot"], d["b_rot"], d["w_tr"], d["b_tr"],
+                                     d["zf"], src, mu, sd, 0, B, 128, cf(0.1))

@@ -16,7 +16,7 @@ def short(n):
     return re.sub(r"\(.*$", "", n)[:70]
 
 
-marks = [i for i, r in enumerate(rows) if "rt_transform_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "rt_transform_kernel" in r["Kernel_Name"] or "pose_tail_kernel" in r["Kernel_Name"]]
 lo = marks[-nlast - 1] + 1
 hi = marks[-1] + 1
 tot_k = tot_g = 0.0
