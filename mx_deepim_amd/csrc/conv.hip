@@ -1053,6 +1053,9 @@ struct ReduceGroup {
   const float* ep_y;      // activation-gradient epilogue (ConvParams::ep_*)
   const float* ep_add;
   float ep_slope;
+  const float* bias;      // forward use (transposed convolution of the decoder): + bias, LeakyReLU, channel slice of a Concat
+  float slope;
+  int out_ctotal, out_coff;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup g) {
   const int b = blockIdx.x;
@@ -1073,7 +1076,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup g)
   for (int s = 1; s < g.S[m]; ++s) v += partial[(long)s * stride + i];
   const int c = (int)((i / hw) % g.Cout);
   const long n = i / ((long)hw * g.Cout);
-  const long o = (n * g.Cout + c) * plane + poff;
+  const long o = (n * g.out_ctotal + g.out_coff + c) * plane + poff;
+  v += g.bias ? g.bias[c] : 0.f;
+  v = v > 0.f ? v : v * g.slope;
   if (g.ep_y) {
     if (g.ep_add) v += g.ep_add[o];
     v = g.ep_y[o] > 0.f ? v : v * g.ep_slope;
@@ -1665,8 +1670,12 @@ int actgrad_pass(deepim_ctx* ctx, float* dx, const ActGrad& ag, size_t n) {
 }
 }  // namespace
 
+// forward use of the same machinery (a transposed convolution IS the data gradient of a stride-2 convolution): explicit size of the
+// input map (the Crop may keep fewer rows than the adjoint's full frame), bias + LeakyReLU + channel slice in the final stores,
+// weights packed once (pack_only fills packed_ws and returns; prepacked skips the pack launch)
+struct S2Forward { int Ho, Wo; const float* bias; float slope; int out_ctotal, out_coff; bool prepacked, pack_only; };
 static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
-                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag);
+                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag, const S2Forward* fw = nullptr);
 
 extern "C" int deepim_conv2d_dgrad_s2(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
                                       int Ci_l, int Hd, int Wd, int Co_l, int k, int pad) {
@@ -1704,11 +1713,11 @@ extern "C" int deepim_conv2d_dgrad(deepim_ctx* ctx, float* dx, const float* dz, 
 }
 
 static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
-                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag) {
+                                int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag, const S2Forward* fw) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(k >= 2 && k <= 7 && pad >= 0 && pad < k, "conv2d_dgrad_s2: kernel 2 … 7, pad < k");
-  const int Ho = (Hd + 2 * pad - k) / 2 + 1, Wo = (Wd + 2 * pad - k) / 2 + 1;
+  const int Ho = fw ? fw->Ho : (Hd + 2 * pad - k) / 2 + 1, Wo = fw ? fw->Wo : (Wd + 2 * pad - k) / 2 + 1;
   S2Class cls[4];
   size_t slot[4], off = 0;
   for (int z = 0; z < 4; ++z) {
@@ -1718,8 +1727,8 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
   }
   const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
   const size_t in_bytes = (size_t)B * Co_l * Ho * Wo * 4;
-  const bool grouped = ctx->dgrad_group && direct && (Co_l & 1) == 0 && !(ctx->conv_tile256 && Ci_l % 256 == 0) &&
-                       in_bytes + (size_t)(4 * Wo + 4) * 4 < 0x7fffffffUL;
+  const bool grouped = fw != nullptr || (ctx->dgrad_group && direct && (Co_l & 1) == 0 && !(ctx->conv_tile256 && Ci_l % 256 == 0) &&
+                                         in_bytes + (size_t)(4 * Wo + 4) * 4 < 0x7fffffffUL);
   // tile of the register-fed kernel: 128 x 128, or 64 rows x 256 pixels when dx has at most 64 channels (conv2's data gradient)
   const int bm = Ci_l <= 64 ? 64 : 128, bn = Ci_l <= 64 ? 256 : 128;
   if (!grouped) {   // class by class: whatever kernel family deepim_conv2d_forward picks for the geometry
@@ -1749,13 +1758,14 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     const S2Class& c = cls[ord[m]];
     ConvParams& p = g.p[m];
     const size_t half = packed_half(Ci_l, Co_l * c.nky * c.nkx);
-    p.in = dz; p.wp = packed_ws + slot[ord[m]]; p.bias = nullptr; p.out = dx;
+    p.in = dz; p.wp = packed_ws + slot[ord[m]]; p.bias = fw ? fw->bias : nullptr; p.out = dx;
     p.B = B; p.Cin = Co_l; p.H = Ho; p.W = Wo; p.Cout = Ci_l;
     p.Ho = Ho + 2 * c.P - c.nky + 1; p.Wo = Wo + 2 * c.P - c.nkx + 1;
     p.stride = 1; p.pad = c.P;
     p.nchunk = chunk_count(Co_l * c.nky * c.nkx);
     p.ngran = gran_count(Ci_l);
-    p.out_ctotal = Ci_l; p.out_coff = 0; p.slope = 1.f; p.crop_y = p.crop_x = 0;
+    p.out_ctotal = fw && fw->out_ctotal > 0 ? fw->out_ctotal : Ci_l; p.out_coff = fw ? fw->out_coff : 0;
+    p.slope = fw ? fw->slope : 1.f; p.crop_y = p.crop_x = 0;
     p.rm_on = 1; p.rm_cy = c.cy; p.rm_cx = c.cx; p.rm_hq = (Hd - c.py + 1) / 2; p.rm_wq = (Wd - c.px + 1) / 2;
     p.rm_py = c.py; p.rm_px = c.px; p.rm_H = Hd; p.rm_W = Wd;
     DI_REQUIRE(p.rm_hq + c.cy <= p.Ho && p.rm_wq + c.cx <= p.Wo, "conv2d_dgrad_s2: class window outside the convolution result");
@@ -1785,6 +1795,11 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     pstart += (int)di_div_up((long)half, 256);
   }
   pg.start[4] = pstart;
+  if (fw && fw->pack_only) {
+    hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
+    DI_LAUNCH_CHECK();
+    return 0;
+  }
   // joint plan: T = K chunks per block; member m runs ceil(nchunk_m / T) slices. cost as plan_ksplit: rounds of 256 blocks x the
   // longest block, + the second pass
   const int nch_max = g.p[0].nchunk;
@@ -1824,6 +1839,8 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
   ReduceGroup rg;
   rg.out = dx; rg.Cout = Ci_l; rg.n = 0;
   rg.ep_y = ag ? ag->y : nullptr; rg.ep_add = ag ? ag->add : nullptr; rg.ep_slope = ag ? ag->slope : 1.f;
+  rg.bias = fw ? fw->bias : nullptr; rg.slope = fw ? fw->slope : 1.f;
+  rg.out_ctotal = fw && fw->out_ctotal > 0 ? fw->out_ctotal : Ci_l; rg.out_coff = fw ? fw->out_coff : 0;
   int cstart = 0, rstart = 0;
   size_t poff = 0;
   for (int m = 0; m < 4; ++m) {
@@ -1842,7 +1859,7 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
   }
   g.start[4] = cstart;
   for (int j = rg.n; j <= CONV_GROUP_MAX; ++j) rg.start[j] = rstart;
-  hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
+  if (!(fw && fw->prepacked)) hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
   if (bm == 64) hipLaunchKernelGGL(conv_direct_group_kernel<1>, dim3(cstart), dim3(256), 0, ctx->stream, g);
   else hipLaunchKernelGGL(conv_direct_group_kernel<2>, dim3(cstart), dim3(256), 0, ctx->stream, g);
   if (rg.n) hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rstart), dim3(256), 0, ctx->stream, rg);
@@ -1978,8 +1995,13 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   return launch_conv<MODE_CONV>(ctx, p, 1);
 }
 
+// [LDS-kernel operand order of the four output-parity classes | the same four 2x2-tap sub-kernels in the register-fed kernel's
+// operand order (deepim_conv2d_dgrad_s2's packing: Deconvolution k4 s2 + Crop(1,1) is the data gradient of a k4 s2 p1 convolution
+// whose (filters, channels) are the MXNet Deconvolution weight's (Cin, Cout))]. The second part exists for even Cin and Cout >= 64.
+static size_t deconv_lds_pack_floats(int Cin, int Cout) { return (size_t)4 * gran_count(Cout) * chunk_count(Cin * 4) * KT * GRAN; }
+static bool deconv_direct_ok(int Cin, int Cout) { return (Cin & 1) == 0 && Cout >= 64; }
 extern "C" size_t deepim_deconv_packed_size(int Cin, int Cout) {
-  return (size_t)4 * gran_count(Cout) * chunk_count(Cin * 4) * KT * GRAN * sizeof(float);
+  return deconv_lds_pack_floats(Cin, Cout) * sizeof(float) + (deconv_direct_ok(Cin, Cout) ? deepim_conv_dgrad_s2_packed_size(Cin, Cout, 4, 1) : 0);
 }
 
 extern "C" int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cin, int Cout) {
@@ -1989,6 +2011,10 @@ extern "C" int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, cons
   hipLaunchKernelGGL(pack_deconv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cin, Cout,
                      ngran, nchunk, total);
   DI_LAUNCH_CHECK();
+  if (deconv_direct_ok(Cin, Cout)) {
+    const S2Forward fw = {1, 1, nullptr, 1.f, 0, 0, false, true};
+    return conv2d_dgrad_s2_impl(ctx, nullptr, nullptr, w, packed_w + deconv_lds_pack_floats(Cin, Cout), 1, Cout, 2, 2, Cin, 4, 1, nullptr, &fw);
+  }
   return 0;
 }
 
@@ -1999,6 +2025,19 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(Ho + crop_y <= (H - 1) * 2 + 4 && Wo + crop_x <= (W - 1) * 2 + 4, "deconv: crop exceeds output");
+  // The decoder's two big transposed convolutions (deconv5 1024 → 512, deconv4 1026 → 256; crop (1,1)) on the register-fed MFMA
+  // kernel: four stride-1 2x2-tap convolutions of the input, one per output parity class, in ONE grouped launch whose final stores
+  // (or one grouped second pass) put bias + LeakyReLU results onto the class's pixels of the Concat slice — the machinery of the
+  // stride-2 data gradient (deepim_conv2d_dgrad_s2), here with weights packed once. Round 3 ran them on the LDS-staged kernel at
+  // 64-77 TFLOP/s (profiles/r03_heads_b4_iteration_trace.txt). Not in the bit-exact configuration (conv_max_split = 1 keeps the
+  // canonical (ci,ky,kx) order of the LDS kernel, as for the encoder).
+  const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
+  if (direct && crop_y == 1 && crop_x == 1 && deconv_direct_ok(Cin, Cout) && !ctx->conv_tile256 &&
+      (size_t)B * Cin * H * W * 4 + (size_t)(4 * W + 4) * 4 < 0x7fffffffUL) {
+    const S2Forward fw = {H, W, bias, slope, out_ctotal > 0 ? out_ctotal : Cout, out_coff, true, false};
+    return conv2d_dgrad_s2_impl(ctx, out, in, nullptr, const_cast<float*>(packed_w) + deconv_lds_pack_floats(Cin, Cout), B, Cout, Ho, Wo,
+                                Cin, 4, 1, nullptr, &fw);
+  }
   ConvParams p;
   p.in = in; p.wp = packed_w; p.bias = bias; p.out = out;
   p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;

@@ -375,6 +375,15 @@ def test_deconv_crop_bit_exact(ctx, case):
     lib.deepim_deconv4x4s2_crop_forward(ctx.handle, out, ctx.array(x), pk, ctx.array(b), B, cin, H, W, cout, ho, wo, 1, 1,
                                         cf(0.1), 0, 0)
     assert np.abs(out.asnumpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # default plan again, into a channel slice of a wider tensor (the decoder's Concat): even Cin with Cout >= 64 takes the grouped
+    # register-fed kernel (round 4: four parity-class convolutions in one launch, weights packed once), its split-K second pass
+    # included at these sizes; everything outside the slice stays untouched
+    cat = ctx.array(np.full((B, cout + 5, ho, wo), 7.0, np.float32))
+    lib.deepim_deconv4x4s2_crop_forward(ctx.handle, cat, ctx.array(x), pk, ctx.array(b), B, cin, H, W, cout, ho, wo, 1, 1,
+                                        cf(0.1), cout + 5, 3)
+    got = cat.asnumpy()
+    assert np.abs(got[:, 3:3 + cout] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert (got[:, :3] == 7.0).all() and (got[:, 3 + cout:] == 7.0).all()
 
 
 def test_upsample16_crop(ctx):
