@@ -288,6 +288,15 @@ int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const
                              const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                              int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8, int out_nc8);
 int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, int C, size_t hw, int to_nc8);
+/* The encoder's 3x3 stride-1 pad-1 layers (conv3_1 / conv4_1 / conv5_1 / conv6_1, deepIM_flownet.py:69-101) as fp32 Winograd
+ * F(2x2,3x3): the same fp32 arithmetic with 2.25x fewer multiplies, a different summation (NOT the direct kernels' fmaf chain:
+ * within 1e-5 of the layer's range, tests/test_gpu_wino.py). `in` is NC8; `out` NC8 (out_nc8 = 1) or channels [out_coff,
+ * out_coff + Cout) of an NCHW tensor with out_ctotal channels (0 = Cout). Cout % 32 == 0, Cin % 8 == 0. packed_w: U = G g G^T
+ * from deepim_conv_wino_pack_weights (16 floats per weight tap set: Cout*Cin*64 bytes). */
+size_t deepim_conv_wino_packed_size(int Cout, int Cin);
+int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
+int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
+                               int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
 /* fp16 conv path (BASELINE config 5): NHWC fp16 activations, fp16 weights (packed once), fp16 matrix cores
  * with fp32 accumulation, bias + LeakyReLU in fp32, NHWC fp16 output. Same layer semantics as
  * deepim_conv2d_forward (deepIM_flownet.py:63-107); tolerance documented in DESIGN.md (fp16 cannot meet 1e-4).

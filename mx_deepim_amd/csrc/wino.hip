@@ -1,0 +1,274 @@
+// fp32 Winograd F(2x2, 3x3) for the encoder's 3x3 stride-1 layers (conv3_1 / conv4_1 / conv5_1 / conv6_1 of
+// deepIM_flownet.py:69-101 — 36.6 % of the encoder's multiply-adds) on channel-blocked activations [n][C/8][h][w][8].
+// Same fp32 arithmetic as the direct kernels, 2.25x fewer multiplies: per 2x2 output tile and channel the 4x4 input patch d
+// becomes V = B^T d B, the 3x3 kernel g becomes U = G g G^T (packed once), the sixteen positions (xi, nu) are sixteen
+// independent GEMMs M = U·V over the input channels, and the tile is Y = A^T M A. Results differ from the direct sum in the
+// last bits (bounded by the tests at 1e-5 of the layer's range), so the layers take this path only on request
+// (deepim_set_option "conv_winograd" via the host class) and never in the canonical-order parity configuration.
+//
+// One kernel, no LDS, no intermediate tensor in HBM:
+//   * a wave owns 32 output channels x 32 tiles x ALL 16 positions: sixteen 32x32 accumulators = 256 AGPRs, one wave per SIMD
+//     (the 512-register budget of gfx950 at occupancy 1); the MFMAs of one position are independent of the next, so a single
+//     wave keeps the matrix pipe busy as long as its operands are loaded a body ahead.
+//   * lane (h = lane / 32, t = lane % 32): tile t of the wave's 32 consecutive tiles, k index h of v_mfma_f32_32x32x2_f32.
+//     Per block of 8 input channels lane h reads channels 4h..4h+3 of each patch pixel with ONE 16-byte load (a wave touches
+//     32 bytes of every pixel record it visits): body j = 0, 1 of the block multiplies channels 4h + 2j + s in its two k-steps
+//     s. 16 pixel loads + 32 weight loads (8 bytes) + 64 pk-adds of transform per 64 MFMAs. (Measured: 8-byte pixel loads, one
+//     body at a time, spend 26 % of the kernel in the texture path — 902 vs 667 µs on conv3_1 without them.)
+//   * patch addresses: 16 per-lane voffsets computed once (out-of-image pixels carry bit 31 → the buffer load returns 0, which
+//     IS the zero padding); the channel walk lives in the scalar offset. No per-load VALU.
+//   * input transform in registers while the previous body multiplies; output transform + bias + LeakyReLU in the lane that
+//     holds all 16 positions of its (channel, tile) pairs; NC8 stores of 16 bytes (or NCHW for the layer fc6 reads).
+//   * block = 4 waves on 32 channels x 128 tiles; blocks are dealt to the XCDs so that each XCD keeps a fixed slice of the
+//     transformed weights (<= 2 MB for conv4_1 / conv5_1) resident in its L2.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WinoParams {
+  const float* in;
+  float* out;
+  const float* wd;     // [Cout/32][Cin/4][16 positions][64 lanes][2]
+  const float* bias;
+  float slope;
+  int Cin, Cout, H, W, TY, TX, ntiles, nb, gx, gy;
+  unsigned in_bytes, wd_bytes;
+  int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
+};
+
+#ifndef WINO_ABL
+#define WINO_ABL 0   // dev ablations (wrong results): 1 = no pixel loads in the loop, 2 = no weight loads, 4 = no transform
+#endif
+
+template <int OUT_NC8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(WinoParams p) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 5, lcol = lane & 31;
+  int mb, bx;
+  {
+    const int bid = blockIdx.x;
+    if ((p.gy & 7) == 0) {   // XCD x (blocks x, x+8, ...) owns channel blocks [x·gy/8, (x+1)·gy/8): channel block fastest inside
+      const int per = p.gy >> 3, xcd = bid & 7, idx = bid >> 3;
+      mb = xcd * per + idx % per;
+      bx = idx / per;
+    } else {
+      mb = bid % p.gy;
+      bx = bid / p.gy;
+    }
+  }
+  const int t = bx * 128 + wave * 32 + lcol;
+  const int tpi = p.TY * p.TX;
+  const bool tvalid = t < p.ntiles;
+  const int n = tvalid ? t / tpi : 0;
+  const int tr = tvalid ? t - n * tpi : 0;
+  const int ty = tr / p.TX, tx = tr - ty * p.TX;
+
+  // patch pixel (i, j) = input (2ty - 1 + i, 2tx - 1 + j); column-major slot k = j*4 + i (the order the loads are issued in)
+  int voff[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = k & 3, j = k >> 2;
+    const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+    const bool ok = tvalid && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    voff[k] = ok ? (((n * (p.Cin >> 3)) * p.H + y) * p.W + x) * 32 + lrow * 16 : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
+  const int wvo0 = lane * 8, wvo1 = lane * 8 + 4096;
+  const int hw32 = p.H * p.W * 32;
+  const int c8n = p.Cin >> 3;
+  const int abase = mb * p.nb;   // first body of this channel block in the packed weights (8 KB per body)
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  f32x4 raw[16];               // pixels of the NEXT channel block: 4 channels per lane (both bodies), row pass in place
+  f32x2 Va[16], Vb[16], Vc[16], A[16];
+#define WLOADB(k, soff) \
+  raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], (soff), 0));
+#define WLOADA(q, soff) \
+  A[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrw, ((q) < 8 ? wvo0 : wvo1) + ((q) & 7) * 512, (soff), 0));
+// row pass of B^T d B on patch column j = k / 4 (slots j*4 + i), in place: slot j*4 + xi becomes T[xi][j]. One call per column.
+#define WROWS(j_)                                                                              \
+  {                                                                                            \
+    const f32x4 d0 = raw[(j_) * 4 + 0], d1 = raw[(j_) * 4 + 1], d2 = raw[(j_) * 4 + 2], d3 = raw[(j_) * 4 + 3]; \
+    raw[(j_) * 4 + 0] = d0 - d2; raw[(j_) * 4 + 1] = d1 + d2; raw[(j_) * 4 + 2] = d2 - d1; raw[(j_) * 4 + 3] = d1 - d3; \
+  }
+// column pass: position k = xi*4 + nu from T[xi][0..3] = raw slots (0..3)*4 + xi; channels .xy go to body 0's V, .zw to body 1's
+#define WCOL(V0_, V1_, k)                                                                      \
+  {                                                                                            \
+    const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
+    const f32x4 t0 = raw[x_], t1 = raw[4 + x_], t2 = raw[8 + x_], t3 = raw[12 + x_];           \
+    const f32x4 r_ = w_ == 0 ? t0 - t2 : w_ == 1 ? t1 + t2 : w_ == 2 ? t2 - t1 : t1 - t3;     \
+    V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
+  }
+
+  // prologue: weights of body 0, pixels of channel block 0 -> V of both its bodies
+  // (issue order pinned: the loop header's one s_waitcnt serves both the entry and the back edge — with the weights loaded
+  // last here, as the scheduler would have it, it becomes vmcnt(0) and drains everything in flight once per trip)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) WLOADA(q, abase * 8192)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) WLOADB(k, 0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) WROWS(j)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) WCOL(Va, Vb, k)
+
+  // channel block c = two bodies of 4 channels (32 MFMAs each). Body 0 multiplies Va and receives the 16 pixel loads of block
+  // c + 1 (one per MFMA slot, a body ahead of their first use); body 1 multiplies X while the transform of block c + 1 runs in
+  // its slots (row passes, then column passes into Va — free by now — and Y). Every A[q] is reloaded for the next body right
+  // behind its last use. X / Y swap roles from one block to the next.
+#define WSUPER(X, Y, sb, sa0, sa1)                                                             \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                             \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].x, Va[q].x, acc[q], 0, 0, 0);          \
+    asm volatile("" : "+a"(acc[q]));                                                           \
+    if (!(WINO_ABL & 1) && q < 8) { WLOADB(2 * q, sb) }                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].y, Va[q].y, acc[q], 0, 0, 0);          \
+    asm volatile("" : "+a"(acc[q]));                                                           \
+    if (!(WINO_ABL & 1) && q < 8) { WLOADB(2 * q + 1, sb) }                                    \
+    if (!(WINO_ABL & 2)) { WLOADA(q, sa0) }                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }                                                                                            \
+  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                             \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].x, X[q].x, acc[q], 0, 0, 0);           \
+    asm volatile("" : "+a"(acc[q]));                                                           \
+    if (!(WINO_ABL & 4)) { if (q < 8) { if (!(q & 1)) WROWS(q >> 1) } else WCOL(Va, Y, 2 * (q - 8)) } \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].y, X[q].y, acc[q], 0, 0, 0);           \
+    asm volatile("" : "+a"(acc[q]));                                                           \
+    if (!(WINO_ABL & 2)) { WLOADA(q, sa1) }                                                    \
+    if (!(WINO_ABL & 4)) { if (q >= 8) WCOL(Va, Y, 2 * (q - 8) + 1) }                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }
+#define WOFFS(c8)                                                                              \
+  const int sb = __builtin_amdgcn_readfirstlane(min((c8) + 1, c8n - 1) * hw32); /* clamped: loads past the end re-read the last block */ \
+  const int sa0 = __builtin_amdgcn_readfirstlane((abase + 2 * (c8) + 1) * 8192);               \
+  const int sa1 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 2, p.nb - 1)) * 8192);
+
+  int c8 = 0;
+  for (; c8 + 2 <= c8n; c8 += 2) {
+    { WOFFS(c8) WSUPER(Vb, Vc, sb, sa0, sa1) }
+    { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa0, sa1) }
+  }
+  if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa0, sa1) }
+#undef WOFFS
+#undef WSUPER
+#undef WCOL
+#undef WROWS
+#undef WLOADA
+#undef WLOADB
+
+  // output transform Y = A^T M A per (channel, tile), bias, LeakyReLU, store. acc[q][r]: channel (r&3) + 8(r>>2) + 4·lrow, tile lcol
+  if (!tvalid) return;
+  const int y0 = 2 * ty, x0 = 2 * tx;
+  const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float o[4][4];   // [a*2+b][channel within the run of 4]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      float s[4][2];
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const float m0 = acc[xi * 4 + 0][r], m1 = acc[xi * 4 + 1][r], m2 = acc[xi * 4 + 2][r], m3 = acc[xi * 4 + 3][r];
+        s[xi][0] = (m0 + m1) + m2;
+        s[xi][1] = (m1 - m2) - m3;
+      }
+      const float bv = p.bias ? p.bias[mb * 32 + 8 * g + 4 * lrow + e] : 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float v0 = ((s[0][b] + s[1][b]) + s[2][b]) + bv;
+        float v1 = ((s[1][b] - s[2][b]) - s[3][b]) + bv;
+        o[0 * 2 + b][e] = v0 > 0.f ? v0 : v0 * p.slope;
+        o[1 * 2 + b][e] = v1 > 0.f ? v1 : v1 * p.slope;
+      }
+    }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const int a = ab >> 1, b = ab & 1;
+      if ((a && !y1ok) || (b && !x1ok)) continue;
+      const long pix = (long)(y0 + a) * p.W + x0 + b;
+      if (OUT_NC8) {
+        const long cb = (long)n * (p.Cout >> 3) + mb * 4 + g;
+        *reinterpret_cast<float4*>(p.out + (cb * p.H * p.W + pix) * 8 + 4 * lrow) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]);
+      } else {
+        const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p.out[(c0 + e) * p.H * p.W + pix] = o[ab][e];
+      }
+    }
+  }
+}
+
+// U = G g G^T in double, rounded once; packed [Cout/32][body = Cin/4][position][lane = h*32 + row][s] with channel 8(body/2) + 4h + 2(body%2) + s
+__global__ void pack_wino_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int s = (int)(i & 1), r = (int)((i >> 1) & 31), h = (int)((i >> 6) & 1), q = (int)((i >> 7) & 15);
+  const long bi = i >> 11;
+  const int nb = Cin >> 2;
+  const int c4 = (int)(bi % nb), mb = (int)(bi / nb);
+  const int co = mb * 32 + r, ci = (c4 >> 1) * 8 + 4 * h + 2 * (c4 & 1) + s;
+  const int xi = q >> 2, nu = q & 3;
+  const float* g = w + ((long)co * Cin + ci) * 9;
+  const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  double u = 0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) u += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+  packed[i] = (float)u;
+}
+
+extern "C" size_t deepim_conv_wino_packed_size(int Cout, int Cin) {
+  if (Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 7)) return 0;
+  return (size_t)Cout * Cin * 16 * sizeof(float);
+}
+
+extern "C" int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(Cout > 0 && Cin > 0 && (Cout & 31) == 0 && (Cin & 7) == 0, "conv_wino_pack_weights: Cout % 32 == 0 and Cin % 8 == 0 required");
+  const long total = (long)Cout * Cin * 16;
+  pack_wino_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(packed_w, w, Cout, Cin, total);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// 3x3, stride 1, pad 1 convolution + bias + LeakyReLU(slope) from channel-blocked `in` (B, Cin/8, H, W, 8) into channel-blocked
+// `out` (out_nc8 = 1) or into channels [out_coff, out_coff + Cout) of an NCHW tensor of out_ctotal channels (out_nc8 = 0).
+extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
+                                          int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal,
+                                          int out_coff) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d_wino_forward: bad shape");
+  DI_REQUIRE((Cout & 31) == 0 && (Cin & 7) == 0, "conv2d_wino_forward: Cout % 32 == 0 and Cin % 8 == 0 required");
+  if (B == 0) return 0;
+  const size_t in_bytes = (size_t)B * Cin * H * W * 4, wd_bytes = (size_t)Cout * Cin * 64;
+  DI_REQUIRE(in_bytes < (1ull << 31) && wd_bytes < (1ull << 31), "conv2d_wino_forward: tensor beyond the 2 GB buffer range");
+  WinoParams p;
+  p.in = in; p.out = out; p.wd = packed_w; p.bias = bias; p.slope = slope;
+  p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+  p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
+  p.ntiles = B * p.TY * p.TX;
+  p.nb = Cin / 4;
+  p.gx = di_div_up(p.ntiles, 128);
+  p.gy = Cout / 32;
+  p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
+  p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
+  p.out_coff = out_coff;
+  const int grid = p.gx * p.gy;
+  if (out_nc8) conv_wino_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
+  else conv_wino_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
+  DI_LAUNCH_CHECK();
+  return 0;
+}

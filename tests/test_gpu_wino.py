@@ -1,0 +1,91 @@
+"""fp32 Winograd F(2x2,3x3) layers (csrc/wino.hip) against the C oracle's direct convolution: a different summation of the same
+fp32 products, so the bar is a tolerance — 1e-5 of the layer's output range — not bit equality."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import net as onet
+from mx_deepim_amd.runtime import DeviceArray, lib
+
+pytestmark = pytest.mark.gpu
+cf = ctypes.c_float
+TOL = 1e-5
+
+
+def _to_nc8(x):
+    B, C, H, W = x.shape
+    return np.ascontiguousarray(x.reshape(B, C // 8, 8, H, W).transpose(0, 1, 3, 4, 2))
+
+
+def _from_nc8(y, shape):
+    B, C, H, W = shape
+    return np.ascontiguousarray(y.reshape(B, C // 8, H, W, 8).transpose(0, 1, 4, 2, 3).reshape(B, C, H, W))
+
+
+def _pack(ctx, w):
+    cout, cin = w.shape[:2]
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, cin) // 4,))
+    lib.deepim_conv_wino_pack_weights(ctx.handle, pk, ctx.array(w), cout, cin)
+    return pk
+
+
+# (B, Cin, H, W, Cout): the four encoder geometries at reduced size, odd H / W (half-covered last tiles), one-tile images,
+# a tile count off the 128 grid, several channel blocks per XCD slice and a channel-block count that is not a multiple of 8
+CASES = [
+    (2, 256, 12, 16, 256),     # conv3_1 channels
+    (1, 512, 30, 40, 512),     # conv4_1 at full spatial size, one sample
+    (3, 64, 15, 20, 64),       # conv5_1 geometry (odd H), few channels
+    (2, 1024, 8, 10, 1024),    # conv6_1
+    (5, 8, 7, 9, 32),          # odd H and W, one body pair, one channel block
+    (1, 16, 2, 2, 96),         # a single tile, 3 channel blocks
+    (2, 24, 1, 5, 160),        # one row: every tile is half outside
+    (33, 8, 6, 6, 32),         # 297 tiles: ragged last block of 128
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_layer_within_1e5_of_the_direct_convolution(ctx, case):
+    B, cin, H, W, cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    x *= (rng.uniform(size=x.shape) > 0.3)          # post-LeakyReLU-like sparsity does not matter, zeros must survive exactly
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = onet.conv2d(x, w, b, 1, 1, 0.1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    xin, pk, bias = ctx.array(_to_nc8(x)), _pack(ctx, w), ctx.array(b)
+    out = ctx.zeros((B, cout, H, W))
+    lib.deepim_conv2d_wino_forward(ctx.handle, out, xin, pk, bias, B, cin, H, W, cout, cf(0.1), 1, 0, 0)
+    got = _from_nc8(out.asnumpy(), (B, cout, H, W))
+    assert np.abs(got - ref).max() <= TOL * scale, np.abs(got - ref).max() / scale
+    # NCHW output into a channel slice of a wider tensor, no bias, no activation
+    wide = ctx.array(np.full((B, cout + 5, H, W), 7.0, np.float32))
+    lib.deepim_conv2d_wino_forward(ctx.handle, wide, xin, pk, None, B, cin, H, W, cout, cf(1.0), 0, cout + 5, 3)
+    ref0 = onet.conv2d(x, w, np.zeros(cout, np.float32), 1, 1, 1.0)
+    gw = wide.asnumpy()
+    assert np.abs(gw[:, 3:3 + cout] - ref0).max() <= TOL * max(1.0, float(np.abs(ref0).max()))
+    assert (gw[:, :3] == 7.0).all() and (gw[:, 3 + cout:] == 7.0).all()
+
+
+def test_wino_weight_transform_is_G_g_Gt(ctx):
+    rng = np.random.default_rng(5)
+    cout, cin = 32, 16
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    pk = _pack(ctx, w).asnumpy().reshape(cout // 32, cin // 4, 16, 2, 32, 2)     # [mb][c4][pos][h][row][s]
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum("xa,ocab,nb->ocxn", G, w.astype(np.float64), G).astype(np.float32)   # (cout, cin, 4, 4)
+    for c4 in range(cin // 4):
+        for h in range(2):
+            for s in range(2):
+                np.testing.assert_array_equal(pk[0, c4, :, h, :, s], U[:, (c4 // 2) * 8 + 4 * h + 2 * (c4 % 2) + s].reshape(cout, 16).T)
+
+
+def test_wino_argument_checks(ctx):
+    assert lib.load().deepim_conv_wino_packed_size(48, 8) == 0 and lib.load().deepim_conv_wino_packed_size(32, 12) == 0
+    d = ctx.zeros((64,))
+    with pytest.raises(RuntimeError):
+        lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 1, 12, 2, 2, 32, cf(0.1), 1, 0, 0)
+    with pytest.raises(RuntimeError):
+        lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 1, 8, 2, 2, 40, cf(0.1), 1, 0, 0)
+    lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 0, 8, 2, 2, 32, cf(0.1), 1, 0, 0)      # empty batch: no launch

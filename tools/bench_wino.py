@@ -1,0 +1,44 @@
+"""Dev probe: the encoder's 3x3 stride-1 layers on the direct NC8 kernel vs the Winograd kernel, random operands, interleaved.
+usage: bench_wino.py [B]"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mx_deepim_amd.runtime import Context, DeviceArray, lib
+ctx = Context.get(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cf = ctypes.c_float
+rng = np.random.default_rng(0)
+LAYERS = [("conv3_1", 256, 60, 80, 256), ("conv4_1", 512, 30, 40, 512), ("conv5_1", 512, 15, 20, 512), ("conv6_1", 1024, 8, 10, 1024)]
+ROUNDS, REPS = 3, 5
+for name, cin, H, W, cout in LAYERS:
+    n = B * cin * H * W
+    x = ctx.array(np.resize(rng.standard_normal(min(n, 1 << 24)).astype(np.float32), n).reshape(B, cin // 8, H, W, 8))
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    wd = ctx.array(w)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cout, cin, 3, 3) // 4,))
+    lib.deepim_conv_pack_weights(ctx.handle, pk, wd, cout, cin, 3, 3)
+    pw = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, cin) // 4,))
+    lib.deepim_conv_wino_pack_weights(ctx.handle, pw, wd, cout, cin)
+    bias = ctx.array(rng.standard_normal(cout).astype(np.float32))
+    o1, o2 = ctx.empty((B, cout, H, W)), ctx.empty((B, cout, H, W))
+    out8 = 0 if name == "conv6_1" else 1
+    direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x, pk, bias, B, cin, H, W, cout, 3, 3, 1, 1, cf(0.1), 0, 0, 1, out8)
+    wino = lambda: lib.deepim_conv2d_wino_forward(ctx.handle, o2, x, pw, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
+    direct(); wino()
+    a, b = o1.asnumpy(), o2.asnumpy()
+    err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
+    td, tw = [], []
+    for r in range(ROUNDS):
+        for fn, acc in ((direct, td), (wino, tw)):
+            fn()
+            t = ctx.timer(); t.start()
+            for _ in range(REPS):
+                fn()
+            t.stop()
+            acc.append(t.elapsed_ms() / REPS)
+    d, wv = float(np.median(td)), float(np.median(tw))
+    fl = 2.0 * cout * cin * 9 * H * W * B
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    fle = 2.0 * cout * cin * 16 * tiles
+    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range"
+          % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err))
