@@ -294,6 +294,8 @@ int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, in
  * out_coff + Cout) of an NCHW tensor with out_ctotal channels (0 = Cout). Cout % 32 == 0, Cin % 8 == 0. packed_w: U = G g G^T
  * from deepim_conv_wino_pack_weights (16 floats per weight tap set: Cout*Cin*64 bytes). */
 size_t deepim_conv_wino_packed_size(int Cout, int Cin);
+/* 1 when the layer has enough 32-channel x 128-tile blocks for this kernel to beat the direct one (no split over Cin) */
+int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
 int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
 int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
                                int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);

@@ -42,6 +42,20 @@ struct WinoParams {
 #define WINO_ABL 0   // dev ablations (wrong results): 1 = no pixel loads in the loop, 2 = no weight loads, 4 = no transform
 #endif
 
+// WINO_PK 0 (with -fno-slp-vectorize): component-wise scalar adds instead of the compiler's mix of v_pk_add_f32 and scalar ops —
+// measured the same within noise (0.779 vs 0.758 ms on conv3_1), so the plain vector form stays
+#ifndef WINO_PK
+#define WINO_PK 1
+#endif
+__device__ __forceinline__ f32x4 wsub(f32x4 a, f32x4 b) {
+  if (WINO_PK) return a - b;
+  f32x4 r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; r.w = a.w - b.w; return r;
+}
+__device__ __forceinline__ f32x4 wadd(f32x4 a, f32x4 b) {
+  if (WINO_PK) return a + b;
+  f32x4 r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w; return r;
+}
+
 template <int OUT_NC8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(WinoParams p) {
   const int tid = threadIdx.x;
@@ -99,14 +113,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WROWS(j_)                                                                              \
   {                                                                                            \
     const f32x4 d0 = raw[(j_) * 4 + 0], d1 = raw[(j_) * 4 + 1], d2 = raw[(j_) * 4 + 2], d3 = raw[(j_) * 4 + 3]; \
-    raw[(j_) * 4 + 0] = d0 - d2; raw[(j_) * 4 + 1] = d1 + d2; raw[(j_) * 4 + 2] = d2 - d1; raw[(j_) * 4 + 3] = d1 - d3; \
+    raw[(j_) * 4 + 0] = wsub(d0, d2); raw[(j_) * 4 + 1] = wadd(d1, d2); raw[(j_) * 4 + 2] = wsub(d2, d1); raw[(j_) * 4 + 3] = wsub(d1, d3); \
   }
 // column pass: position k = xi*4 + nu from T[xi][0..3] = raw slots (0..3)*4 + xi; channels .xy go to body 0's V, .zw to body 1's
 #define WCOL(V0_, V1_, k)                                                                      \
   {                                                                                            \
     const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
     const f32x4 t0 = raw[x_], t1 = raw[4 + x_], t2 = raw[8 + x_], t3 = raw[12 + x_];           \
-    const f32x4 r_ = w_ == 0 ? t0 - t2 : w_ == 1 ? t1 + t2 : w_ == 2 ? t2 - t1 : t1 - t3;     \
+    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3);     \
     V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
   }
 
@@ -128,27 +142,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // c + 1 (one per MFMA slot, a body ahead of their first use); body 1 multiplies X while the transform of block c + 1 runs in
   // its slots (row passes, then column passes into Va — free by now — and Y). Every A[q] is reloaded for the next body right
   // behind its last use. X / Y swap roles from one block to the next.
+#define WMFMA(VV, q, s_) \
+  acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) ? A[q].y : A[q].x, (s_) ? VV[q].y : VV[q].x, acc[q], 0, 0, 0); \
+  asm volatile("" : "+a"(acc[q]));
+// MFMA order inside a body: positions in pairs, (q0,s0) (q1,s0) (q0,s1) (q1,s1) — WINO_PAIR 0 puts the two k-steps of a
+// position back to back (an accumulator dependent on the MFMA right before it)
+#ifndef WINO_PAIR
+#define WINO_PAIR 1
+#endif
+#define WQ(sl) (WINO_PAIR ? (((sl) >> 2) * 2 + ((sl) & 1)) : ((sl) >> 1))
+#define WS(sl) (WINO_PAIR ? (((sl) >> 1) & 1) : ((sl) & 1))
 #define WSUPER(X, Y, sb, sa0, sa1)                                                             \
-  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                             \
-    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].x, Va[q].x, acc[q], 0, 0, 0);          \
-    asm volatile("" : "+a"(acc[q]));                                                           \
-    if (!(WINO_ABL & 1) && q < 8) { WLOADB(2 * q, sb) }                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].y, Va[q].y, acc[q], 0, 0, 0);          \
-    asm volatile("" : "+a"(acc[q]));                                                           \
-    if (!(WINO_ABL & 1) && q < 8) { WLOADB(2 * q + 1, sb) }                                    \
-    if (!(WINO_ABL & 2)) { WLOADA(q, sa0) }                                                    \
+  _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
+    WMFMA(Va, WQ(sl), WS(sl))                                                                  \
+    if (!(WINO_ABL & 1) && sl < 16) { WLOADB(sl, sb) }                                         \
+    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa0) }                                     \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }                                                                                            \
-  _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                             \
-    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].x, X[q].x, acc[q], 0, 0, 0);           \
-    asm volatile("" : "+a"(acc[q]));                                                           \
-    if (!(WINO_ABL & 4)) { if (q < 8) { if (!(q & 1)) WROWS(q >> 1) } else WCOL(Va, Y, 2 * (q - 8)) } \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[q].y, X[q].y, acc[q], 0, 0, 0);           \
-    asm volatile("" : "+a"(acc[q]));                                                           \
-    if (!(WINO_ABL & 2)) { WLOADA(q, sa1) }                                                    \
-    if (!(WINO_ABL & 4)) { if (q >= 8) WCOL(Va, Y, 2 * (q - 8) + 1) }                          \
+  _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
+    WMFMA(X, WQ(sl), WS(sl))                                                                   \
+    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa1) }                                     \
+    if (!(WINO_ABL & 4)) { if (sl < 16) { if (!(sl & 3)) WROWS(sl >> 2) } else WCOL(Va, Y, sl - 16) } \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }
 #define WOFFS(c8)                                                                              \
@@ -164,6 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa0, sa1) }
 #undef WOFFS
 #undef WSUPER
+#undef WMFMA
 #undef WCOL
 #undef WROWS
 #undef WLOADA
@@ -233,6 +248,19 @@ __global__ void pack_wino_kernel(float* __restrict__ packed, const float* __rest
 extern "C" size_t deepim_conv_wino_packed_size(int Cout, int Cin) {
   if (Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 7)) return 0;
   return (size_t)Cout * Cin * 16 * sizeof(float);
+}
+
+// Whether the layer should take this kernel: it needs enough 32-channel x 128-tile blocks to occupy the chip — there is no split
+// over the input channels, a block walks all of Cin (measured, tools/bench_wino.py: 160 blocks and more win 1.3-1.9x over the
+// direct kernel, 48 and fewer lose to its split-K plans).
+#ifndef WINO_MIN_BLOCKS
+#define WINO_MIN_BLOCKS 128
+#endif
+extern "C" int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
+  (void)ctx;
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7)) return 0;
+  const long tiles = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return (long)di_div_up(tiles, 128) * (Cout / 32) >= WINO_MIN_BLOCKS ? 1 : 0;
 }
 
 extern "C" int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin) {

@@ -153,6 +153,10 @@ class deepIM_flownet(object):
         # conv2 … conv6_1; conv1 stays on the fp32 kernel. Within the 1e-4 bar (observed ~1e-6), not bit-exact.
         self.x3_conv = bool(n.get("X3_CONV", False)) and not self.fp16_conv
         self.nc8 = bool(cfg.network.get('NC8_CONV', True)) if hasattr(cfg.network, 'get') else True
+        # the 3x3 stride-1 encoder layers as fp32 Winograd F(2x2,3x3) (csrc/wino.hip) wherever the layer fills the chip: same fp32
+        # arithmetic, 2.25x fewer multiplies, a different summation (<= 1e-5 of the layer's range from the direct sum). Only on
+        # the channel-blocked path; network.WINOGRAD_CONV = False keeps the direct kernels.
+        self.winograd = bool(cfg.network.get('WINOGRAD_CONV', True)) if hasattr(cfg.network, 'get') else True
         self.H, self.W = cfg.SCALES[0]
         self.K = np.ascontiguousarray(cfg.dataset.INTRINSIC_MATRIX, dtype=np.float32).reshape(3, 3)
         # Prop-side channel reversal of the means (zoom_image_with_factor.py:79-81)
@@ -270,6 +274,16 @@ class deepIM_flownet(object):
                 pk = DeviceArray(ctx, (nb // 4,))
                 lib.deepim_conv_pack_weights(h, pk, self.params[name], cout, cin, kh, kw)
             self.packed[base] = pk
+        self.packed_wino = {}
+        if self.nc8 and getattr(self, "winograd", False) and not (self.fp16_conv or self.x3_conv or getattr(self, "is_train", False)):
+            hh, ww, cin = H, W, self.cin
+            for name, cout, k, s_, p_ in ENCODER:
+                if (k, s_, p_) == (3, 1, 1) and lib.load().deepim_conv_wino_preferred(h, B, cin, hh, ww, cout):
+                    pk = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, cin) // 4,))
+                    lib.deepim_conv_wino_pack_weights(h, pk, self.params[name + "_weight"], cout, cin)
+                    self.packed_wino[name] = pk
+                hh, ww = _out_hw(hh, ww, k, s_, p_)
+                cin = cout
         # fc6: the 84 MB weight in MFMA operand order, so the layer is one pass over the weights on the matrix cores
         nb = lib.load().deepim_fc_packed_size(256, 1024 * 8 * 10)
         self.packed["fc6"] = DeviceArray(ctx, (nb // 4,))
@@ -476,7 +490,10 @@ class deepIM_flownet(object):
     def encoder_layer(self, li, src):
         """One encoder conv (index into enc_geom) from `src` into its activation buffer, in the configured layout."""
         name, cin, h, w, cout, k, s, p = self.enc_geom[li]
-        if self.nc8:
+        if self.nc8 and name in self.packed_wino:
+            lib.deepim_conv2d_wino_forward(self.ctx.handle, self.act[name], src, self.packed_wino[name], self.params[name + "_bias"],
+                                           self.B, cin, h, w, cout, ctypes.c_float(SLOPE), 1 if li < len(self.enc_geom) - 1 else 0, 0, 0)
+        elif self.nc8:
             in8 = 1 if (li > 0 or src.shape == (self.B, self.H, self.W, 8)) else 0     # conv1: NC8 records from the zoom front end
             lib.deepim_conv2d_forward_ex(self.ctx.handle, self.act[name], src, self.packed[name], self.params[name + "_bias"],
                                          self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,

@@ -38,6 +38,8 @@ def test_fast_test_iteration_matches_oracle(ctx, small_batch, nc8):
     params = net.init_weights(cfg, seed=7)
     net.bind(ctx, B, params)
     net.nc8 = nc8
+    wino, net.packed_wino = net.packed_wino, {}               # the Winograd layers sum in another order: off for the bit-exact part
+    assert "conv3_1" in wino                                  # (bound by default where the layer fills the chip)
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)   # single fmaf chain per output → bit-exact convs
     pose = net.refine_iteration(_data(ctx, d)).asnumpy()
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
@@ -51,8 +53,13 @@ def test_fast_test_iteration_matches_oracle(ctx, small_batch, nc8):
     assert np.abs(se3 - ref["se3"]).max() / np.abs(ref["se3"]).max() < 1e-4
     assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
     assert np.all(np.isfinite(pose)) and np.abs(ref["conv6_1"]).max() > 1e-3  # activations did not die
-    # default policy (auto split-K on the small deep layers): same results to fp32 re-association noise
+    # default policy (auto split-K on the small deep layers, fp32 Winograd on the 3x3 stride-1 layers that fill the chip): same
+    # results to fp32 re-association noise
+    net.packed_wino = wino
     pose2 = net.refine_iteration(_data(ctx, d)).asnumpy()
+    if nc8:
+        c3 = net.activation_nchw("conv3_1").asnumpy()
+        assert 0 < np.abs(c3 - ref["conv3_1"]).max() <= 1e-5 * np.abs(ref["conv3_1"]).max()     # ran, and within the layer bar
     c2 = net.act["conv6_1"].asnumpy()
     assert np.abs(c2 - ref["conv6_1"]).max() <= 1e-5 * np.abs(ref["conv6_1"]).max()
     assert np.abs(pose2 - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4
@@ -147,9 +154,11 @@ def test_opt_in_conv1_from_channel_blocked_net_input(ctx, small_batch):
     from mx_deepim_amd.symbols import deepIM_flownet
     d = small_batch
     cfg = default_config()
+    cfg.network.WINOGRAD_CONV = False      # bit-exact comparison below: every layer on the direct kernels' fmaf chains
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=5)
     net.bind(ctx, 2, params)
+    assert not net.packed_wino
     net.conv1_nc8 = True
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
     data = {k: ctx.array(d[k]) for k in ("image_observed", "mask_observed")}
