@@ -57,7 +57,8 @@ def encoder_executed_flops_per_pair(net):
     for name, cin, h, w, cout, k, s, p in net.enc_geom:
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         if name in getattr(net, "packed_wino", {}):
-            total += 2 * cout * cin * 16 * ((ho + 1) // 2) * ((wo + 1) // 2)
+            c_eff = 4 * cin if name in getattr(net, "wino_s2d", ()) else cin     # stride 2: the four input phases as channels
+            total += 2 * cout * c_eff * 16 * ((ho + 1) // 2) * ((wo + 1) // 2)
         else:
             total += 2 * cout * cin * k * k * ho * wo
     return total
@@ -675,7 +676,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("conv_f16_dma_kernel / conv1 patch kernel (fp16 MFMA 32x32x16)" if args.fp16 else "conv_f16_dma_kernel<X3> (conv2-conv6_1: 3 fp16 "
                                                       "MFMAs per product; peak = 2.5 PF / 3) + conv_direct_kernel (conv1, fp32)"
                                                       if args.x3 else "conv_nc8_kernel / conv_direct_kernel" +
-                                                      (" / conv_wino_kernel (fp32 Winograd F(2x2,3x3): %s)" % ", ".join(wino_layers) if wino_layers else "")) +
+                                                      (" / conv_wino_kernel (fp32 Winograd F(2x2,3x3): %s; stride-2 layers over the space-to-depth input)" % ", ".join(wino_layers) if wino_layers else "")) +
                          " (10 encoder launches per iteration incl. split-K reduces)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,

@@ -296,7 +296,17 @@ int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, in
 size_t deepim_conv_wino_packed_size(int Cout, int Cin);
 /* 1 when the layer has enough 32-channel x 128-tile blocks for this kernel to beat the direct one (no split over Cin) */
 int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
+/* the same for a 5x5 stride-2 pad-2 layer (B, Cin, H, W) run over its space-to-depth form (needs several full rounds of blocks) */
+int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
 int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
+/* The 5x5 stride-2 pad-2 layers (conv2 / conv3, deepIM_flownet.py:65-68) on the same kernel: a stride-2 convolution is a stride-1
+ * convolution over the four input phases (x[2m + py][2l + px] as channel (py*2+px)*Cin + c of a (4 Cin, H/2, W/2) tensor) with the
+ * taps w[2a+py][2b+px] — a 3x3 kernel, zero where the index reaches 5. The producer writes that "space-to-depth" NC8 tensor itself
+ * (out_nc8 = 3 of deepim_conv2d_forward_ex / deepim_conv2d_wino_forward; deepim_relayout_nc8_s2d converts for tests), this packs
+ * the layer's own (Cout, Cin, 5, 5) weights for it (size: deepim_conv_wino_packed_size(Cout, 4*Cin)), and the layer runs as
+ * deepim_conv2d_wino_forward(ctx, out, in_s2d, packed, bias, B, 4*Cin, H/2, W/2, Cout, ...). 1.56x fewer multiplies than direct. */
+int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,5,5 dev*/, int Cout, int Cin);
+int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float* src, int B, int C, int H, int W, int to_s2d);
 int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
                                int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
 /* fp16 conv path (BASELINE config 5): NHWC fp16 activations, fp16 weights (packed once), fp16 matrix cores

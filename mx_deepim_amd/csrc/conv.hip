@@ -91,6 +91,8 @@ struct ConvParams {
   float* tail_partial;      // [tail_s][R][128 co][128 px]
   // channel-blocked activations ("NC8": [n][C/8][h][w][8]) between the encoder layers
   int in_nc8, out_nc8;      // layout of the input / output tensor (0 = NCHW, 1 = NC8; output only: 2 = split16 fp16 pairs)
+  int out_s2d;              // NC8 output in space-to-depth order: pixel (y, x) of channel c -> channel ((y&1)*2 + (x&1))*Cout + c at
+                            // (y/2, x/2) of a (4*Cout, Ho/2, Wo/2) NC8 tensor — what the stride-2 Winograd layers read (csrc/wino.hip)
   float out_scale;          // split16 output: stored value = result · out_scale
   int* status;              // context status word (split16 output: saturation flag)
   // Output remap of the final NCHW stores (not of split-K partials): the window [rm_cy, rm_cy + rm_hq) x [rm_cx, rm_cx + rm_wq) of
@@ -399,7 +401,16 @@ __device__ __forceinline__ void store_tile_nc8(f32x16 (&acc)[TM][TN], float* __r
     const long op = pix0 + j * 32 + lcol;
     if (op >= p.npix) continue;
     const int n = (int)(op / hw);
-    const int r0 = (int)(op - (long)n * hw);
+    int r0 = (int)(op - (long)n * hw);
+    long nbase = (long)n * c8n;      // first channel block of sample n, in blocks of hw pixels
+    if (p.out_s2d) {                 // (block, pixel) -> (phase*c8n + block, (y/2, x/2)) of a tensor with hw/4 pixels per block
+      const int ho = r0 / p.Wo, wo = r0 - ho * p.Wo;
+      nbase = (nbase * 4 + ((ho & 1) * 2 + (wo & 1)) * c8n) * (hw >> 2);
+      r0 = (ho >> 1) * (p.Wo >> 1) + (wo >> 1);
+    } else {
+      nbase *= hw;
+    }
+    const int hwb = p.out_s2d ? hw >> 2 : hw;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -414,7 +425,7 @@ __device__ __forceinline__ void store_tile_nc8(f32x16 (&acc)[TM][TN], float* __r
           v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
           v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
         }
-        *reinterpret_cast<float4*>(outp + (((long)n * c8n + cb) * hw + r0) * 8 + 4 * lrow) = v;
+        *reinterpret_cast<float4*>(outp + (nbase + (long)cb * hwb + r0) * 8 + 4 * lrow) = v;
       }
     }
   }
@@ -1114,7 +1125,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ ou
 // elementwise on float4 (4 consecutive channels)
 __global__ __launch_bounds__(256) void splitk_reduce_nc8_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                                 const float* __restrict__ bias, long total4,
-                                                                long stride, int S, int C8, int hw, float slope) {
+                                                                long stride, int S, int C8, int hw, float slope, int C8mod) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   float4 v = reinterpret_cast<const float4*>(partial)[i];
@@ -1122,7 +1133,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_nc8_kernel(float* __restric
     const float4 w = reinterpret_cast<const float4*>(partial + (long)s * stride)[i];
     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
   }
-  const int c = (int)((i / (2L * hw)) % C8) * 8 + (int)(i & 1) * 4;   // 2 float4 per pixel record
+  // 2 float4 per pixel record; space-to-depth output: C8 = 4 phases x C8mod blocks of hw = Ho*Wo/4 pixels
+  const int c = (int)(((i / (2L * hw)) % C8) % C8mod) * 8 + (int)(i & 1) * 4;
   const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
   v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
@@ -1395,7 +1407,8 @@ int launch_one(deepim_ctx* ctx, ConvParams p, int classes, TileChoice t) {
     const long total = p.partial_stride;
     if (p.out_nc8)
       hipLaunchKernelGGL(splitk_reduce_nc8_kernel, dim3(di_div_up(total / 4, 256)), dim3(256), 0, ctx->stream, p.out,
-                         p.partial, p.bias, total / 4, p.partial_stride, p.ksplit, p.Cout >> 3, p.Ho * p.Wo, p.slope);
+                         p.partial, p.bias, total / 4, p.partial_stride, p.ksplit, (p.Cout >> 3) * (p.out_s2d ? 4 : 1),
+                         p.Ho * p.Wo / (p.out_s2d ? 4 : 1), p.slope, p.Cout >> 3);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, p.out, p.partial,
                          p.bias, total, p.partial_stride, p.ksplit, p.Cout, p.Ho * p.Wo, p.out_ctotal, p.out_coff,
@@ -1605,7 +1618,7 @@ extern "C" int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float
                                         int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8,
                                         int out_nc8) {
   return conv2d_forward_impl(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, kh, kw, stride, pad, slope, out_ctotal, out_coff,
-                             in_nc8, out_nc8 ? 1 : 0, 1.f);
+                             in_nc8, out_nc8 == 3 ? 3 : (out_nc8 ? 1 : 0), 1.f);   // 3: NC8 in space-to-depth order
 }
 
 // One output parity class of a stride-2 data gradient, straight into dx: a stride-1 convolution of the un-dilated gradient `in`
@@ -1779,7 +1792,7 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     if (rc) return rc;
     p.tab = tab; p.tab2 = tab2;
     p.wd = packed_ws + slot[ord[m]] + half; p.wd_bytes = (unsigned)(half * sizeof(float));
-    p.in_nc8 = 0; p.out_nc8 = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
+    p.in_nc8 = 0; p.out_nc8 = 0; p.out_s2d = 0; p.out_scale = 1.f; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
     p.ep_y = ag ? ag->y : nullptr; p.ep_add = ag ? ag->add : nullptr; p.ep_slope = ag ? ag->slope : 1.f;
     p.swizzle = ctx->conv_xcd_swizzle;
     p.gx = di_div_up(p.npix, bn); p.gy = di_div_up(Ci_l, bm);
@@ -1930,10 +1943,13 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
+  p.out_s2d = out_nc8 == 3 ? 1 : 0;
+  if (out_nc8 == 3) out_nc8 = 1;
   p.in_nc8 = in_nc8 ? 1 : 0; p.out_nc8 = out_nc8; p.out_scale = out_scale; p.status = ctx->status; p.wd8 = nullptr; p.tab8 = nullptr;
   p.ep_y = ag ? ag->y : nullptr; p.ep_add = ag ? ag->add : nullptr; p.ep_slope = ag ? ag->slope : 1.f;
   if (out_nc8 == 2) DI_REQUIRE(!in_nc8, "conv2d: split16 output is built for the NCHW-input LDS-free kernel (conv1)");
   if (out_nc8) DI_REQUIRE((Cout & 7) == 0 && p.out_ctotal == Cout && out_coff == 0, "conv2d: NC8 output needs Cout % 8 == 0 and no channel slice");
+  if (p.out_s2d) DI_REQUIRE(((p.Ho | p.Wo) & 1) == 0, "conv2d: space-to-depth output needs even output height and width");
   if (in_nc8) {
     DI_REQUIRE((Cin & 7) == 0 && (Cout > 64 || (Cout == 64 && out_nc8 == 1)),
                "conv2d: NC8 input needs Cin % 8 == 0 and Cout > 64 (or Cout == 64 with NC8 output: the 64x256-tile kernel)");
@@ -2059,7 +2075,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   if (rc) return rc;
   p.tab = tab;
   p.wd = nullptr; p.tab2 = nullptr; p.wd_bytes = 0;
-  p.in_nc8 = p.out_nc8 = 0; p.wd8 = nullptr; p.tab8 = nullptr;
+  p.in_nc8 = p.out_nc8 = p.out_s2d = 0; p.wd8 = nullptr; p.tab8 = nullptr;
   p.ep_y = p.ep_add = nullptr; p.ep_slope = 1.f;
   return launch_conv<MODE_DECONV>(ctx, p, 4);
 }
@@ -2072,6 +2088,30 @@ extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const
   dim3 grid(di_div_up(Wo, 256), Ho, B * C);
   hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
                      scale);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// NC8 in space-to-depth order <-> NCHW: (B, C, H, W) <-> [n][(phase*C + c)/8][H/2][W/2][8], phase = (y&1)*2 + (x&1)
+__global__ __launch_bounds__(256) void relayout_s2d_kernel(float* __restrict__ dst, const float* __restrict__ src, int C, int H, int W,
+                                                           long total, int to_s2d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index in the space-to-depth tensor
+  if (i >= total) return;
+  const int q = (int)(i & 7), hw4 = (H >> 1) * (W >> 1), C8 = C >> 3;
+  const int pix = (int)((i >> 3) % hw4);
+  const long plane = (i >> 3) / hw4;
+  const long n = plane / (4 * C8);
+  const int r = (int)(plane % (4 * C8)), ph = r / C8, c = (r % C8) * 8 + q;
+  const int y = 2 * (pix / (W >> 1)) + (ph >> 1), x = 2 * (pix % (W >> 1)) + (ph & 1);
+  const long j = ((n * C + c) * H + y) * W + x;
+  if (to_s2d) dst[i] = src[j]; else dst[j] = src[i];
+}
+extern "C" int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float* src, int B, int C, int H, int W, int to_s2d) {
+  DI_DEVICE(ctx);
+  if (B == 0 || C == 0) return 0;
+  DI_REQUIRE((C & 7) == 0 && ((H | W) & 1) == 0, "relayout_nc8_s2d: C % 8 == 0, even H and W");
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(relayout_s2d_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dst, src, C, H, W, total, to_s2d);
   DI_LAUNCH_CHECK();
   return 0;
 }

@@ -36,6 +36,7 @@ struct WinoParams {
   int Cin, Cout, H, W, TY, TX, ntiles, nb, gx, gy;
   unsigned in_bytes, wd_bytes;
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
+  int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
 };
 
 #ifndef WINO_ABL
@@ -56,8 +57,23 @@ __device__ __forceinline__ f32x4 wadd(f32x4 a, f32x4 b) {
   f32x4 r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w; return r;
 }
 
+// dev builds (-DWINO_TRACE=1, tools/wino_trace.py): the four waves of one block in the middle of the grid sum the s_memtime ticks of
+// their body 0 (pixel + weight loads beside the MFMAs) and body 1 (transform + weight loads) segments; stamps are read a segment
+// after they were issued, so the scalar wait is free
+#ifndef WINO_TRACE
+#define WINO_TRACE 0
+#endif
+#if WINO_TRACE
+__device__ unsigned long long* g_wino_trace = nullptr;
+#define WTR_STAMP(dst) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0" : "=s"(dst) : "s"(tr_prev) : "memory"); 
+#endif
+
 template <int OUT_NC8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(WinoParams p) {
+#if WINO_TRACE
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tr_a = 0, tr_b = 0, tr_prev = 0, tr_sum0 = 0, tr_sum1 = 0, tr_loop0 = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,6 +105,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
     const bool ok = tvalid && y >= 0 && y < p.H && x >= 0 && x < p.W;
     voff[k] = ok ? (((n * (p.Cin >> 3)) * p.H + y) * p.W + x) * 32 + lrow * 16 : (int)0x80000000;
+    if (WINO_ABL & 8) {   // dev: same bytes per load, but the wave's 64 lanes read two contiguous 512-byte runs (wrong results)
+      const int t0 = min(bx * 128 + wave * 32, p.ntiles - 32);
+      const int n0 = t0 / tpi, r0 = t0 - n0 * tpi, ty0 = r0 / p.TX, tx0 = r0 - ty0 * p.TX;
+      const int y0 = min(max(2 * ty0 - 1 + i, 0), p.H - 2), x0 = min(max(2 * tx0 - 1 + j, 0), p.W - 1);
+      voff[k] = (((n0 * (p.Cin >> 3)) * p.H + y0) * p.W + x0) * 32 + lcol * 16 + lrow * 512;
+    }
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
@@ -103,46 +125,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-  f32x4 raw[16];               // pixels of the NEXT channel block: 4 channels per lane (both bodies), row pass in place
-  f32x2 Va[16], Vb[16], Vc[16], A[16];
+  f32x4 raw[16], T[16];        // pixels of the NEXT channel block (4 channels per lane = both bodies) and their row pass
+  f32x2 Va[16], Vb[16], Vc[16], A0[16], A1[16];   // weights of body 0 / body 1: each reloaded right behind its last use, a whole block ahead
 #define WLOADB(k, soff) \
   raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], (soff), 0));
-#define WLOADA(q, soff) \
+#define WLOADA(A, q, soff) \
   A[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrw, ((q) < 8 ? wvo0 : wvo1) + ((q) & 7) * 512, (soff), 0));
-// row pass of B^T d B on patch column j = k / 4 (slots j*4 + i), in place: slot j*4 + xi becomes T[xi][j]. One call per column.
-#define WROWS(j_)                                                                              \
+// row pass of B^T d B, one output per call: T[xi*4 + j] from patch column j (raw slots j*4 + i). (One call per MFMA slot: a slot
+// that carries a whole column's 16 scalar adds overruns the 64-cycle MFMA gap of the wave's only SIMD.)
+#define WROW(k)                                                                                \
   {                                                                                            \
-    const f32x4 d0 = raw[(j_) * 4 + 0], d1 = raw[(j_) * 4 + 1], d2 = raw[(j_) * 4 + 2], d3 = raw[(j_) * 4 + 3]; \
-    raw[(j_) * 4 + 0] = wsub(d0, d2); raw[(j_) * 4 + 1] = wadd(d1, d2); raw[(j_) * 4 + 2] = wsub(d2, d1); raw[(j_) * 4 + 3] = wsub(d1, d3); \
+    const int j_ = (k) >> 2, w_ = (k) & 3;                                                     \
+    const f32x4 d0 = raw[j_ * 4 + 0], d1 = raw[j_ * 4 + 1], d2 = raw[j_ * 4 + 2], d3 = raw[j_ * 4 + 3]; \
+    T[w_ * 4 + j_] = w_ == 0 ? wsub(d0, d2) : w_ == 1 ? wadd(d1, d2) : w_ == 2 ? wsub(d2, d1) : wsub(d1, d3); \
   }
-// column pass: position k = xi*4 + nu from T[xi][0..3] = raw slots (0..3)*4 + xi; channels .xy go to body 0's V, .zw to body 1's
+// column pass: position k = xi*4 + nu from T[xi*4 + 0..3]; channels .xy go to body 0's V, .zw to body 1's
 #define WCOL(V0_, V1_, k)                                                                      \
   {                                                                                            \
     const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
-    const f32x4 t0 = raw[x_], t1 = raw[4 + x_], t2 = raw[8 + x_], t3 = raw[12 + x_];           \
-    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3);     \
+    const f32x4 t0 = T[x_ * 4 + 0], t1 = T[x_ * 4 + 1], t2 = T[x_ * 4 + 2], t3 = T[x_ * 4 + 3]; \
+    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3); \
     V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
   }
+// the two halves of the column pass on their own (WINO_SPLITCOL): .xy in body 1, .zw in the first slots of the next block's body 0
+#define WCOLH(V_, k, HI)                                                                       \
+  {                                                                                            \
+    const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
+    const f32x2 t0 = (HI) ? T[x_ * 4 + 0].zw : T[x_ * 4 + 0].xy, t1 = (HI) ? T[x_ * 4 + 1].zw : T[x_ * 4 + 1].xy; \
+    const f32x2 t2 = (HI) ? T[x_ * 4 + 2].zw : T[x_ * 4 + 2].xy, t3 = (HI) ? T[x_ * 4 + 3].zw : T[x_ * 4 + 3].xy; \
+    V_[k] = w_ == 0 ? t0 - t2 : w_ == 1 ? t1 + t2 : w_ == 2 ? t2 - t1 : t1 - t3;              \
+  }
+#ifndef WINO_SPLITCOL
+#define WINO_SPLITCOL 0   // measured: 0.787 vs 0.770 ms on conv3_1 — the cost is per VALU instruction beside the MFMAs, not per crowded slot
+#endif
 
-  // prologue: weights of body 0, pixels of channel block 0 -> V of both its bodies
+  // prologue: weights of bodies 0 and 1, pixels of channel block 0 -> V of both its bodies, then the pixels of block 1
   // (issue order pinned: the loop header's one s_waitcnt serves both the entry and the back edge — with the weights loaded
   // last here, as the scheduler would have it, it becomes vmcnt(0) and drains everything in flight once per trip)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) WLOADA(q, abase * 8192)
+  for (int q = 0; q < 16; ++q) WLOADA(A0, q, abase * 8192)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) WLOADA(A1, q, (abase + 1) * 8192)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 16; ++k) WLOADB(k, 0)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) WROWS(j)
+  for (int k = 0; k < 16; ++k) WROW(k)
 #pragma unroll
   for (int k = 0; k < 16; ++k) WCOL(Va, Vb, k)
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const int sb1 = __builtin_amdgcn_readfirstlane(min(1, c8n - 1) * hw32);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) WLOADB(k, sb1)
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
-  // channel block c = two bodies of 4 channels (32 MFMAs each). Body 0 multiplies Va and receives the 16 pixel loads of block
-  // c + 1 (one per MFMA slot, a body ahead of their first use); body 1 multiplies X while the transform of block c + 1 runs in
-  // its slots (row passes, then column passes into Va — free by now — and Y). Every A[q] is reloaded for the next body right
-  // behind its last use. X / Y swap roles from one block to the next.
-#define WMFMA(VV, q, s_) \
+  // channel block c = two bodies of 4 channels (32 MFMAs each). Body 0 multiplies Va; body 1 multiplies X while the transform of
+  // block c + 1 runs in its slots — row passes in the first 16, column passes in the last 16 (into Va, free by now, and Y), and
+  // behind each row pass slot's column the 16 pixel loads of block c + 2 refill `raw` (48 slots ahead of their first use).
+  // Every A0[q] / A1[q] is reloaded for the next block right behind its last use (62 slots ahead): loads return in order, so a
+  // weight load needed soon must not queue behind a pixel load that misses to HBM — with the weights one body ahead (30 slots)
+  // the pixel loads cost 13 % (tools/wino_trace.py, ablations in profiles/r04_winograd.md). X / Y swap roles from block to block.
+#define WMFMA(A, VV, q, s_) \
   acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) ? A[q].y : A[q].x, (s_) ? VV[q].y : VV[q].x, acc[q], 0, 0, 0); \
   asm volatile("" : "+a"(acc[q]));
 // MFMA order inside a body: positions in pairs, (q0,s0) (q1,s0) (q0,s1) (q1,s1) — WINO_PAIR 0 puts the two k-steps of a
@@ -152,23 +198,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 #define WQ(sl) (WINO_PAIR ? (((sl) >> 2) * 2 + ((sl) & 1)) : ((sl) >> 1))
 #define WS(sl) (WINO_PAIR ? (((sl) >> 1) & 1) : ((sl) & 1))
+#if WINO_TRACE
+#define WTR0 { tr_prev = tr_b; WTR_STAMP(tr_a) if (tr_prev) tr_sum1 += tr_a - tr_prev; else tr_loop0 = tr_a; }
+#define WTR1 { tr_prev = tr_a; WTR_STAMP(tr_b) tr_sum0 += tr_b - tr_prev; }
+#else
+#define WTR0
+#define WTR1
+#endif
 #define WSUPER(X, Y, sb, sa0, sa1)                                                             \
+  WTR0                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(Va, WQ(sl), WS(sl))                                                                  \
-    if (!(WINO_ABL & 1) && sl < 16) { WLOADB(sl, sb) }                                         \
-    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa0) }                                     \
+    WMFMA(A0, Va, WQ(sl), WS(sl))                                                              \
+    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(A0, WQ(sl), sa0) }                                 \
+    if (WINO_SPLITCOL && !(WINO_ABL & 4) && sl < 16) WCOLH(X, sl, 1)   /* this block's body-1 operands, from the T left by the previous body 1 */ \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }                                                                                            \
+  WTR1                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(X, WQ(sl), WS(sl))                                                                   \
-    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa1) }                                     \
-    if (!(WINO_ABL & 4)) { if (sl < 16) { if (!(sl & 3)) WROWS(sl >> 2) } else WCOL(Va, Y, sl - 16) } \
+    WMFMA(A1, X, WQ(sl), WS(sl))                                                               \
+    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(A1, WQ(sl), sa1) }                                 \
+    if (!(WINO_ABL & 4)) { if (sl < 16) WROW(sl) else if (WINO_SPLITCOL) WCOLH(Va, sl - 16, 0) else WCOL(Va, Y, sl - 16) } \
+    if ((WINO_ABL & 16) && sl < 16) asm volatile("" :: "v"(raw[sl]));   /* dev: pixel loads kept alive without the transform */ \
+    if (!(WINO_ABL & 1) && sl >= 16) { WLOADB(sl - 16, sb) }                                   \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }
 #define WOFFS(c8)                                                                              \
-  const int sb = __builtin_amdgcn_readfirstlane(min((c8) + 1, c8n - 1) * hw32); /* clamped: loads past the end re-read the last block */ \
-  const int sa0 = __builtin_amdgcn_readfirstlane((abase + 2 * (c8) + 1) * 8192);               \
-  const int sa1 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 2, p.nb - 1)) * 8192);
+  const int sb = __builtin_amdgcn_readfirstlane(min((c8) + 2, c8n - 1) * hw32); /* clamped: loads past the end re-read the last block */ \
+  const int sa0 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 2, p.nb - 2)) * 8192);  \
+  const int sa1 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 3, p.nb - 1)) * 8192);
 
   int c8 = 0;
   for (; c8 + 2 <= c8n; c8 += 2) {
@@ -180,10 +237,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WSUPER
 #undef WMFMA
 #undef WCOL
-#undef WROWS
+#undef WCOLH
+#undef WROW
 #undef WLOADA
 #undef WLOADB
 
+#if WINO_TRACE
+  const unsigned long long tr_t2 = __builtin_amdgcn_s_memtime();
+#endif
   // output transform Y = A^T M A per (channel, tile), bias, LeakyReLU, store. acc[q][r]: channel (r&3) + 8(r>>2) + 4·lrow, tile lcol
   if (!tvalid) return;
   const int y0 = 2 * ty, x0 = 2 * tx;
@@ -216,8 +277,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if ((a && !y1ok) || (b && !x1ok)) continue;
       const long pix = (long)(y0 + a) * p.W + x0 + b;
       if (OUT_NC8) {
-        const long cb = (long)n * (p.Cout >> 3) + mb * 4 + g;
-        *reinterpret_cast<float4*>(p.out + (cb * p.H * p.W + pix) * 8 + 4 * lrow) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]);
+        long rec;
+        if (p.out_s2d)   // output (2ty + a, 2tx + b) is pixel (ty, tx) of phase plane a*2 + b: consecutive tiles, consecutive records
+          rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * p.TX) + ty * p.TX + tx;
+        else
+          rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;
+        *reinterpret_cast<float4*>(p.out + rec * 8 + 4 * lrow) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]);
       } else {
         const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow;
 #pragma unroll
@@ -225,10 +290,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   }
+#if WINO_TRACE
+  if (g_wino_trace && blockIdx.x == gridDim.x / 2 && lane == 0) {   // [wave][8]: prologue, sum body 0, sum body 1, epilogue, total, blocks of 8 channels
+    const unsigned long long tr_t3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = g_wino_trace + wave * 8;
+    o[0] = tr_loop0 - tr_t0; o[1] = tr_sum0; o[2] = tr_sum1 + (tr_t2 - tr_b); o[3] = tr_t3 - tr_t2; o[4] = tr_t3 - tr_t0; o[5] = (unsigned long long)c8n;
+  }
+#endif
 }
 
 // U = G g G^T in double, rounded once; packed [Cout/32][body = Cin/4][position][lane = h*32 + row][s] with channel 8(body/2) + 4h + 2(body%2) + s
-__global__ void pack_wino_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, long total) {
+// s2d: `w` is a (Cout, Cin/4, 5, 5) stride-2 pad-2 kernel read as the 3x3 stride-1 pad-1 kernel over the 4 input phases it is
+// equivalent to — channel phase*(Cin/4) + c, phase = py*2 + px, tap (a, b) = w[2a + py][2b + px] (zero where 2a + py or 2b + px = 5)
+__global__ void pack_wino_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, long total, int s2d) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int s = (int)(i & 1), r = (int)((i >> 1) & 31), h = (int)((i >> 6) & 1), q = (int)((i >> 7) & 15);
@@ -237,11 +311,19 @@ __global__ void pack_wino_kernel(float* __restrict__ packed, const float* __rest
   const int c4 = (int)(bi % nb), mb = (int)(bi / nb);
   const int co = mb * 32 + r, ci = (c4 >> 1) * 8 + 4 * h + 2 * (c4 & 1) + s;
   const int xi = q >> 2, nu = q & 3;
-  const float* g = w + ((long)co * Cin + ci) * 9;
   const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   double u = 0;
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) u += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+  if (s2d) {
+    const int C0 = Cin >> 2, ph = ci / C0, py = ph >> 1, px = ph & 1;
+    const float* g = w + ((long)co * C0 + (ci - ph * C0)) * 25;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b)
+        if (2 * a + py < 5 && 2 * b + px < 5) u += G[xi][a] * (double)g[(2 * a + py) * 5 + 2 * b + px] * G[nu][b];
+  } else {
+    const float* g = w + ((long)co * Cin + ci) * 9;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) u += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
+  }
   packed[i] = (float)u;
 }
 
@@ -256,24 +338,53 @@ extern "C" size_t deepim_conv_wino_packed_size(int Cout, int Cin) {
 #ifndef WINO_MIN_BLOCKS
 #define WINO_MIN_BLOCKS 128
 #endif
+// (stride-2 layers over the space-to-depth input save 1.56x multiplies, not 2.25x: they need a grid of several full rounds
+// before the saving outweighs the under-filled last round — at B = 4 conv2 + conv3 on this kernel cost 4 % of the iteration,
+// from 1200 blocks on they gain)
+#ifndef WINO_MIN_BLOCKS_S2D
+#define WINO_MIN_BLOCKS_S2D 1024
+#endif
+static long wino_blocks(int B, int H, int W, int Cout) {
+  const long tiles = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return (long)di_div_up(tiles, 128) * (Cout / 32);
+}
 extern "C" int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
   (void)ctx;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7)) return 0;
-  const long tiles = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
-  return (long)di_div_up(tiles, 128) * (Cout / 32) >= WINO_MIN_BLOCKS ? 1 : 0;
+  return wino_blocks(B, H, W, Cout) >= WINO_MIN_BLOCKS ? 1 : 0;
+}
+// the same question for a 5x5 stride-2 pad-2 layer with input (B, Cin, H, W) run over its space-to-depth form
+extern "C" int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
+  (void)ctx;
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7) || ((H | W) & 1)) return 0;
+  return wino_blocks(B, H / 2, W / 2, Cout) >= WINO_MIN_BLOCKS_S2D ? 1 : 0;
 }
 
 extern "C" int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin) {
   DI_DEVICE(ctx);
   DI_REQUIRE(Cout > 0 && Cin > 0 && (Cout & 31) == 0 && (Cin & 7) == 0, "conv_wino_pack_weights: Cout % 32 == 0 and Cin % 8 == 0 required");
   const long total = (long)Cout * Cin * 16;
-  pack_wino_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(packed_w, w, Cout, Cin, total);
+  pack_wino_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(packed_w, w, Cout, Cin, total, 0);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// A 5x5 stride-2 pad-2 layer (conv2 / conv3) as this kernel's 3x3 stride-1 pad-1 problem over the space-to-depth input:
+// (B, Cin, H, W) -> (B, 4 Cin, H/2, W/2), 16 positions x 4 Cin instead of 25 taps x 4 outputs x Cin per 2x2 tile = 1.56x fewer
+// multiplies. w is the layer's own (Cout, Cin, 5, 5) tensor; the packed size is deepim_conv_wino_packed_size(Cout, 4 * Cin) and
+// the forward call is deepim_conv2d_wino_forward(..., Cin = 4 * Cin, H / 2, W / 2, ...) on the space-to-depth NC8 tensor.
+extern "C" int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin) {
+  DI_DEVICE(ctx);
+  DI_REQUIRE(Cout > 0 && Cin > 0 && (Cout & 31) == 0 && (Cin & 7) == 0, "conv_wino_pack_weights_s2d: Cout % 32 == 0 and Cin % 8 == 0 required");
+  const long total = (long)Cout * Cin * 4 * 16;
+  pack_wino_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(packed_w, w, Cout, Cin * 4, total, 1);
   DI_LAUNCH_CHECK();
   return 0;
 }
 
 // 3x3, stride 1, pad 1 convolution + bias + LeakyReLU(slope) from channel-blocked `in` (B, Cin/8, H, W, 8) into channel-blocked
-// `out` (out_nc8 = 1) or into channels [out_coff, out_coff + Cout) of an NCHW tensor of out_ctotal channels (out_nc8 = 0).
+// `out` (out_nc8 = 1; 3 = channel-blocked in space-to-depth order, what a stride-2 layer on this kernel reads) or into channels
+// [out_coff, out_coff + Cout) of an NCHW tensor of out_ctotal channels (out_nc8 = 0).
 extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
                                           int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal,
                                           int out_coff) {
@@ -294,9 +405,18 @@ extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const flo
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
+  p.out_s2d = out_nc8 == 3 ? 1 : 0;
+  if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   const int grid = p.gx * p.gy;
   if (out_nc8) conv_wino_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
   else conv_wino_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
   DI_LAUNCH_CHECK();
   return 0;
 }
+
+#if WINO_TRACE
+extern "C" int deepim_dev_wino_trace(void* buf) {
+  unsigned long long* b = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &b, sizeof(b));
+}
+#endif

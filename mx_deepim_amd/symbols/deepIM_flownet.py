@@ -274,14 +274,21 @@ class deepIM_flownet(object):
                 pk = DeviceArray(ctx, (nb // 4,))
                 lib.deepim_conv_pack_weights(h, pk, self.params[name], cout, cin, kh, kw)
             self.packed[base] = pk
-        self.packed_wino = {}
+        self.packed_wino, self.wino_s2d = {}, set()
         if self.nc8 and getattr(self, "winograd", False) and not (self.fp16_conv or self.x3_conv or getattr(self, "is_train", False)):
             hh, ww, cin = H, W, self.cin
-            for name, cout, k, s_, p_ in ENCODER:
-                if (k, s_, p_) == (3, 1, 1) and lib.load().deepim_conv_wino_preferred(h, B, cin, hh, ww, cout):
-                    pk = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, cin) // 4,))
+            L = lib.load()
+            for li, (name, cout, k, s_, p_) in enumerate(ENCODER):
+                if (k, s_, p_) == (3, 1, 1) and L.deepim_conv_wino_preferred(h, B, cin, hh, ww, cout):
+                    pk = DeviceArray(ctx, (L.deepim_conv_wino_packed_size(cout, cin) // 4,))
                     lib.deepim_conv_wino_pack_weights(h, pk, self.params[name + "_weight"], cout, cin)
                     self.packed_wino[name] = pk
+                elif (k, s_, p_) == (5, 2, 2) and li > 0 and L.deepim_conv_wino_preferred_s2d(h, B, cin, hh, ww, cout):
+                    # stride 2 = stride 1 over the four input phases: the layer before writes its output space-to-depth
+                    pk = DeviceArray(ctx, (L.deepim_conv_wino_packed_size(cout, 4 * cin) // 4,))
+                    lib.deepim_conv_wino_pack_weights_s2d(h, pk, self.params[name + "_weight"], cout, cin)
+                    self.packed_wino[name] = pk
+                    self.wino_s2d.add(name)
                 hh, ww = _out_hw(hh, ww, k, s_, p_)
                 cin = cout
         # fc6: the 84 MB weight in MFMA operand order, so the layer is one pass over the weights on the matrix cores
@@ -490,16 +497,27 @@ class deepIM_flownet(object):
     def encoder_layer(self, li, src):
         """One encoder conv (index into enc_geom) from `src` into its activation buffer, in the configured layout."""
         name, cin, h, w, cout, k, s, p = self.enc_geom[li]
+        out_mode = self._enc_out_mode(li)
         if self.nc8 and name in self.packed_wino:
+            if name in self.wino_s2d:      # 5x5 stride 2 over the space-to-depth tensor the previous layer wrote
+                cin, h, w = 4 * cin, h // 2, w // 2
             lib.deepim_conv2d_wino_forward(self.ctx.handle, self.act[name], src, self.packed_wino[name], self.params[name + "_bias"],
-                                           self.B, cin, h, w, cout, ctypes.c_float(SLOPE), 1 if li < len(self.enc_geom) - 1 else 0, 0, 0)
+                                           self.B, cin, h, w, cout, ctypes.c_float(SLOPE), out_mode, 0, 0)
         elif self.nc8:
             in8 = 1 if (li > 0 or src.shape == (self.B, self.H, self.W, 8)) else 0     # conv1: NC8 records from the zoom front end
             lib.deepim_conv2d_forward_ex(self.ctx.handle, self.act[name], src, self.packed[name], self.params[name + "_bias"],
                                          self.B, cin, h, w, cout, k, k, s, p, ctypes.c_float(SLOPE), 0, 0,
-                                         in8, 1 if li < len(self.enc_geom) - 1 else 0)
+                                         in8, out_mode)
         else:
             self._conv(name, src, self.act[name], self.B, cin, h, w, cout, k, s, p, SLOPE)
+
+    def _enc_out_mode(self, li):
+        """Output layout of encoder layer li on the channel-blocked path: 0 = NCHW (the last layer, for fc6), 3 = NC8 in
+        space-to-depth order (the next layer is a stride-2 Winograd layer), 1 = NC8."""
+        if li == len(self.enc_geom) - 1:
+            return 0
+        nxt = self.enc_geom[li + 1][0]
+        return 3 if self.nc8 and nxt in getattr(self, "wino_s2d", ()) and nxt in getattr(self, "packed_wino", {}) else 1
 
     def activation_nchw(self, name):
         """Encoder activation `name` as an NCHW device array (a converted copy when the encoder ran channel-blocked)."""
@@ -515,6 +533,9 @@ class deepIM_flownet(object):
         if key not in self.act:
             self.act[key] = self.ctx.empty(a.shape)
         out = self.act[key]
+        if self._enc_out_mode(names.index(name)) == 3:
+            lib.deepim_relayout_nc8_s2d(self.ctx.handle, out, a, a.shape[0], a.shape[1], a.shape[2], a.shape[3], 0)
+            return out
         lib.deepim_relayout_nc8(self.ctx.handle, out, a, a.shape[0], a.shape[1], a.shape[2] * a.shape[3], 0)
         return out
 

@@ -78,6 +78,7 @@ def test_heads_iteration_matches_oracle(ctx, small_batch, nc8):
     params = net.init_weights(cfg, seed=8)
     net.bind(ctx, B, params)
     net.nc8 = nc8
+    net.packed_wino = {}        # bit-exact comparison: every layer on the direct kernels (none is bound at B = 1 anyway)
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)
     out = net.forward(_data(ctx, d1))
     lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)

@@ -89,3 +89,70 @@ def test_wino_argument_checks(ctx):
     with pytest.raises(RuntimeError):
         lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 1, 8, 2, 2, 40, cf(0.1), 1, 0, 0)
     lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 0, 8, 2, 2, 32, cf(0.1), 1, 0, 0)      # empty batch: no launch
+
+
+S2D_CASES = [
+    (2, 64, 24, 32, 128),      # conv2 channels at reduced size
+    (1, 128, 12, 16, 256),     # conv3 channels
+    (3, 8, 6, 10, 32),         # one channel block per phase
+    (1, 16, 2, 2, 64),         # a single output pixel row / column pair: every tap but the centre ones in the padding
+]
+
+
+@pytest.mark.parametrize("case", S2D_CASES)
+def test_wino_stride2_5x5_layer_over_space_to_depth_input(ctx, case):
+    """conv2 / conv3 (5x5, stride 2, pad 2) as the 3x3 stride-1 problem over the four input phases: relayout round trip, the layer
+    within 1e-5 of the direct convolution, and its own output in space-to-depth order (what the next such layer reads)."""
+    B, cin, H, W, cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = onet.conv2d(x, w, b, 2, 2, 0.1)
+    Ho, Wo = H // 2, W // 2
+    assert ref.shape == (B, cout, Ho, Wo)
+    xs = ctx.empty((B, 4 * cin, Ho, Wo))
+    lib.deepim_relayout_nc8_s2d(ctx.handle, xs, ctx.array(x), B, cin, H, W, 1)
+    want = np.concatenate([x[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], axis=1)      # channel (py*2+px)*cin + c
+    np.testing.assert_array_equal(_from_nc8(xs.asnumpy(), (B, 4 * cin, Ho, Wo)), want)
+    back = ctx.empty(x.shape)
+    lib.deepim_relayout_nc8_s2d(ctx.handle, back, xs, B, cin, H, W, 0)
+    np.testing.assert_array_equal(back.asnumpy(), x)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, 4 * cin) // 4,))
+    lib.deepim_conv_wino_pack_weights_s2d(ctx.handle, pk, ctx.array(w), cout, cin)
+    out = ctx.zeros((B, cout, Ho, Wo))
+    lib.deepim_conv2d_wino_forward(ctx.handle, out, xs, pk, ctx.array(b), B, 4 * cin, Ho, Wo, cout, cf(0.1), 1, 0, 0)
+    got = _from_nc8(out.asnumpy(), (B, cout, Ho, Wo))
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= TOL * scale, np.abs(got - ref).max() / scale
+    if Ho % 2 == 0 and Wo % 2 == 0:
+        out2 = ctx.zeros((B, cout, Ho, Wo))
+        lib.deepim_conv2d_wino_forward(ctx.handle, out2, xs, pk, ctx.array(b), B, 4 * cin, Ho, Wo, cout, cf(0.1), 3, 0, 0)
+        nchw = ctx.empty((B, cout, Ho, Wo))
+        lib.deepim_relayout_nc8_s2d(ctx.handle, nchw, out2, B, cout, Ho, Wo, 0)
+        np.testing.assert_array_equal(nchw.asnumpy(), got)
+
+
+@pytest.mark.parametrize("max_split", [1, 0])
+def test_direct_kernels_write_space_to_depth_output(ctx, max_split):
+    """out_nc8 = 3 of deepim_conv2d_forward_ex: the same values as the NC8 output, at their space-to-depth addresses — from the
+    NCHW-input kernel (conv1's) and from the NC8-input kernel, with and without a split-K second pass."""
+    rng = np.random.default_rng(3)
+    for (B, cin, H, W, cout, k, s, p, in8) in [(2, 8, 24, 40, 64, 7, 2, 3, 0), (1, 64, 12, 20, 128, 5, 2, 2, 1), (1, 512, 8, 12, 256, 3, 1, 1, 1)]:
+        x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cout, cin, k, k) // 4,))
+        lib.deepim_conv_pack_weights(ctx.handle, pk, ctx.array(w), cout, cin, k, k)
+        xin = ctx.array(_to_nc8(x) if in8 else x)
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", max_split)
+        try:
+            o1, o3 = ctx.zeros((B, cout, Ho, Wo)), ctx.zeros((B, cout, Ho, Wo))
+            lib.deepim_conv2d_forward_ex(ctx.handle, o1, xin, pk, ctx.array(b), B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, in8, 1)
+            lib.deepim_conv2d_forward_ex(ctx.handle, o3, xin, pk, ctx.array(b), B, cin, H, W, cout, k, k, s, p, cf(0.1), 0, 0, in8, 3)
+        finally:
+            lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+        nchw = ctx.empty((B, cout, Ho, Wo))
+        lib.deepim_relayout_nc8_s2d(ctx.handle, nchw, o3, B, cout, Ho, Wo, 0)
+        np.testing.assert_array_equal(nchw.asnumpy(), _from_nc8(o1.asnumpy(), (B, cout, Ho, Wo)))

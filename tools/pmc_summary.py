@@ -8,18 +8,20 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 disp = OrderedDict()
 for r in rows:
     key = r["Dispatch_Id"]
-    d = disp.setdefault(key, {"name": r["Kernel_Name"], "grid": r.get("Grid_Size", "?"), "vgpr": r.get("VGPR_Count", "?"), "agpr": r.get("Accum_VGPR_Count", "?")})
+    d = disp.setdefault(key, {"name": r["Kernel_Name"], "grid": r.get("Grid_Size", "?"), "vgpr": r.get("VGPR_Count", "?"), "agpr": r.get("Accum_VGPR_Count", "?"),
+                              "ns": (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) if r.get("End_Timestamp") else 0.0})
     d[r["Counter_Name"]] = float(r["Counter_Value"])
 last = OrderedDict()
 for d in disp.values():
     last[(d["name"], d["grid"])] = d
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*$", "", n)[:44]
-print("%-44s %9s %9s %6s %6s %6s %6s %6s" % ("kernel", "grid", "vgpr+a", "mfma", "w_any", "w_inst", "active", "ldsbc"))
+print("%-44s %9s %9s %6s %6s %6s %6s %6s %8s %6s" % ("kernel", "grid", "vgpr+a", "mfma", "w_any", "w_inst", "active", "ldsbc", "us", "GHz"))
 for (n, g), d in last.items():
     if "wgrad" not in n and "conv" not in n: continue
     wc = d.get("SQ_WAVE_CYCLES", 0) or 1
     gui = d.get("GRBM_GUI_ACTIVE", 0) or 1
-    print("%-44s %9s %9s %6.3f %6.2f %6.2f %6.2f %6.3f" % (short(n), g, "%s+%s" % (d["vgpr"], d["agpr"]),
+    print("%-44s %9s %9s %6.3f %6.2f %6.2f %6.2f %6.3f %8.1f %6.2f" % (short(n), g, "%s+%s" % (d["vgpr"], d["agpr"]),
           d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 128), d.get("SQ_WAIT_ANY", 0) / wc, d.get("SQ_WAIT_INST_ANY", 0) / wc,
-          d.get("SQ_ACTIVE_INST_ANY", 0) / wc, d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, d.get("SQ_ACTIVE_INST_LDS", 0))))
+          d.get("SQ_ACTIVE_INST_ANY", 0) / wc, d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, d.get("SQ_ACTIVE_INST_LDS", 0)),
+          d["ns"] / 1e3, (gui / d["ns"]) if d["ns"] else 0.0))   # effective shader clock = GRBM_GUI_ACTIVE / wall (profiled pass)
