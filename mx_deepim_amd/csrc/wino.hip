@@ -249,6 +249,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (!tvalid) return;
   const int y0 = 2 * ty, x0 = 2 * tx;
   const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+  // the lane's 16 bias values in one batch (element-wise loads behind a null check each serialise four round trips per g); the
+  // opaque copy of mb keeps the loads BELOW the K loop, where their 16 registers would spill
+  float4 bq[4];
+  int mbe = mb;
+  asm volatile("" : "+s"(mbe));
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    bq[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + mbe * 32 + 8 * g + 4 * lrow) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float o[4][4];   // [a*2+b][channel within the run of 4]
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         s[xi][0] = (m0 + m1) + m2;
         s[xi][1] = (m1 - m2) - m3;
       }
-      const float bv = p.bias ? p.bias[mb * 32 + 8 * g + 4 * lrow + e] : 0.f;
+      const float bv = e == 0 ? bq[g].x : e == 1 ? bq[g].y : e == 2 ? bq[g].z : bq[g].w;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         float v0 = ((s[0][b] + s[1][b]) + s[2][b]) + bv;
