@@ -642,7 +642,7 @@ def main():
         traffic, traffic_src = None, None                # HBM bytes per conv launch group from a recorded PMC pass
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and not args.fp16:
-            tj = json.load(open(tpath)).get(("x3_B%d" if args.x3 else "B%d") % B)
+            tj = json.load(open(tpath)).get(("x3_B%d" if args.x3 else ("wino_B%d" if getattr(net, "packed_wino", None) else "B%d")) % B)
             if tj:
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         out = headline(args, world, NIT, dt, pairs_total, scaling, args.steps, args.warmup, gbatch if scaling == "strong" else B)
@@ -683,8 +683,7 @@ def main():
                          # `achieved` counts the ALGORITHMIC multiply-adds (9 per output and input channel); the Winograd layers
                          # execute 16 per 2x2 tile = 4/9 of that, so the matrix pipe's own rate is `executed`
                          "executed": executed, "frac_executed": executed / peak, "winograd_layers": wino_layers,
-                         "traffic": traffic if not wino_layers else None,
-                         "traffic_source": traffic_src if not wino_layers else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch_group": flops, "ms_per_launch_group": enc_ms},
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",
                               "achieved": zoom_bytes / (zoom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

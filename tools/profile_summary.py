@@ -24,7 +24,7 @@ def short(name):
 
 
 def is_conv(n):
-    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "splitk_reduce", "tail_reduce",
+    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "conv_wino_kernel", "splitk_reduce", "tail_reduce",
                          "conv_f16", "conv1_x3", "splitk_x3", "splitk_f16", "tail_f16", "split16_to_nchw", "nchw_to_split16",
                          "_ZN12_GLOBAL__N_123splitk_x3", "_ZN12_GLOBAL__N_122split16_to"))
 
@@ -33,7 +33,7 @@ def cmd_stats(a):
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
-    marks = [i for i, n in enumerate(names) if n.startswith("rt_transform_kernel")]
+    marks = [i for i, n in enumerate(names) if n.startswith(("rt_transform_kernel", "pose_tail_kernel"))]
     assert len(marks) >= a.iters, "trace holds fewer iterations than --iters"
     # timed region = from just after the (iters+1)-th last pose update to the last kernel
     first = marks[-a.iters - 1] + 1 if len(marks) > a.iters else 0
@@ -68,14 +68,14 @@ def cmd_traffic(a):
     def load(path):
         g = defaultdict(lambda: [0, 0.0])
         rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-        marks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("rt_transform_kernel")]
+        marks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("rt_transform_kernel", "pose_tail_kernel"))]
         assert len(marks) > a.iters, "run holds no priming pass before the last --iters iterations"
         for r in rows[marks[-a.iters - 1] + 1:]:       # the last `iters` iterations: priming/autotuning launches excluded
             n = short(r["Kernel_Name"])
             key = "conv kernels + split-K reduces" if is_conv(n) else (
                 "zoom front end (bbox, zoom_factor, resample)" if re.match(r"bbox|zoom_factor|resample|zoom_concat", n) else (
                     "re-render + mask update" if re.match(r"project|raster|resolve|depth_to_mask|mask_b", n) else (
-                        "fc / pose head / rt_transform" if re.match(r"fc_|pose_head|rt_transform", n) else n)))
+                        "fc / pose head / rt_transform" if re.match(r"fc_|pose_head|pose_tail|rt_transform", n) else n)))
             g[key][0] += 1
             g[key][1] += float(r["Counter_Value"])
         return g
@@ -100,7 +100,7 @@ def cmd_traffic(a):
     open(a.md, "w").write("\n".join(lines) + "\n")
     import os
     allj = json.load(open(a.json)) if os.path.exists(a.json) else {}
-    allj = {k: v for k, v in allj.items() if k.startswith(("B", "x3_"))}          # one entry per mode / per-GPU batch size
+    allj = {k: v for k, v in allj.items() if k.startswith(("B", "x3_", "wino_"))}          # one entry per mode / per-GPU batch size
     allj[a.key or "B%d" % a.batch] = {"conv_launch_group_bytes_corrected": (2 * fr + wr) * 1e6, "conv_launch_group_bytes_raw": (fr + wr) * 1e6,
                              "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=%d, FETCH doubled per MI355X_MICROARCH.md)" % (a.md, a.batch)}
     json.dump(allj, open(a.json, "w"), indent=1)
