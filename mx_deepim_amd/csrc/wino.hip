@@ -359,12 +359,14 @@ static long wino_blocks(int B, int H, int W, int Cout) {
 extern "C" int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
   (void)ctx;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7)) return 0;
+  if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;   // one buffer descriptor per launch: larger inputs stay on the direct kernels (sub-batched there)
   return wino_blocks(B, H, W, Cout) >= WINO_MIN_BLOCKS ? 1 : 0;
 }
 // the same question for a 5x5 stride-2 pad-2 layer with input (B, Cin, H, W) run over its space-to-depth form
 extern "C" int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
   (void)ctx;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7) || ((H | W) & 1)) return 0;
+  if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;
   return wino_blocks(B, H / 2, W / 2, Cout) >= WINO_MIN_BLOCKS_S2D ? 1 : 0;
 }
 

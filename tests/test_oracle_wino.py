@@ -1,0 +1,76 @@
+"""CPU: the identities behind csrc/wino.hip against the oracle's direct convolution — exact in float64, and inside the layer bar
+(1e-5 of the output range) in float32 at the encoder's reduction lengths; plus the layer-selection rule of the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import net as onet
+from oracle import wino
+
+
+def _direct64(x, w, stride, pad):
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xp = np.zeros((B, Cin, H + 2 * pad, W + 2 * pad))
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    out = np.zeros((B, Cout, Ho, Wo))
+    for a in range(k):
+        for b in range(k):
+            out += np.einsum("oc,bcyx->boyx", w[:, :, a, b].astype(np.float64),
+                             xp[:, :, a:a + stride * Ho:stride, b:b + stride * Wo:stride])
+    return out
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9, 6), (1, 3, 2, 2, 4), (1, 4, 1, 6, 3)])
+def test_winograd_identity_is_exact_in_float64(shape):
+    B, cin, H, W, cout = shape
+    rng = np.random.default_rng(sum(shape))
+    x, w = rng.standard_normal((B, cin, H, W)), rng.standard_normal((cout, cin, 3, 3))
+    np.testing.assert_allclose(wino.winograd_f2x2_3x3(x, w), _direct64(x, w, 1, 1), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 12, 5), (1, 2, 2, 2, 3), (1, 8, 6, 4, 2)])
+def test_stride2_5x5_equals_3x3_over_the_four_phases(shape):
+    B, cin, H, W, cout = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    x, w = rng.standard_normal((B, cin, H, W)), rng.standard_normal((cout, cin, 5, 5))
+    ref = _direct64(x, w, 2, 2)
+    got = _direct64(wino.space_to_depth(x), wino.s2d_weights_5x5(w), 1, 1)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(wino.winograd_f2x2_3x3(wino.space_to_depth(x), wino.s2d_weights_5x5(w)), ref, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("cin", [256, 1024])
+def test_float32_winograd_stays_inside_the_layer_bar(cin):
+    """The kernel's arithmetic (fp32 transforms, fp32 channel sum, U rounded once) on K = 9 * cin products per output: error relative
+    to the output range against the oracle's fp32 direct convolution — the 1e-5 bar of tests/test_gpu_wino.py has a decade of room."""
+    rng = np.random.default_rng(cin)
+    x = rng.standard_normal((1, cin, 4, 6)).astype(np.float32)
+    w = (rng.standard_normal((8, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    ref = onet.conv2d(x, w, np.zeros(8, np.float32), 1, 1, 1.0)
+    got = wino.winograd_f2x2_3x3(x, w, dtype=np.float32)
+    err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    assert err <= 2e-6, err
+
+
+def test_layer_selection_rule():
+    """deepim_conv_wino_preferred[_s2d] is host arithmetic (no device call): which encoder layers take the Winograd kernel per batch."""
+    from mx_deepim_amd.runtime import lib
+    L = lib.load()
+    k3 = {"conv3_1": (256, 60, 80, 256), "conv4_1": (512, 30, 40, 512), "conv5_1": (512, 15, 20, 512), "conv6_1": (1024, 8, 10, 1024)}
+    k5 = {"conv2": (64, 240, 320, 128), "conv3": (128, 120, 160, 256)}
+
+    def chosen(B):
+        s = {n for n, (ci, h, w, co) in k3.items() if L.deepim_conv_wino_preferred(None, B, ci, h, w, co)}
+        return s | {n for n, (ci, h, w, co) in k5.items() if L.deepim_conv_wino_preferred_s2d(None, B, ci, h, w, co)}
+    assert chosen(32) == set(k3) | set(k5)
+    assert chosen(16) == {"conv2", "conv3", "conv3_1", "conv4_1", "conv5_1"}
+    assert chosen(8) == {"conv2", "conv3_1", "conv4_1"}
+    assert chosen(4) == {"conv3_1", "conv4_1"}
+    assert chosen(1) == set()
+    assert not L.deepim_conv_wino_preferred(None, 32, 12, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 32, 256, 60, 80, 48)
+    assert not L.deepim_conv_wino_preferred_s2d(None, 32, 64, 241, 320, 128)          # odd height: no space-to-depth form
+    assert L.deepim_conv_wino_packed_size(256, 256) == 256 * 256 * 64
+    assert L.deepim_conv_wino_preferred(None, 64, 256, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 512, 256, 60, 80, 256)   # >= 2 GiB input
