@@ -13,7 +13,7 @@
 //   * lane (h = lane / 32, t = lane % 32): tile t of the wave's 32 consecutive tiles, k index h of v_mfma_f32_32x32x2_f32.
 //     Per block of 8 input channels lane h reads channels 4h..4h+3 of each patch pixel with ONE 16-byte load (a wave touches
 //     32 bytes of every pixel record it visits): body j = 0, 1 of the block multiplies channels 4h + 2j + s in its two k-steps
-//     s. 16 pixel loads + 32 weight loads (8 bytes) + 64 pk-adds of transform per 64 MFMAs. (Measured: 8-byte pixel loads, one
+//     s. 16 pixel loads + 16 weight loads (all 16 bytes) + 128 adds of transform per 64 MFMAs. (Measured: 8-byte pixel loads, one
 //     body at a time, spend 26 % of the kernel in the texture path — 902 vs 667 µs on conv3_1 without them.)
 //   * patch addresses: 16 per-lane voffsets computed once (out-of-image pixels carry bit 31 → the buffer load returns 0, which
 //     IS the zero padding); the channel walk lives in the scalar offset. No per-load VALU.
@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WinoParams {
   const float* in;
   float* out;
-  const float* wd;     // [Cout/32][Cin/4][16 positions][64 lanes][2]
+  const float* wd;     // [Cout/32][Cin/8][16 positions][64 lanes][4]
   const float* bias;
   float slope;
   int Cin, Cout, H, W, TY, TX, ntiles, nb, gx, gy;
@@ -114,10 +114,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
-  const int wvo0 = lane * 8, wvo1 = lane * 8 + 4096;
+  int wvo[4];   // weights: 1 KB per position, 16 KB per block of 8 channels; immediate offsets reach 4 KB
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wvo[i] = lane * 16 + i * 4096;
   const int hw32 = p.H * p.W * 32;
   const int c8n = p.Cin >> 3;
-  const int abase = mb * p.nb;   // first body of this channel block in the packed weights (8 KB per body)
+  const int abase = mb * c8n;   // first block of 8 input channels of this channel block in the packed weights (16 KB each)
 
   f32x16 acc[16];
 #pragma unroll
@@ -126,11 +128,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
   f32x4 raw[16], T[16];        // pixels of the NEXT channel block (4 channels per lane = both bodies) and their row pass
-  f32x2 Va[16], Vb[16], Vc[16], A0[16], A1[16];   // weights of body 0 / body 1: each reloaded right behind its last use, a whole block ahead
+  f32x2 Va[16], Vb[16], Vc[16];
+  f32x4 A[16];   // weights of both bodies of a position (.xy body 0, .zw body 1): ONE 16-byte load, reloaded right behind its last use
 #define WLOADB(k, soff) \
   raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], (soff), 0));
-#define WLOADA(A, q, soff) \
-  A[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrw, ((q) < 8 ? wvo0 : wvo1) + ((q) & 7) * 512, (soff), 0));
+#define WLOADA(q, soff) \
+  A[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, wvo[(q) >> 2] + ((q) & 3) * 1024, (soff), 0));
 // row pass of B^T d B, one output per call: T[xi*4 + j] from patch column j (raw slots j*4 + i). (One call per MFMA slot: a slot
 // that carries a whole column's 16 scalar adds overruns the 64-cycle MFMA gap of the wave's only SIMD.)
 #define WROW(k)                                                                                \
@@ -163,9 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // (issue order pinned: the loop header's one s_waitcnt serves both the entry and the back edge — with the weights loaded
   // last here, as the scheduler would have it, it becomes vmcnt(0) and drains everything in flight once per trip)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) WLOADA(A0, q, abase * 8192)
-#pragma unroll
-  for (int q = 0; q < 16; ++q) WLOADA(A1, q, (abase + 1) * 8192)
+  for (int q = 0; q < 16; ++q) WLOADA(q, abase * 16384)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 16; ++k) WLOADB(k, 0)
@@ -185,11 +186,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // channel block c = two bodies of 4 channels (32 MFMAs each). Body 0 multiplies Va; body 1 multiplies X while the transform of
   // block c + 1 runs in its slots — row passes in the first 16, column passes in the last 16 (into Va, free by now, and Y), and
   // behind each row pass slot's column the 16 pixel loads of block c + 2 refill `raw` (48 slots ahead of their first use).
-  // Every A0[q] / A1[q] is reloaded for the next block right behind its last use (62 slots ahead): loads return in order, so a
-  // weight load needed soon must not queue behind a pixel load that misses to HBM — with the weights one body ahead (30 slots)
-  // the pixel loads cost 13 % (tools/wino_trace.py, ablations in profiles/r04_winograd.md). X / Y swap roles from block to block.
-#define WMFMA(A, VV, q, s_) \
-  acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) ? A[q].y : A[q].x, (s_) ? VV[q].y : VV[q].x, acc[q], 0, 0, 0); \
+  // Every A[q] (16 bytes = both bodies of position q) is reloaded for the next block right behind its last use in body 1, 32 slots
+  // ahead of its next. Wide loads, few of them: a single wave pays ~23 cycles of MFMA issue per load instruction
+  // (tools/wino_issue_probe.hip: a b64 load every other slot costs 18 %, the same bytes as a b128 every fourth slot 12 %; two
+  // v_pk_add_f32 per slot cost MORE than the four scalar adds they replace; a second wave per SIMD hides the loads, not the adds).
+  // X / Y swap roles from block to block.
+#define WMFMA(J, VV, q, s_) \
+  acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32((J) ? ((s_) ? A[q].w : A[q].z) : ((s_) ? A[q].y : A[q].x), (s_) ? VV[q].y : VV[q].x, acc[q], 0, 0, 0); \
   asm volatile("" : "+a"(acc[q]));
 // MFMA order inside a body: positions in pairs, (q0,s0) (q1,s0) (q0,s1) (q1,s1) — WINO_PAIR 0 puts the two k-steps of a
 // position back to back (an accumulator dependent on the MFMA right before it)
@@ -205,18 +208,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WTR0
 #define WTR1
 #endif
-#define WSUPER(X, Y, sb, sa0, sa1)                                                             \
+#define WSUPER(X, Y, sb, sa)                                                             \
   WTR0                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(A0, Va, WQ(sl), WS(sl))                                                              \
-    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(A0, WQ(sl), sa0) }                                 \
+    WMFMA(0, Va, WQ(sl), WS(sl))                                                               \
     if (WINO_SPLITCOL && !(WINO_ABL & 4) && sl < 16) WCOLH(X, sl, 1)   /* this block's body-1 operands, from the T left by the previous body 1 */ \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }                                                                                            \
   WTR1                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(A1, X, WQ(sl), WS(sl))                                                               \
-    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(A1, WQ(sl), sa1) }                                 \
+    WMFMA(1, X, WQ(sl), WS(sl))                                                                \
+    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa) }                                      \
     if (!(WINO_ABL & 4)) { if (sl < 16) WROW(sl) else if (WINO_SPLITCOL) WCOLH(Va, sl - 16, 0) else WCOL(Va, Y, sl - 16) } \
     if ((WINO_ABL & 16) && sl < 16) asm volatile("" :: "v"(raw[sl]));   /* dev: pixel loads kept alive without the transform */ \
     if (!(WINO_ABL & 1) && sl >= 16) { WLOADB(sl - 16, sb) }                                   \
@@ -224,15 +226,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #define WOFFS(c8)                                                                              \
   const int sb = __builtin_amdgcn_readfirstlane(min((c8) + 2, c8n - 1) * hw32); /* clamped: loads past the end re-read the last block */ \
-  const int sa0 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 2, p.nb - 2)) * 8192);  \
-  const int sa1 = __builtin_amdgcn_readfirstlane((abase + min(2 * (c8) + 3, p.nb - 1)) * 8192);
+  const int sa = __builtin_amdgcn_readfirstlane((abase + min((c8) + 1, c8n - 1)) * 16384);
 
   int c8 = 0;
   for (; c8 + 2 <= c8n; c8 += 2) {
-    { WOFFS(c8) WSUPER(Vb, Vc, sb, sa0, sa1) }
-    { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa0, sa1) }
+    { WOFFS(c8) WSUPER(Vb, Vc, sb, sa) }
+    { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa) }
   }
-  if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa0, sa1) }
+  if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa) }
 #undef WOFFS
 #undef WSUPER
 #undef WMFMA
@@ -307,17 +308,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-// U = G g G^T in double, rounded once; packed [Cout/32][body = Cin/4][position][lane = h*32 + row][s] with channel 8(body/2) + 4h + 2(body%2) + s
+// U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
 // s2d: `w` is a (Cout, Cin/4, 5, 5) stride-2 pad-2 kernel read as the 3x3 stride-1 pad-1 kernel over the 4 input phases it is
 // equivalent to — channel phase*(Cin/4) + c, phase = py*2 + px, tap (a, b) = w[2a + py][2b + px] (zero where 2a + py or 2b + px = 5)
 __global__ void pack_wino_kernel(float* __restrict__ packed, const float* __restrict__ w, int Cout, int Cin, long total, int s2d) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int s = (int)(i & 1), r = (int)((i >> 1) & 31), h = (int)((i >> 6) & 1), q = (int)((i >> 7) & 15);
-  const long bi = i >> 11;
-  const int nb = Cin >> 2;
-  const int c4 = (int)(bi % nb), mb = (int)(bi / nb);
-  const int co = mb * 32 + r, ci = (c4 >> 1) * 8 + 4 * h + 2 * (c4 & 1) + s;
+  const int s = (int)(i & 3), r = (int)((i >> 2) & 31), h = (int)((i >> 7) & 1), q = (int)((i >> 8) & 15);
+  const long bi = i >> 12;
+  const int c8n = Cin >> 3;
+  const int c8 = (int)(bi % c8n), mb = (int)(bi / c8n);
+  const int co = mb * 32 + r, ci = c8 * 8 + 4 * h + s;
   const int xi = q >> 2, nu = q & 3;
   const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   double u = 0;
@@ -409,7 +410,7 @@ extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const flo
   p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
-  p.nb = Cin / 4;
+  p.nb = Cin / 8;
   p.gx = di_div_up(p.ntiles, 128);
   p.gy = Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;

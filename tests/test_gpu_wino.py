@@ -72,13 +72,13 @@ def test_wino_weight_transform_is_G_g_Gt(ctx):
     rng = np.random.default_rng(5)
     cout, cin = 32, 16
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
-    pk = _pack(ctx, w).asnumpy().reshape(cout // 32, cin // 4, 16, 2, 32, 2)     # [mb][c4][pos][h][row][s]
+    pk = _pack(ctx, w).asnumpy().reshape(cout // 32, cin // 8, 16, 2, 32, 4)     # [mb][c8][pos][h][row][s]
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum("xa,ocab,nb->ocxn", G, w.astype(np.float64), G).astype(np.float32)   # (cout, cin, 4, 4)
-    for c4 in range(cin // 4):
+    for c8 in range(cin // 8):
         for h in range(2):
-            for s in range(2):
-                np.testing.assert_array_equal(pk[0, c4, :, h, :, s], U[:, (c4 // 2) * 8 + 4 * h + 2 * (c4 % 2) + s].reshape(cout, 16).T)
+            for s in range(4):
+                np.testing.assert_array_equal(pk[0, c8, :, h, :, s], U[:, c8 * 8 + 4 * h + s].reshape(cout, 16).T)
 
 
 def test_wino_argument_checks(ctx):
