@@ -308,6 +308,215 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two waves per SIMD (deepim_set_option "wino_two_wave" = 1; NOT the default). The same algorithm with the sixteen positions of a
+// (32 channels x 32 tiles) tile split over TWO waves — "top": xi = 0, 1 (patch rows 0..2), "bottom": xi = 2, 3 (rows 1..3) —
+// 8 accumulators = 128 AGPRs + 128 VGPRs each, so that two waves share a SIMD and one wave's loads, waits, prologue and epilogue
+// run under the other's MFMAs (tools/wino_issue_probe.hip: a second wave hides the load issue a single wave pays for). Measured:
+// each half loads 3 of the 4 patch rows and its own weights, 28 loads per 32 MFMAs instead of 32 per 64, and that costs more than
+// the overlap gains — conv3_1 0.92 vs 0.75 ms, conv4_1 0.83 vs 0.71 at B = 32 (0.84 with the same bytes on contiguous addresses:
+// the texture path); it wins only where the one-wave grid is between one and two rounds (conv5_1 at B = 32: 0.27 vs 0.31 ms).
+// Block = 4 waves = 2 tile groups x (top, bottom) on 32 channels x 64 tiles, two blocks per CU. Both halves run the same stream:
+// with (f0, f1, f2) = patch rows (0, 1, 2) / (2, 3, 1) and sgn = +1 / -1 the row pass is Ta = f0 - f2, Tb = fma(f1, sgn, f2)
+// (= d0 - d2, d1 + d2 / d2 - d1, d1 - d3); only the row each load slot addresses differs. The output transform needs the other
+// half's two partial rows: bottom waves hand them over through 16 KB of LDS per tile group, top waves finish and store.
+template <int OUT_NC8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino2_kernel(WinoParams p) {
+  __shared__ float xch[2][64][64];   // [tile group][value][lane]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 1, grp = wave & 1;
+  const int lrow = lane >> 5, lcol = lane & 31;
+  int mb, bx;
+  {
+    const int bid = blockIdx.x;
+    if ((p.gy & 7) == 0) {
+      const int per = p.gy >> 3, xcd = bid & 7, idx = bid >> 3;
+      mb = xcd * per + idx % per;
+      bx = idx / per;
+    } else {
+      mb = bid % p.gy;
+      bx = bid / p.gy;
+    }
+  }
+  const int t = bx * 64 + grp * 32 + lcol;
+  const int tpi = p.TY * p.TX;
+  const bool tvalid = t < p.ntiles;
+  const int n = tvalid ? t / tpi : 0;
+  const int tr = tvalid ? t - n * tpi : 0;
+  const int ty = tr / p.TX, tx = tr - ty * p.TX;
+
+  // load slot k = j*3 + e: patch column j, row operand f_e of this half
+  int voff[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int j = k / 3, e = k - 3 * j;
+    const int i = half ? (e == 0 ? 2 : e == 1 ? 3 : 1) : e;
+    const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+    const bool ok = tvalid && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    voff[k] = ok ? (((n * (p.Cin >> 3)) * p.H + y) * p.W + x) * 32 + lrow * 16 : (int)0x80000000;
+    if (WINO_ABL & 8) {   // dev: same bytes per load, the wave's 64 lanes on two contiguous 512-byte runs (wrong results)
+      const int t0 = min(bx * 64 + grp * 32, p.ntiles - 32);
+      const int n0 = t0 / tpi, r0 = t0 - n0 * tpi, ty0 = r0 / p.TX, tx0 = r0 - ty0 * p.TX;
+      const int y0 = min(max(2 * ty0 - 1 + i, 0), p.H - 2), x0 = min(max(2 * tx0 - 1 + j, 0), p.W - 1);
+      voff[k] = (((n0 * (p.Cin >> 3)) * p.H + y0) * p.W + x0) * 32 + lcol * 16 + lrow * 512;
+    }
+  }
+  const float sgn = half ? -1.f : 1.f;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
+  int wvo[2];   // this half's 8 positions: 1 KB each (16 bytes per lane, body 0 in the first 8)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wvo[i] = lane * 16 + half * 8192 + i * 4096;
+  const int hw32 = p.H * p.W * 32;
+  const int c8n = p.Cin >> 3;
+  const int abase = mb * c8n;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  f32x4 raw[12], T[8];
+  f32x2 Va[8], Vb[8], Vc[8], A[8];   // A: ONE body's weights, reloaded for the next body right behind its last use
+#define W2LOADB(k, soff) \
+  raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[k], (soff), 0));
+#define W2LOADA(q, soff, body) \
+  A[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrw, wvo[(q) >> 2] + ((q) & 3) * 1024 + (body) * 8, (soff), 0));
+// row pass, one output per call: o = j*2 + which -> T[which*4 + j]
+#define W2ROW(o)                                                                               \
+  {                                                                                            \
+    const int j_ = (o) >> 1;                                                                   \
+    const f32x4 f0 = raw[j_ * 3 + 0], f1 = raw[j_ * 3 + 1], f2 = raw[j_ * 3 + 2];              \
+    if ((o) & 1) { f32x4 r_; r_.x = __builtin_fmaf(f1.x, sgn, f2.x); r_.y = __builtin_fmaf(f1.y, sgn, f2.y);                  \
+                   r_.z = __builtin_fmaf(f1.z, sgn, f2.z); r_.w = __builtin_fmaf(f1.w, sgn, f2.w); T[4 + j_] = r_; }         \
+    else T[j_] = wsub(f0, f2);                                                                 \
+  }
+#define W2COL(V0_, V1_, k)                                                                     \
+  {                                                                                            \
+    const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
+    const f32x4 t0 = T[x_ * 4 + 0], t1 = T[x_ * 4 + 1], t2 = T[x_ * 4 + 2], t3 = T[x_ * 4 + 3]; \
+    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3); \
+    V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
+  }
+#define W2MFMA(VV, q, s_) \
+  acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) ? A[q].y : A[q].x, (s_) ? VV[q].y : VV[q].x, acc[q], 0, 0, 0); \
+  asm volatile("" : "+a"(acc[q]));
+
+#pragma unroll
+  for (int q = 0; q < 8; ++q) W2LOADA(q, abase * 16384, 0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) W2LOADB(k, 0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 8; ++o) W2ROW(o)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) W2COL(Va, Vb, k)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // block c: body 0 multiplies Va (weights .xy) and receives the 12 pixel loads of block c + 1; body 1 multiplies X (weights .zw)
+  // while the transform of block c + 1 runs in its slots (8 row passes, 8 column passes into Va and Y)
+#define W2SUPER(X, Y, sb, sa, san)                                                             \
+  _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) {                                          \
+    W2MFMA(Va, WQ(sl), WS(sl))                                                                 \
+    if (sl < 12) { W2LOADB(sl, sb) }                                                           \
+    if (WS(sl)) { W2LOADA(WQ(sl), sa, 1) }                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }                                                                                            \
+  _Pragma("unroll") for (int sl = 0; sl < 16; ++sl) {                                          \
+    W2MFMA(X, WQ(sl), WS(sl))                                                                  \
+    if (WS(sl)) { W2LOADA(WQ(sl), san, 0) }                                                    \
+    if (sl < 8) W2ROW(sl) else W2COL(Va, Y, sl - 8)                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  }
+#define W2OFFS(c8)                                                                             \
+  const int sb = __builtin_amdgcn_readfirstlane(min((c8) + 1, c8n - 1) * hw32);                \
+  const int sa = __builtin_amdgcn_readfirstlane((abase + (c8)) * 16384);                       \
+  const int san = __builtin_amdgcn_readfirstlane((abase + min((c8) + 1, c8n - 1)) * 16384);
+  int c8 = 0;
+  for (; c8 + 2 <= c8n; c8 += 2) {
+    { W2OFFS(c8) W2SUPER(Vb, Vc, sb, sa, san) }
+    { W2OFFS(c8 + 1) W2SUPER(Vc, Vb, sb, sa, san) }
+  }
+  if (c8 < c8n) { W2OFFS(c8) W2SUPER(Vb, Vc, sb, sa, san) }
+#undef W2OFFS
+#undef W2SUPER
+#undef W2MFMA
+#undef W2COL
+#undef W2ROW
+#undef W2LOADA
+#undef W2LOADB
+
+  // output transform. This half's partial rows per accumulator row r: sA[b], sB[b] from its xi = 0 / 1 (top: s0, s1; bottom: s2, s3)
+  // Y[0][b] = (s0 + s1) + s2, Y[1][b] = s1 + (-s2 - s3): bottom hands {s2, -s2 - s3} over, top adds and stores.
+  float* xl = &xch[grp][0][lane];
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float a0 = acc[0][r], a1 = acc[1][r], a2 = acc[2][r], a3 = acc[3][r];
+        const float c0 = acc[4][r], c1 = acc[5][r], c2 = acc[6][r], c3 = acc[7][r];
+        const float sA = b == 0 ? (a0 + a1) + a2 : (a1 - a2) - a3;
+        const float sB = b == 0 ? (c0 + c1) + c2 : (c1 - c2) - c3;
+        xl[(r * 4 + b) * 64] = sA;
+        xl[(r * 4 + 2 + b) * 64] = -sA - sB;
+      }
+    }
+  }
+  __syncthreads();
+  if (half || !tvalid) return;
+  const int y0 = 2 * ty, x0 = 2 * tx;
+  const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+  float4 bq[4];
+  int mbe = mb;
+  asm volatile("" : "+s"(mbe));
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    bq[g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + mbe * 32 + 8 * g + 4 * lrow) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float o[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      const float bv = e == 0 ? bq[g].x : e == 1 ? bq[g].y : e == 2 ? bq[g].z : bq[g].w;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float a0 = acc[0][r], a1 = acc[1][r], a2 = acc[2][r], a3 = acc[3][r];
+        const float c0 = acc[4][r], c1 = acc[5][r], c2 = acc[6][r], c3 = acc[7][r];
+        const float sA = b == 0 ? (a0 + a1) + a2 : (a1 - a2) - a3;
+        const float sB = b == 0 ? (c0 + c1) + c2 : (c1 - c2) - c3;
+        float v0 = ((sA + sB) + xl[(r * 4 + b) * 64]) + bv;
+        float v1 = (sB + xl[(r * 4 + 2 + b) * 64]) + bv;
+        o[0 * 2 + b][e] = v0 > 0.f ? v0 : v0 * p.slope;
+        o[1 * 2 + b][e] = v1 > 0.f ? v1 : v1 * p.slope;
+      }
+    }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const int a = ab >> 1, b = ab & 1;
+      if ((a && !y1ok) || (b && !x1ok)) continue;
+      const long pix = (long)(y0 + a) * p.W + x0 + b;
+      if (OUT_NC8) {
+        long rec;
+        if (p.out_s2d)
+          rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * p.TX) + ty * p.TX + tx;
+        else
+          rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;
+        *reinterpret_cast<float4*>(p.out + rec * 8 + 4 * lrow) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]);
+      } else {
+        const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p.out[(c0 + e) * p.H * p.W + pix] = o[ab][e];
+      }
+    }
+  }
+}
+
 // U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
 // s2d: `w` is a (Cout, Cin/4, 5, 5) stride-2 pad-2 kernel read as the 3x3 stride-1 pad-1 kernel over the 4 input phases it is
 // equivalent to — channel phase*(Cin/4) + c, phase = py*2 + px, tap (a, b) = w[2a + py][2b + px] (zero where 2a + py or 2b + px = 5)
@@ -411,7 +620,8 @@ extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const flo
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
   p.nb = Cin / 8;
-  p.gx = di_div_up(p.ntiles, 128);
+  const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
+  p.gx = di_div_up(p.ntiles, two_wave ? 64 : 128);
   p.gy = Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
@@ -419,8 +629,13 @@ extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const flo
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   const int grid = p.gx * p.gy;
-  if (out_nc8) conv_wino_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
-  else conv_wino_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
+  if (two_wave) {
+    if (out_nc8) conv_wino2_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
+    else conv_wino2_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
+  } else {
+    if (out_nc8) conv_wino_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
+    else conv_wino_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
+  }
   DI_LAUNCH_CHECK();
   return 0;
 }

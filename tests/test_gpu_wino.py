@@ -13,6 +13,14 @@ cf = ctypes.c_float
 TOL = 1e-5
 
 
+@pytest.fixture(params=[0, 1], ids=["one_wave_per_simd", "two_waves_per_simd"], autouse=True)
+def wino_kernel(ctx, request):
+    """Every test on both kernels: the default (one 16-position wave per SIMD) and the optional two-wave form."""
+    lib.deepim_set_option(ctx.handle, b"wino_two_wave", request.param)
+    yield request.param
+    lib.deepim_set_option(ctx.handle, b"wino_two_wave", 0)
+
+
 def _to_nc8(x):
     B, C, H, W = x.shape
     return np.ascontiguousarray(x.reshape(B, C // 8, 8, H, W).transpose(0, 1, 3, 4, 2))

@@ -24,21 +24,23 @@ for name, cin, H, W, cout in LAYERS:
     out8 = 0 if name == "conv6_1" else 1
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x, pk, bias, B, cin, H, W, cout, 3, 3, 1, 1, cf(0.1), 0, 0, 1, out8)
     wino = lambda: lib.deepim_conv2d_wino_forward(ctx.handle, o2, x, pw, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
+    def wino1():
+        lib.deepim_set_option(ctx.handle, b"wino_two_wave", 1); wino(); lib.deepim_set_option(ctx.handle, b"wino_two_wave", 0)
     direct(); wino()
     a, b = o1.asnumpy(), o2.asnumpy()
     err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
-    td, tw = [], []
+    td, tw, t1 = [], [], []
     for r in range(ROUNDS):
-        for fn, acc in ((direct, td), (wino, tw)):
+        for fn, acc in ((direct, td), (wino, tw), (wino1, t1)):
             fn()
             t = ctx.timer(); t.start()
             for _ in range(REPS):
                 fn()
             t.stop()
             acc.append(t.elapsed_ms() / REPS)
-    d, wv = float(np.median(td)), float(np.median(tw))
+    d, wv, w1 = float(np.median(td)), float(np.median(tw)), float(np.median(t1))
     fl = 2.0 * cout * cin * 9 * H * W * B
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
     fle = 2.0 * cout * cin * 16 * tiles
-    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range"
-          % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err))
+    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range | two-wave kernel %.3f ms"
+          % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err, w1))
