@@ -306,6 +306,10 @@ int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float*
  * the layer's own (Cout, Cin, 5, 5) weights for it (size: deepim_conv_wino_packed_size(Cout, 4*Cin)), and the layer runs as
  * deepim_conv2d_wino_forward(ctx, out, in_s2d, packed, bias, B, 4*Cin, H/2, W/2, Cout, ...). 1.56x fewer multiplies than direct. */
 int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,5,5 dev*/, int Cout, int Cin);
+/* the stride-2 layer in one call: (B, Cin, H, W) input given in its space-to-depth NC8 form, output (B, Cout, H/2, W/2); the positions
+ * whose transformed weights are identically zero (third kernel row / column of the odd input phases) are skipped: 49 of 64 MFMAs */
+int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const float* in_s2d, const float* packed_w, const float* bias,
+                                   int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
 int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float* src, int B, int C, int H, int W, int to_s2d);
 int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
                                int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);

@@ -68,7 +68,12 @@ __device__ unsigned long long* g_wino_trace = nullptr;
 #define WTR_STAMP(dst) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0" : "=s"(dst) : "s"(tr_prev) : "memory"); 
 #endif
 
-template <int OUT_NC8>
+// S2D: the input is the space-to-depth form of a stride-2 layer's input and the weights come from deepim_conv_wino_pack_weights_s2d:
+// the channels of input phase (py, px) — a quarter of Cin each, in the order (0,0) (0,1) (1,0) (1,1) — carry a 3x3 kernel whose
+// third row (py = 1) / column (px = 1) is zero, so U[xi = 3][.] / U[.][nu = 3] vanish identically for them: the K loop runs phase by
+// phase and skips those positions' MFMAs, weight loads, transform adds and the patch pixels only they read — 49 of 64
+// (position, phase) pairs are left, the skipped terms are exact zeros.
+template <int OUT_NC8, int S2D = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(WinoParams p) {
 #if WINO_TRACE
   const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
@@ -150,17 +155,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3); \
     V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
   }
-// the two halves of the column pass on their own (WINO_SPLITCOL): .xy in body 1, .zw in the first slots of the next block's body 0
-#define WCOLH(V_, k, HI)                                                                       \
-  {                                                                                            \
-    const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
-    const f32x2 t0 = (HI) ? T[x_ * 4 + 0].zw : T[x_ * 4 + 0].xy, t1 = (HI) ? T[x_ * 4 + 1].zw : T[x_ * 4 + 1].xy; \
-    const f32x2 t2 = (HI) ? T[x_ * 4 + 2].zw : T[x_ * 4 + 2].xy, t3 = (HI) ? T[x_ * 4 + 3].zw : T[x_ * 4 + 3].xy; \
-    V_[k] = w_ == 0 ? t0 - t2 : w_ == 1 ? t1 + t2 : w_ == 2 ? t2 - t1 : t1 - t3;              \
-  }
-#ifndef WINO_SPLITCOL
-#define WINO_SPLITCOL 0   // measured: 0.787 vs 0.770 ms on conv3_1 — the cost is per VALU instruction beside the MFMAs, not per crowded slot
-#endif
 
   // prologue: weights of bodies 0 and 1, pixels of channel block 0 -> V of both its bodies, then the pixels of block 1
   // (issue order pinned: the loop header's one s_waitcnt serves both the entry and the back edge — with the weights loaded
@@ -208,20 +202,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define WTR0
 #define WTR1
 #endif
-#define WSUPER(X, Y, sb, sa)                                                             \
+// phase masks: P < 0 = every position; else py = P >> 1, px = P & 1
+#define WACT(P, q) ((P) < 0 || !((((P) >> 1) && ((q) >> 2) == 3) || (((P) & 1) && ((q) & 3) == 3)))   /* position q = xi*4 + nu */
+#define WPIX(P, k) ((P) < 0 || !((((P) >> 1) && ((k) & 3) == 3) || (((P) & 1) && ((k) >> 2) == 3)))   /* patch slot k = j*4 + i */
+// PC: phase of the block being multiplied; PN: of the next block (its transform and weight loads run here); PB: of the block
+// after that (its pixel loads are issued here)
+#define WSUPER(X, Y, sb, sa, PC, PN, PB)                                                       \
   WTR0                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(0, Va, WQ(sl), WS(sl))                                                               \
-    if (WINO_SPLITCOL && !(WINO_ABL & 4) && sl < 16) WCOLH(X, sl, 1)   /* this block's body-1 operands, from the T left by the previous body 1 */ \
+    if (WACT(PC, WQ(sl))) { WMFMA(0, Va, WQ(sl), WS(sl)) }                                     \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }                                                                                            \
   WTR1                                                                                         \
   _Pragma("unroll") for (int sl = 0; sl < 32; ++sl) {                                          \
-    WMFMA(1, X, WQ(sl), WS(sl))                                                                \
-    if (!(WINO_ABL & 2) && WS(sl)) { WLOADA(WQ(sl), sa) }                                      \
-    if (!(WINO_ABL & 4)) { if (sl < 16) WROW(sl) else if (WINO_SPLITCOL) WCOLH(Va, sl - 16, 0) else WCOL(Va, Y, sl - 16) } \
+    if (WACT(PC, WQ(sl))) { WMFMA(1, X, WQ(sl), WS(sl)) }                                      \
+    if (!(WINO_ABL & 2) && WS(sl) && WACT(PN, WQ(sl))) { WLOADA(WQ(sl), sa) }                  \
+    if (!(WINO_ABL & 4)) {                                                                     \
+      if (sl < 16) { if (WPIX(PN, ((sl) >> 2) * 4 + 0) && WACT(PN, ((sl) & 3) * 4)) WROW(sl) } /* row op sl: column sl/4, xi = sl%4 */ \
+      else if (WACT(PN, sl - 16)) WCOL(Va, Y, sl - 16)                                         \
+    }                                                                                          \
     if ((WINO_ABL & 16) && sl < 16) asm volatile("" :: "v"(raw[sl]));   /* dev: pixel loads kept alive without the transform */ \
-    if (!(WINO_ABL & 1) && sl >= 16) { WLOADB(sl - 16, sb) }                                   \
+    if (!(WINO_ABL & 1) && sl >= 16 && WPIX(PB, sl - 16)) { WLOADB(sl - 16, sb) }              \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }
 #define WOFFS(c8)                                                                              \
@@ -229,16 +230,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int sa = __builtin_amdgcn_readfirstlane((abase + min((c8) + 1, c8n - 1)) * 16384);
 
   int c8 = 0;
-  for (; c8 + 2 <= c8n; c8 += 2) {
-    { WOFFS(c8) WSUPER(Vb, Vc, sb, sa) }
-    { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa) }
+  if (!S2D) {
+    for (; c8 + 2 <= c8n; c8 += 2) {
+      { WOFFS(c8) WSUPER(Vb, Vc, sb, sa, -1, -1, -1) }
+      { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa, -1, -1, -1) }
+    }
+    if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa, -1, -1, -1) }
+  } else {
+    // four phases of c8n / 4 blocks each (an even number: the launcher checks); the last two blocks of a phase prepare the next one's
+    const int npb = c8n >> 2;
+#define WPHASE(PH, NX)                                                                         \
+    for (const int e_ = ((PH) + 1) * npb - 2; c8 < e_; c8 += 2) {                              \
+      { WOFFS(c8) WSUPER(Vb, Vc, sb, sa, PH, PH, PH) }                                         \
+      { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa, PH, PH, PH) }                                     \
+    }                                                                                          \
+    { WOFFS(c8) WSUPER(Vb, Vc, sb, sa, PH, PH, NX) }                                           \
+    { WOFFS(c8 + 1) WSUPER(Vc, Vb, sb, sa, PH, NX, NX) }                                       \
+    c8 += 2;
+    WPHASE(0, 1) WPHASE(1, 2) WPHASE(2, 3) WPHASE(3, -1)
+#undef WPHASE
   }
-  if (c8 < c8n) { WOFFS(c8) WSUPER(Vb, Vc, sb, sa) }
 #undef WOFFS
 #undef WSUPER
+#undef WACT
+#undef WPIX
 #undef WMFMA
 #undef WCOL
-#undef WCOLH
 #undef WROW
 #undef WLOADA
 #undef WLOADB
@@ -605,9 +622,8 @@ extern "C" int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_
 // 3x3, stride 1, pad 1 convolution + bias + LeakyReLU(slope) from channel-blocked `in` (B, Cin/8, H, W, 8) into channel-blocked
 // `out` (out_nc8 = 1; 3 = channel-blocked in space-to-depth order, what a stride-2 layer on this kernel reads) or into channels
 // [out_coff, out_coff + Cout) of an NCHW tensor of out_ctotal channels (out_nc8 = 0).
-extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
-                                          int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal,
-                                          int out_coff) {
+static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B, int Cin,
+                             int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff, bool s2d) {
   DI_DEVICE(ctx);
   DI_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d_wino_forward: bad shape");
   DI_REQUIRE((Cout & 31) == 0 && (Cin & 7) == 0, "conv2d_wino_forward: Cout % 32 == 0 and Cin % 8 == 0 required");
@@ -629,15 +645,36 @@ extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const flo
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   const int grid = p.gx * p.gy;
+  // phase-by-phase K loop with the zero positions skipped: needs an even number of 8-channel blocks per input phase
+  const bool phases = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
   if (two_wave) {
     if (out_nc8) conv_wino2_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
     else conv_wino2_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
+  } else if (phases) {
+    if (out_nc8) conv_wino_kernel<1, 1><<<grid, 256, 0, ctx->stream>>>(p);
+    else conv_wino_kernel<0, 1><<<grid, 256, 0, ctx->stream>>>(p);
   } else {
     if (out_nc8) conv_wino_kernel<1><<<grid, 256, 0, ctx->stream>>>(p);
     else conv_wino_kernel<0><<<grid, 256, 0, ctx->stream>>>(p);
   }
   DI_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
+                                          int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal,
+                                          int out_coff) {
+  return wino_forward_impl(ctx, out, in, packed_w, bias, B, Cin, H, W, Cout, slope, out_nc8, out_ctotal, out_coff, false);
+}
+
+// The 5x5 stride-2 pad-2 layer itself: `in` = the space-to-depth NC8 form (B, 4 Cin, H/2, W/2) of its (B, Cin, H, W) input, packed_w
+// from deepim_conv_wino_pack_weights_s2d, output (B, Cout, H/2, W/2). Same kernel as deepim_conv2d_wino_forward on (4 Cin, H/2, W/2),
+// with the positions whose transformed weights are identically zero skipped (bit-identical results, 49 of 64 MFMAs).
+extern "C" int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const float* in_s2d, const float* packed_w, const float* bias,
+                                              int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal,
+                                              int out_coff) {
+  DI_REQUIRE(H > 0 && W > 0 && ((H | W) & 1) == 0, "conv2d_wino_forward_s2d: even H and W required");
+  return wino_forward_impl(ctx, out, in_s2d, packed_w, bias, B, 4 * Cin, H / 2, W / 2, Cout, slope, out_nc8, out_ctotal, out_coff, true);
 }
 
 #if WINO_TRACE

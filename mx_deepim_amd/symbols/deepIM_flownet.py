@@ -499,10 +499,9 @@ class deepIM_flownet(object):
         name, cin, h, w, cout, k, s, p = self.enc_geom[li]
         out_mode = self._enc_out_mode(li)
         if self.nc8 and name in self.packed_wino:
-            if name in self.wino_s2d:      # 5x5 stride 2 over the space-to-depth tensor the previous layer wrote
-                cin, h, w = 4 * cin, h // 2, w // 2
-            lib.deepim_conv2d_wino_forward(self.ctx.handle, self.act[name], src, self.packed_wino[name], self.params[name + "_bias"],
-                                           self.B, cin, h, w, cout, ctypes.c_float(SLOPE), out_mode, 0, 0)
+            fwd = lib.deepim_conv2d_wino_forward_s2d if name in self.wino_s2d else lib.deepim_conv2d_wino_forward
+            fwd(self.ctx.handle, self.act[name], src, self.packed_wino[name], self.params[name + "_bias"],      # s2d: 5x5 stride 2 over
+                self.B, cin, h, w, cout, ctypes.c_float(SLOPE), out_mode, 0, 0)                                  # the space-to-depth tensor
         elif self.nc8:
             in8 = 1 if (li > 0 or src.shape == (self.B, self.H, self.W, 8)) else 0     # conv1: NC8 records from the zoom front end
             lib.deepim_conv2d_forward_ex(self.ctx.handle, self.act[name], src, self.packed[name], self.params[name + "_bias"],

@@ -104,6 +104,7 @@ S2D_CASES = [
     (1, 128, 12, 16, 256),     # conv3 channels
     (3, 8, 6, 10, 32),         # one channel block per phase
     (1, 16, 2, 2, 64),         # a single output pixel row / column pair: every tap but the centre ones in the padding
+    (2, 32, 10, 14, 96),       # four blocks of 8 channels per phase: the phase loops run their steady-state bodies
 ]
 
 
@@ -133,6 +134,18 @@ def test_wino_stride2_5x5_layer_over_space_to_depth_input(ctx, case):
     got = _from_nc8(out.asnumpy(), (B, cout, Ho, Wo))
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(got - ref).max() <= TOL * scale, np.abs(got - ref).max() / scale
+    # the layer's own entry: same kernel with the identically-zero positions of the odd phases skipped (Cin % 16 == 0; otherwise the
+    # full loop) — the skipped terms are exact zeros, so the results are the same bits
+    out_s = ctx.zeros((B, cout, Ho, Wo))
+    lib.deepim_conv2d_wino_forward_s2d(ctx.handle, out_s, xs, pk, ctx.array(b), B, cin, H, W, cout, cf(0.1), 1, 0, 0)
+    np.testing.assert_array_equal(_from_nc8(out_s.asnumpy(), (B, cout, Ho, Wo)), got)
+    lib.deepim_set_option(ctx.handle, b"wino_s2d_skip", 0)
+    try:
+        out_f = ctx.zeros((B, cout, Ho, Wo))
+        lib.deepim_conv2d_wino_forward_s2d(ctx.handle, out_f, xs, pk, ctx.array(b), B, cin, H, W, cout, cf(0.1), 0, 0, 0)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"wino_s2d_skip", 1)
+    np.testing.assert_array_equal(out_f.asnumpy(), got)
     if Ho % 2 == 0 and Wo % 2 == 0:
         out2 = ctx.zeros((B, cout, Ho, Wo))
         lib.deepim_conv2d_wino_forward(ctx.handle, out2, xs, pk, ctx.array(b), B, 4 * cin, Ho, Wo, cout, cf(0.1), 3, 0, 0)

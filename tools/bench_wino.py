@@ -44,3 +44,40 @@ for name, cin, H, W, cout in LAYERS:
     fle = 2.0 * cout * cin * 16 * tiles
     print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range | two-wave kernel %.3f ms"
           % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err, w1))
+# the 5x5 stride-2 layers: direct NC8 kernel vs the Winograd kernel over the space-to-depth input (zero positions skipped / not skipped)
+for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 160, 256)]:
+    n = B * cin * H * W
+    xn = ctx.array(np.resize(rng.standard_normal(min(n, 1 << 24)).astype(np.float32), n).reshape(B, cin, H, W))
+    x8, xs = ctx.empty((B, cin, H, W)), ctx.empty((B, 4 * cin, H // 2, W // 2))
+    lib.deepim_relayout_nc8(ctx.handle, x8, xn, B, cin, H * W, 1)
+    lib.deepim_relayout_nc8_s2d(ctx.handle, xs, xn, B, cin, H, W, 1)
+    del xn
+    w = (rng.standard_normal((cout, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    wd = ctx.array(w)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_packed_size(cout, cin, 5, 5) // 4,))
+    lib.deepim_conv_pack_weights(ctx.handle, pk, wd, cout, cin, 5, 5)
+    pw = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, 4 * cin) // 4,))
+    lib.deepim_conv_wino_pack_weights_s2d(ctx.handle, pw, wd, cout, cin)
+    bias = ctx.array(rng.standard_normal(cout).astype(np.float32))
+    Ho, Wo = H // 2, W // 2
+    o1, o2 = ctx.empty((B, cout, Ho, Wo)), ctx.empty((B, cout, Ho, Wo))
+    direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x8, pk, bias, B, cin, H, W, cout, 5, 5, 2, 2, cf(0.1), 0, 0, 1, 1)
+    wino = lambda: lib.deepim_conv2d_wino_forward_s2d(ctx.handle, o2, xs, pw, bias, B, cin, H, W, cout, cf(0.1), 1, 0, 0)
+    def wino_full():
+        lib.deepim_set_option(ctx.handle, b"wino_s2d_skip", 0); wino(); lib.deepim_set_option(ctx.handle, b"wino_s2d_skip", 1)
+    direct(); wino()
+    a, b = o1.asnumpy(), o2.asnumpy()
+    err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
+    ts = {}
+    for r in range(ROUNDS):
+        for key, fn in (("direct", direct), ("wino", wino), ("full", wino_full)):
+            fn()
+            t = ctx.timer(); t.start()
+            for _ in range(REPS):
+                fn()
+            t.stop()
+            ts.setdefault(key, []).append(t.elapsed_ms() / REPS)
+    d, wv, wf = (float(np.median(ts[k])) for k in ("direct", "wino", "full"))
+    fl = 2.0 * cout * cin * 25 * Ho * Wo * B
+    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd over space-to-depth %.3f ms  %5.1f TF algorithmic | x%.2f | max diff %.1e of range | all 16 positions %.3f ms"
+          % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, d / wv, err, wf))
