@@ -67,8 +67,9 @@ def test_layer_selection_rule():
         return s | {n for n, (ci, h, w, co) in k5.items() if L.deepim_conv_wino_preferred_s2d(None, B, ci, h, w, co)}
     assert chosen(32) == set(k3) | set(k5)
     assert chosen(16) == {"conv2", "conv3", "conv3_1", "conv4_1", "conv5_1"}
-    assert chosen(8) == {"conv2", "conv3_1", "conv4_1"}
-    assert chosen(4) == {"conv3_1", "conv4_1"}
+    assert chosen(8) == {"conv2", "conv3", "conv3_1", "conv4_1"}
+    assert chosen(4) == {"conv2", "conv3", "conv3_1", "conv4_1"}
+    assert chosen(2) == {"conv2", "conv3_1"}
     assert chosen(1) == set()
     assert not L.deepim_conv_wino_preferred(None, 32, 12, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 32, 256, 60, 80, 48)
     assert not L.deepim_conv_wino_preferred_s2d(None, 32, 64, 241, 320, 128)          # odd height: no space-to-depth form
