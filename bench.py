@@ -57,8 +57,10 @@ def encoder_executed_flops_per_pair(net):
     for name, cin, h, w, cout, k, s, p in net.enc_geom:
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         if name in getattr(net, "packed_wino", {}):
-            c_eff = 4 * cin if name in getattr(net, "wino_s2d", ()) else cin     # stride 2: the four input phases as channels
-            total += 2 * cout * c_eff * 16 * ((ho + 1) // 2) * ((wo + 1) // 2)
+            pos_ch = 16 * cin
+            if name in getattr(net, "wino_s2d", ()):     # stride 2: the four input phases as channels; with Cin % 16 == 0 the kernel
+                pos_ch = (49 if cin % 16 == 0 else 64) * cin   # skips the identically-zero positions: 16 + 12 + 12 + 9 of 4 x 16
+            total += 2 * cout * pos_ch * ((ho + 1) // 2) * ((wo + 1) // 2)
         else:
             total += 2 * cout * cin * k * k * ho * wo
     return total
