@@ -62,7 +62,10 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * geometry, time a few split-K factors and keep the fastest (plans then depend on timing noise). "conv_tile256": 1 = 256x128 tiles on 512-thread blocks when
  * Cout % 256 == 0 (default 0: measured no faster than 128x128). "wgrad_lds": 1 (default) = LDS-staged weight-gradient kernel
  * (and the few-filter stream kernel for Cout <= 4), 0 = the round-2 register-fed kernel; "dgrad_group": 1 (default) = the four
- * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). Unknown names fail. */
+ * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). "wino_two_wave": 0 (default) =
+ * the Winograd layers on the one-wave-per-SIMD kernel (16 positions per wave), 1 = the two-wave form (8 positions per wave, LDS
+ * hand-over; measured slower on the big layers); "wino_s2d_skip": 1 (default) = deepim_conv2d_wino_forward_s2d skips the positions
+ * whose transformed weights are identically zero, 0 = runs all 16 (same bits; A/B measurements). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */

@@ -33,7 +33,7 @@ struct WinoParams {
   const float* wd;     // [Cout/32][Cin/8][16 positions][64 lanes][4]
   const float* bias;
   float slope;
-  int Cin, Cout, H, W, TY, TX, ntiles, nb, gx, gy;
+  int Cin, Cout, H, W, TY, TX, ntiles, gx, gy;
   unsigned in_bytes, wd_bytes;
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
@@ -634,7 +634,6 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
-  p.nb = Cin / 8;
   const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
   p.gx = di_div_up(p.ntiles, two_wave ? 64 : 128);
   p.gy = Cout / 32;
