@@ -1,6 +1,6 @@
 # short closed-loop runs over per-GPU batch sizes (the shards of a strong-scaling run): value, Winograd layers bound, parity
 cd /root/repo
-for B in 1 2 3 8 16; do
+for B in ${BATCHES:-1 2 3 4 8 16}; do
   timeout 150 python bench.py --batch $B --no-cpu-baseline --no-other-configs --steps 8 --warmup 2 --verify 1 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=j.get('parity') or {}
