@@ -372,3 +372,29 @@ def test_cpu_baseline_follows_the_stated_protocol():
     assert "1 untimed warm-up" in r["protocol"] and "2 timed" in r["protocol"]
     from oracle import net as onet
     assert onet.BLOCKED is False            # the timing switch is reset: the checker stays the checker
+
+
+def test_bench_executed_flops_count_what_the_winograd_layers_run():
+    """bench.py's `roofline.executed`: 16 positions per 2x2 tile and channel pair on the 3x3 Winograd layers, 49 of the 64 (position,
+    phase) pairs on the stride-2 ones (Cin % 16 == 0), 9 / 25 / 49 taps per output on the direct layers."""
+    import bench
+    from mx_deepim_amd.symbols.deepIM_flownet import ENCODER
+
+    class Net(object):
+        pass
+    net = Net()
+    net.enc_geom, h, w, cin = [], 480, 640, 8
+    for name, cout, k, s, p in ENCODER:
+        net.enc_geom.append((name, cin, h, w, cout, k, s, p))
+        h, w, cin = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1, cout
+    net.packed_wino, net.wino_s2d = {}, set()
+    assert bench.encoder_executed_flops_per_pair(net) == bench.encoder_flops_per_pair(8)
+    net.packed_wino = {n: None for n in ("conv2", "conv3", "conv3_1", "conv4_1", "conv5_1", "conv6_1")}
+    net.wino_s2d = {"conv2", "conv3"}
+    direct = {g[0]: 2 * g[4] * g[1] * g[5] ** 2 * ((g[2] + 2 * g[7] - g[5]) // g[6] + 1) * ((g[3] + 2 * g[7] - g[5]) // g[6] + 1) for g in net.enc_geom}
+    want = sum(v for n, v in direct.items() if n not in net.packed_wino)
+    want += 2 * 128 * 49 * 64 * 60 * 80 + 2 * 256 * 49 * 128 * 30 * 40                     # conv2, conv3: 49 positions x Cin per 2x2 tile
+    want += 2 * 256 * 256 * 16 * 30 * 40 + 2 * 512 * 512 * 16 * 15 * 20                   # conv3_1, conv4_1
+    want += 2 * 512 * 512 * 16 * 8 * 10 + 2 * 1024 * 1024 * 16 * 4 * 5                    # conv5_1 (15x20 -> 8x10 tiles), conv6_1
+    assert bench.encoder_executed_flops_per_pair(net) == want
+    assert 0.55 < want / bench.encoder_flops_per_pair(8) < 0.62
