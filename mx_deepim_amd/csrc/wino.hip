@@ -37,6 +37,7 @@ struct WinoParams {
   unsigned in_bytes, wd_bytes;
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
+  int lnpb;                   // conv_wino8_kernel<., 1>: log2 of the 8-channel blocks per input phase
 };
 
 #ifndef WINO_ABL
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {                                                                                            \
     const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
     const f32x4 t0 = T[x_ * 4 + 0], t1 = T[x_ * 4 + 1], t2 = T[x_ * 4 + 2], t3 = T[x_ * 4 + 3]; \
-    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3); \
+    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t3, t1);   /* nu = 3 NEGATED on both sides (pack_wino_kernel) */ \
     V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
   }
 
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {                                                                                            \
     const int x_ = (k) >> 2, w_ = (k) & 3;                                                     \
     const f32x4 t0 = T[x_ * 4 + 0], t1 = T[x_ * 4 + 1], t2 = T[x_ * 4 + 2], t3 = T[x_ * 4 + 3]; \
-    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t1, t3); \
+    const f32x4 r_ = w_ == 0 ? wsub(t0, t2) : w_ == 1 ? wadd(t1, t2) : w_ == 2 ? wsub(t2, t1) : wsub(t3, t1);   /* nu = 3 NEGATED on both sides (pack_wino_kernel) */ \
     V0_[k] = r_.xy; V1_[k] = r_.zw;                                                            \
   }
 #define W2MFMA(VV, q, s_) \
@@ -534,6 +535,422 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Shared-transform kernel (round 5, the default wherever Cout % 64 == 0): the same algorithm and the same bits as
+// conv_wino_kernel, re-cut so that the work a lone wave pays for with matrix-pipe time is shared or hidden.
+// What round 4 measured on the one-wave kernel: its 128 transform adds and 32 loads per 64 MFMAs are not hidden behind the fp32
+// matrix pipe (which runs on the fp32 vector lanes) — they add to it (0.68 MFMA-busy against 0.88 of the direct kernel);
+// a second wave per SIMD hides load issue, but the two-wave form above re-loads 3 of 4 patch rows per half and drowns in loads.
+// Here a 512-thread block (8 waves, two per SIMD, 128 + 128 registers) owns 64 output channels x 64 tiles x 16 positions:
+//   * the input transform of a step (8 input channels x 64 tiles) is computed ONCE per block — a lane owns one patch COLUMN of
+//     one tile and four channels: 4 pixel loads (16 B), row pass in registers, the column pass across the four lanes of a quad
+//     with DPP quad_perm operands, 4 ds_write_b128 of V — 32 fp32 ops and 4 loads per wave per 32 MFMAs where the one-wave
+//     kernel spends 64 and 8 (and every V is multiplied by 64 output channels instead of 32);
+//   * the transformed weights of the step (2 x 16 KB, already in MFMA operand order) come in by LDS-DMA, 4 x 1 KB per wave;
+//   * wave (ph, mh, tg) multiplies positions xi in {2ph, 2ph+1} of channel half mh and tile half tg: operands are one
+//     ds_read_b128 per position and side per step (4 k-steps each), re-read right behind their last use;
+//   * two LDS slots (U 32 KB + V 36.25 KB each); ONE barrier per step, placed after the step's first 8 MFMAs so that the wait for
+//     this wave's own LDS traffic and DMA has been covered; stage s is loaded in step s-3, transformed in step s-2, read into
+//     registers in step s-1 and multiplied in step s;
+//   * output transform: s[xi][b] per wave, the halves swap 32 values per lane through LDS and each finishes 16 of the 32 channels
+//     in the one-wave kernel's order of operations: results are bit-identical to conv_wino_kernel.
+//   * S2D: the phase structure of the stride-2 layers with the identically-zero positions skipped by wave-uniform branches
+//     (top waves 28, bottom waves 21 of 32 MFMAs per four phases; a top and a bottom wave share each SIMD).
+#ifndef W8_ADIRECT
+#define W8_ADIRECT 1
+#endif
+#ifndef W8_ABL
+#define W8_ABL 0   // dev ablations (wrong results): 1 no step barriers, 2 no weight DMA, 4 no pixel loads + transform + V stores, 8 no operand reads in the loop, 16 no output transform / stores, 32 no MFMAs
+#endif
+#define W8_QS 2320                       /* V: bytes per position: 2 tile halves x 2 k halves x (512 + 64 pad) + 16 */
+#define W8_HS 576
+#define W8_TGS 1152
+#define W8_USLOT 32768                   /* U: 2 slots of [channel half][position][lane][16 B] */
+#define W8_VOFF (2 * W8_USLOT)           /* then V: 2 slots of 16 positions; every offset of either slot fits the ds 16-bit immediate */
+#define W8_VSLOT (16 * W8_QS)            /* 37 120 B */
+#define W8_LDS_BYTES (W8_VOFF + 2 * W8_VSLOT)   /* 139 776 B */
+
+// PH: the wave's half (0 top: xi = 0, 1; 1 bottom: xi = 2, 3) as a COMPILE-TIME constant — the two halves run different streams, and
+// with the choice behind run-time branches inside one body the register allocator cannot keep the accumulator tuples in place
+// across the joins (hundreds of scratch spills); the kernel branches once, at its top, into two complete bodies.
+template <int OUT_NC8, int S2D, int PH>
+__device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  constexpr int ph = PH;
+  const int mh = wave & 1, tg = (wave >> 1) & 1;
+  const int lrow = lane >> 5, lcol = lane & 31;
+  int mb2, bx;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    if ((p.gy & 7) == 0) {          // XCD x owns the channel blocks [x·gy/8, (x+1)·gy/8): its slice of U stays in its L2
+      const int per = p.gy >> 3;
+      mb2 = xcd * per + idx % per;
+      bx = idx / per;
+    } else if ((8 % p.gy) == 0) {   // 8 / gy XCDs per channel block
+      const int r = 8 / p.gy;
+      mb2 = xcd % p.gy;
+      bx = idx * r + xcd / p.gy;
+    } else {
+      mb2 = bid % p.gy;
+      bx = bid / p.gy;
+    }
+  }
+  if (bx >= p.gx) return;
+  const int tpi = p.TY * p.TX;
+  const int c8n = p.Cin >> 3;
+  const int hw32 = p.H * p.W * 32;
+
+  // ---- transform role: lane = (tile Tl of the block's 64, k half hT, patch column j)
+  const int j = lane & 3, hT = (lane >> 2) & 1, Tl = wave * 8 + (lane >> 3);
+  int voffT[4];
+  {
+    const int tT = bx * 64 + Tl;
+    const bool tv = tT < p.ntiles;
+    const int n = tv ? tT / tpi : 0;
+    const int tr = tv ? tT - n * tpi : 0;
+    const int ty = tr / p.TX, tx = tr - ty * p.TX;
+    const int x = 2 * tx - 1 + j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = 2 * ty - 1 + i;
+      const bool ok = tv && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      voffT[i] = ok ? (((n * c8n) * p.H + y) * p.W + x) * 32 + hT * 16 : (int)0x80000000;
+    }
+  }
+  const float sgn = j == 1 ? 1.f : -1.f;
+  const unsigned vw = W8_VOFF + (unsigned)((Tl >> 5) * W8_TGS + hT * W8_HS + (Tl & 31) * 16 + j * W8_QS);
+  // ---- multiply role
+  const unsigned ra = (unsigned)(mh * 16384 + ph * 8192 + lane * 16);
+  const unsigned rb = W8_VOFF + (unsigned)(ph * 8 * W8_QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
+  const int ra_g = lane * 16 + ph * 8192;                  // W8_ADIRECT: this lane's 16 bytes of position 8 ph + i at + i * 1024 ...
+  const int ra_s0 = ((mb2 * 2 + mh) * c8n) * 16384;         // ... of the channel half's 16 KB per 8-channel block
+  // ---- DMA role: pieces wave*4 .. wave*4 + 3 of the step's 32 (1 KB each: [channel half][position])
+  const unsigned dma_v = (unsigned)(lane * 16 + (wave & 3) * 4096);
+  const unsigned dma_l = (unsigned)(size_t)smem + (unsigned)(wave * 4096);
+  const int dma_s0 = ((mb2 * 2 + (wave >> 2)) * c8n) * 16384;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);   // no records: every load returns 0
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  f32x4 raw[4], T[4], A[8], Bv[8];
+
+  // S2D: stage s belongs to input phase s / npb (py = phase >> 1, px = phase & 1): positions xi = 3 (py) / nu = 3 (px) vanish
+  const int lnpb = S2D ? p.lnpb : 0;   // log2(stages per phase): a power of two (the launcher checks), so a phase is a shift
+#define W8_PH(s) (S2D ? min((s) >> lnpb, 3) : 0)
+// position i of this wave in a stage of phase (px_, py_) — wave-uniform; a compile-time `true` wherever the position is never dropped
+#define W8_ACTR(i) (!S2D || !((px_ && ((i) & 3) == 3) || (py_ && ph && (i) >= 4)))
+#define W8_LDS4(off) (*reinterpret_cast<f32x4*>(smem + (off)))
+// (one M0 / voffset pair per slot: the instruction offset advances the LDS address and the global address together)
+#define W8_DMA1(i_, soff, slot_)                                                                      \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds"   \
+               :: "s"(__builtin_amdgcn_readfirstlane(dma_l + (unsigned)((slot_) * W8_USLOT))), "v"(dma_v), "s"(rsrw), "s"(soff), "n"((i_) * 1024) : "memory");
+// the step's 4 weight pieces of this wave (S2D: only those of positions the stage's phase keeps)
+#define W8_DMA(stage, slot_)                                                                          \
+  {                                                                                                   \
+    const int st_ = min((stage), c8n - 1);                                                            \
+    const int so_ = __builtin_amdgcn_readfirstlane(dma_s0 + st_ * 16384);                             \
+    const int ps_ = W8_PH(stage);                                                                     \
+    if (!(W8_ABL & 2) && !W8_ADIRECT) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                             \
+      const int q_ = ((wave & 3) * 4 + i_);                                                           \
+      if (!S2D || !(((ps_ & 1) && (q_ & 3) == 3) || ((ps_ >> 1) && (q_ >> 2) == 3))) { W8_DMA1(i_, so_, slot_) } \
+    }                                                                                                 \
+  }
+// one of them (i_ = 0..3)
+#define W8_DMAP(stage, slot_, i_)                                                                     \
+  if (!(W8_ABL & 2) && !W8_ADIRECT) {                                                                                \
+    const int st_ = min((stage), c8n - 1);                                                            \
+    const int so_ = __builtin_amdgcn_readfirstlane(dma_s0 + st_ * 16384);                             \
+    const int ps_ = W8_PH(stage);                                                                     \
+    const int q_ = ((wave & 3) * 4 + (i_));                                                           \
+    if (!S2D || __builtin_amdgcn_readfirstlane((int)!(((ps_ & 1) && (q_ & 3) == 3) || ((ps_ >> 1) && (q_ >> 2) == 3)))) { W8_DMA1(i_, so_, slot_) } \
+  }
+// the 4 pixel loads of this lane's patch column. S2D: patch row 3 feeds only xi = 3 — where the stage's phase drops those positions the
+// load is still issued (no control flow around register writes) but through an empty descriptor: no memory access, no VALU work.
+// (Column 3 feeds only nu = 3 as well; masking those lanes would cost 4 vector ORs per step, more than their L1 hits.)
+#define W8_PIX(stage)                                                                                 \
+  if (!(W8_ABL & 4)) {                                                                                \
+    const int st_ = min((stage), c8n - 1);                                                            \
+    const int so_ = __builtin_amdgcn_readfirstlane(st_ * hw32);                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                                  \
+      raw[i_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[i_], so_, 0)); \
+    if (S2D && (W8_PH(stage) >> 1)) raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voffT[3], 0, 0)); \
+    else raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[3], so_, 0)); \
+  }
+#define W8_ROW()                                                                                      \
+  {                                                                                                   \
+    T[0] = wsub(raw[0], raw[2]); T[1] = wadd(raw[1], raw[2]); T[2] = wsub(raw[2], raw[1]); T[3] = wsub(raw[1], raw[3]); \
+  }
+// column pass of row xi across the quad, IN PLACE: lane j holds t_j and needs (t0 - t2, t1 + t2, t2 - t1, t3 - t1)[j] (nu = 3 negated, as
+// packed) = self + sgn * T[lane (2, 2, 1, 1)[j]], sgn = (-1, +1, -1, -1): one v_fmac_f32 with a DPP quad_perm source per value
+// (every VALU instruction of either wave — integer, move or fp32 — comes out of the fp32 matrix pipe's time: profiles/r05_winograd.md).
+// s_nop 1: a DPP source written by the VALU instruction right before needs two wait states, and the hazard pass cannot see inside the asm
+#define W8_FMACD(t_)                                                                                  \
+  asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(sgn));
+#define W8_COL(xi, slot_)                                                                             \
+  {                                                                                                   \
+    float c0_ = T[xi].x, c1_ = T[xi].y, c2_ = T[xi].z, c3_ = T[xi].w;                                 \
+    asm volatile("s_nop 1");                                                                          \
+    W8_FMACD(c0_) W8_FMACD(c1_) W8_FMACD(c2_) W8_FMACD(c3_)                                           \
+    f32x4 v_; v_.x = c0_; v_.y = c1_; v_.z = c2_; v_.w = c3_;                                         \
+    W8_LDS4(vw + (unsigned)((slot_) * W8_VSLOT + (xi) * 4 * W8_QS)) = v_;                                           \
+  }
+// W8_ADIRECT 1: the weights of position i come straight from global memory (L1 / L2: the two tile halves of a channel half read the
+// same bytes) into the operand registers, rsa_ = the scalar offset of the stage being read; 0: through the LDS-DMA slots
+#define W8_RD(i, slot_)                                                                               \
+  {                                                                                                   \
+    if (W8_ADIRECT) A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0)); \
+    else A[i] = W8_LDS4(ra + (unsigned)((slot_) * W8_USLOT + (i) * 1024));                             \
+    Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * W8_VSLOT + (i) * W8_QS));                               \
+  }
+#define W8_MFMA(i, s_)                                                                                \
+  acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) == 0 ? A[i].x : (s_) == 1 ? A[i].y : (s_) == 2 ? A[i].z : A[i].w, \
+                                                (s_) == 0 ? Bv[i].x : (s_) == 1 ? Bv[i].y : (s_) == 2 ? Bv[i].z : Bv[i].w, acc[i], 0, 0, 0); \
+  asm volatile("" : "+a"(acc[i]));
+#define W8_SYNC()                                                                                     \
+  if (W8_ADIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  asm volatile("" ::: "memory");
+// MFMA blocks: two positions interleaved (i0,s0) (i1,s0) (i0,s1) ... or one position's four k-steps; X(sl) = the slot's share of the
+// other roles. Blocks a phase can drop carry no X and sit behind ONE wave-uniform branch each (branches around single MFMAs, or arms
+// that duplicate the other roles, make the register allocator move accumulator tuples at the joins).
+#define W8_M2X(i0, i1, X)                                                                             \
+  _Pragma("unroll") for (int sl = 0; sl < 8; ++sl) {                                                  \
+    if (!(W8_ABL & 32)) { if (sl & 1) { W8_MFMA(i1, sl >> 1) } else { W8_MFMA(i0, sl >> 1) } }        \
+    X(sl) __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+#define W8_M1X(i0, X)                                                                                 \
+  _Pragma("unroll") for (int sl = 0; sl < 8; sl += 2) {                                               \
+    if (!(W8_ABL & 32)) { W8_MFMA(i0, sl >> 1) }                                                      \
+    X(sl) __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+
+  // ---- prologue: stage 0 into slot 0 and into the operand registers, the weights of stage 1 into slot 1; the top wave also
+  // transforms stage 1 into slot 1 and loads the pixels of stage 2 (the bottom wave does both in its first step)
+  W8_PIX(0)
+  W8_DMA(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  W8_ROW()
+  W8_PIX(1)
+  W8_DMA(1, 1)
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 0)
+  W8_SYNC()
+  {
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W8_RD(i, 0)
+  }
+  if (!ph) {
+    W8_ROW()
+    W8_PIX(2)
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 1)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- one step per stage k (SL = k & 1), ONE barrier each: behind barrier k every wave reads stage k + 1 into its operand
+  // registers from slot SL ^ 1 and brings its 4 weight pieces of stage k + 2 into slot SL; between barriers k and k + 1 it transforms
+  // its share of stage k + 2 (pixels loaded a step earlier) into slot SL and loads its pixels of stage k + 3. The two waves of a SIMD
+  // run 16 MFMAs apart — in lockstep both would leave the matrix pipe idle at the same time:
+  //   top    (ph 0): P0(k) | barrier k | R01 | P1(k) + transform k+2 | R23 | P2(k) + DMA | R45 | P3(k) | R67
+  //   bottom (ph 1): P0(k) + transform k+1 | P1(k) | barrier k | R01 R23 | P2(k) + DMA | R45 | P3(k) | R67
+  // (Pn = the 8 MFMAs of positions 2n, 2n+1; Rab = the operand reads of positions a, b for stage k + 1). Between two barriers the
+  // top wave's transform sits in the first quarter and the bottom wave's in the last but one; the bottom wave's barrier leaves its
+  // pixel loads in flight. All MFMAs of a step belong to stage k, so the S2D form specialises the step on the stage's phase.
+// the operand reads of two positions for the next stage (S2D: positions the next stage's phase drops are read all the same — stale
+// bytes that are never multiplied; a branch around register writes costs the allocator more than the read costs the LDS)
+#define W8_R2(i0, i1, SLR)                                                                            \
+    if (!(W8_ABL & 8)) { W8_RD(i0, SLR) W8_RD(i1, SLR) }                                              \
+    __builtin_amdgcn_sched_barrier(0);
+#define W8_R1(i0, SLR)                                                                                \
+    if (!(W8_ABL & 8)) { W8_RD(i0, SLR) }                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define W8_XNONE(sl)
+// slots with the transform of stage xst_ into slot xsl_ and the pixel loads of stage xst_ + 1
+#define W8_XWORK(sl)                                                                                  \
+      if (sl == 0 && !(W8_ABL & 4)) { W8_ROW() }                                                      \
+      if (sl >= 1 && sl <= 4 && !(W8_ABL & 4)) { W8_COL(sl - 1, xsl_) }                               \
+      if (sl == 5) { W8_PIX(xst_ + 1) }   /* behind the column pass: the loads' 16 registers are the row pass's */
+// slots with the 4 weight pieces of stage dst_ into slot dsl_, one in every other slot
+#define W8_XDMA(sl)                                                                                   \
+      if (!(sl & 1)) { W8_DMAP(dst_, dsl_, sl >> 1) }
+// the bottom wave's barrier: everything but the 4 pixel loads it has just issued
+#define W8_SYNC_B()                                                                                   \
+  if (W8_ADIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+  else if (W8_ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                    \
+  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                    \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  asm volatile("" ::: "memory");
+// top    (positions i = x*4 + nu, xi = x):     always 0 1 2 4 5 6;  nu = 3 (3, 7) unless px
+// bottom (xi = 2 + x):                         always 0 1 2;  3 unless px;  4 5 6 unless py;  7 unless px or py
+#define W8_STEP(k, SL)                                                                                \
+  {                                                                                                   \
+    const int pc_ = W8_PH(k);                                                                         \
+    const bool px_ = S2D && (pc_ & 1), py_ = S2D && (pc_ >> 1);                                       \
+    const int dst_ = (k) + 2; constexpr int dsl_ = (SL);                                              \
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + min((k) + 1, c8n - 1) * 16384);          \
+    if (!ph) {                                                                                        \
+      const int xst_ = (k) + 2; constexpr int xsl_ = (SL);                                            \
+      W8_M2X(0, 1, W8_XNONE)                                                                          \
+      if (!(W8_ABL & 1)) { W8_SYNC() }                                                                \
+      W8_R2(0, 1, (SL) ^ 1)                                                                           \
+      W8_M2X(2, 4, W8_XWORK)                                                                          \
+      W8_R2(2, 4, (SL) ^ 1)                                                                           \
+      W8_M2X(5, 6, W8_XDMA)                                                                           \
+      W8_R2(5, 6, (SL) ^ 1)                                                                           \
+      if (!px_) { W8_M2X(3, 7, W8_XNONE) }                                                            \
+      W8_R2(3, 7, (SL) ^ 1)                                                                           \
+    } else {                                                                                          \
+      const int xst_ = (k) + 1; constexpr int xsl_ = (SL) ^ 1;                                        \
+      W8_M2X(0, 1, W8_XWORK)                                                                          \
+      if (!px_) { W8_M1X(3, W8_XNONE) }                                                               \
+      if (!(W8_ABL & 1)) { W8_SYNC_B() }                                                              \
+      W8_R2(0, 1, (SL) ^ 1)                                                                           \
+      W8_R1(3, (SL) ^ 1)                                                                              \
+      W8_M1X(2, W8_XDMA)                                                                              \
+      W8_R1(2, (SL) ^ 1)                                                                              \
+      if (!py_) { W8_M2X(4, 5, W8_XNONE) }                                                            \
+      W8_R2(4, 5, (SL) ^ 1)                                                                           \
+      if (!py_) { if (!px_) { W8_M2X(6, 7, W8_XNONE) } else { W8_M1X(6, W8_XNONE) } }                 \
+      W8_R2(6, 7, (SL) ^ 1)                                                                           \
+    }                                                                                                 \
+  }
+  {
+    int k = 0;
+    for (; k + 2 <= c8n; k += 2) {
+      W8_STEP(k, 0)
+      W8_STEP(k + 1, 1)
+    }
+    if (k < c8n) W8_STEP(k, 0)
+  }
+#undef W8_STEP
+#undef W8_SYNC_B
+#undef W8_XDMA
+#undef W8_XWORK
+#undef W8_XNONE
+#undef W8_R1
+#undef W8_R2
+#undef W8_M1X
+#undef W8_M2X
+#undef W8_DMAP
+#undef W8_MFMA
+#undef W8_RD
+#undef W8_COL
+#undef W8_FMACD
+#undef W8_ROW
+#undef W8_PIX
+#undef W8_DMA
+#undef W8_DMA1
+#undef W8_PH
+
+  // ---- output transform. acc[x*4 + nu][r] with xi = 2ph + x: channel (r&3) + 8(r>>2) + 4·lrow of the wave's 32, tile lcol.
+  // s[xi][0] = (m0 + m1) + m2, s[xi][1] = (m1 - m2) - m3; Y[0][b] = ((s0 + s1) + s2) + bias, Y[1][b] = ((s1 - s2) - s3) + bias.
+  // The top wave (s0, s1) finishes accumulator rows 0-7, the bottom wave (s2, s3) rows 8-15; each hands the other its s of the
+  // rows it does not finish: 32 floats per lane through LDS, [wave][value][lane].
+  W8_SYNC()   // every wave is done with both slots, every DMA piece has landed
+  if (W8_ABL & 16) { if (acc[0][0] == 123.f && acc[7][15] == 4.f) p.out[0] = acc[3][2]; return; }
+  // opaque copies: everything the epilogue derives from the block index is computed HERE (hoisted above the K loop it would sit in
+  // registers the loop needs, i.e. in scratch)
+  int bxe = __builtin_amdgcn_readfirstlane(bx), mb2e = __builtin_amdgcn_readfirstlane(mb2), tpie = __builtin_amdgcn_readfirstlane(tpi),
+      TXe = __builtin_amdgcn_readfirstlane(p.TX);   // (bx, mb2 come out of a VALU division: uniform, but in vector registers)
+  asm volatile("" : "+s"(bxe), "+s"(mb2e), "+s"(tpie), "+s"(TXe));
+  const int lanee = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int lrow_e = lanee >> 5, lcol_e = lanee & 31;
+  const int t = bxe * 64 + tg * 32 + lcol_e;
+  const bool tvalid = t < p.ntiles;
+  const int n = tvalid ? t / tpie : 0;
+  const int trm = tvalid ? t - n * tpie : 0;
+  const int ty = trm / TXe, tx = trm - ty * TXe;
+  const int y0 = 2 * ty, x0 = 2 * tx;
+  const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+  const int mb = mb2e * 2 + mh;
+  float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
+  const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ 4) * 2048 + lanee;
+  // whole-vector forms: reading single elements of an AGPR-resident f32x16 makes the compiler copy all 16 registers each time
+  f32x16 sx[2][2];   // [x][b], all 16 rows
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const f32x16 t_ = acc[x * 4 + 0] + acc[x * 4 + 1];
+    sx[x][0] = t_ + acc[x * 4 + 2];
+    const f32x16 u_ = acc[x * 4 + 1] - acc[x * 4 + 2];
+    sx[x][1] = u_ - acc[x * 4 + 3];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#define W8_SEND(PHC)                                                                                  \
+  {                                                                                                   \
+    _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                                \
+      const int r = (PHC) ? rr : rr + 8;   /* the rows the OTHER half finishes */                     \
+      xw[(rr * 4 + 0) * 64] = sx[0][0][r]; xw[(rr * 4 + 1) * 64] = sx[0][1][r];                       \
+      xw[(rr * 4 + 2) * 64] = sx[1][0][r]; xw[(rr * 4 + 3) * 64] = sx[1][1][r];                       \
+    }                                                                                                 \
+  }
+#define W8_FINISH(PHC)                                                                                \
+  {                                                                                                   \
+      float4 bq[2];                                                                                   \
+      _Pragma("unroll") for (int gg = 0; gg < 2; ++gg)                                                \
+        bq[gg] = p.bias ? *reinterpret_cast<const float4*>(p.bias + mb * 32 + 8 * ((PHC) * 2 + gg) + 4 * lrow_e) : make_float4(0.f, 0.f, 0.f, 0.f); \
+      _Pragma("unroll") for (int gg = 0; gg < 2; ++gg) {                                              \
+        const int g = (PHC) * 2 + gg;                                                                 \
+        float o[4][4];                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+          const int r = 4 * g + e, rr = r - (PHC) * 8;                                                \
+          const float bv = e == 0 ? bq[gg].x : e == 1 ? bq[gg].y : e == 2 ? bq[gg].z : bq[gg].w;      \
+          _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                             \
+            const float mine0 = sx[0][b][r], mine1 = sx[1][b][r];                                     \
+            const float oth0 = xr[(rr * 4 + b) * 64], oth1 = xr[(rr * 4 + 2 + b) * 64];               \
+            const float s0 = (PHC) ? oth0 : mine0, s1 = (PHC) ? oth1 : mine1;                         \
+            const float s2 = (PHC) ? mine0 : oth0, s3 = (PHC) ? mine1 : oth1;                         \
+            float v0 = ((s0 + s1) + s2) + bv;                                                         \
+            float v1 = ((s1 - s2) - s3) + bv;                                                         \
+            o[0 * 2 + b][e] = v0 > 0.f ? v0 : v0 * p.slope;                                           \
+            o[1 * 2 + b][e] = v1 > 0.f ? v1 : v1 * p.slope;                                           \
+          }                                                                                           \
+        }                                                                                             \
+        _Pragma("unroll") for (int ab = 0; ab < 4; ++ab) {                                            \
+          const int a = ab >> 1, b = ab & 1;                                                          \
+          if ((a && !y1ok) || (b && !x1ok)) continue;                                                 \
+          const long pix = (long)(y0 + a) * p.W + x0 + b;                                             \
+          if (OUT_NC8) {                                                                              \
+            long rec;                                                                                 \
+            if (p.out_s2d)                                                                            \
+              rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * TXe) + ty * TXe + tx; \
+            else                                                                                      \
+              rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;                         \
+            *reinterpret_cast<float4*>(p.out + rec * 8 + 4 * lrow_e) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]); \
+          } else {                                                                                    \
+            const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow_e;         \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) p.out[(c0 + e) * p.H * p.W + pix] = o[ab][e]; \
+          }                                                                                           \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+      }                                                                                               \
+  }
+  if (ph == 0) W8_SEND(0) else W8_SEND(1)
+  W8_SYNC()
+  if (!tvalid) return;
+  if (ph == 0) W8_FINISH(0) else W8_FINISH(1)
+#undef W8_SEND
+#undef W8_FINISH
+#undef W8_SYNC
+#undef W8_LDS4
+}
+
+template <int OUT_NC8, int S2D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(WinoParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[W8_LDS_BYTES];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // waves w and w + 4 share a SIMD: a top and a bottom half each
+  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0>(p, smem, wave);
+  else wino8_body<OUT_NC8, S2D, 1>(p, smem, wave);
+}
+
 // U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
 // s2d: `w` is a (Cout, Cin/4, 5, 5) stride-2 pad-2 kernel read as the 3x3 stride-1 pad-1 kernel over the 4 input phases it is
 // equivalent to — channel phase*(Cin/4) + c, phase = py*2 + px, tap (a, b) = w[2a + py][2b + px] (zero where 2a + py or 2b + px = 5)
@@ -559,7 +976,9 @@ __global__ void pack_wino_kernel(float* __restrict__ packed, const float* __rest
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) u += G[xi][a] * (double)g[a * 3 + b] * G[nu][b];
   }
-  packed[i] = (float)u;
+  // positions nu = 3 are stored NEGATED, and every kernel multiplies them with the negated V (t3 - t1 instead of t1 - t3): the
+  // products are the same bits, and conv_wino8_kernel's column pass becomes ONE v_fmac_f32_dpp per value (self + sgn * neighbour)
+  packed[i] = nu == 3 ? -(float)u : (float)u;
 }
 
 extern "C" size_t deepim_conv_wino_packed_size(int Cout, int Cin) {
@@ -635,14 +1054,36 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
   const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
-  p.gx = di_div_up(p.ntiles, two_wave ? 64 : 128);
-  p.gy = Cout / 32;
+  // (the stride-2 layers stay on the one-wave kernel: with the zero positions skipped behind wave-uniform branches the compiler moves
+  // this kernel's accumulator tuples between the arms and spills them; ctx->wino_shared == 2 forces it for measurements)
+  const bool shared = !two_wave && (ctx->wino_shared == 2 || (ctx->wino_shared && !s2d)) && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel on 64 channels x 64 tiles
+  p.gx = di_div_up(p.ntiles, (two_wave || shared) ? 64 : 128);
+  p.gy = shared ? Cout / 64 : Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
+  p.lnpb = 0;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
-  const int grid = p.gx * p.gy;
+  int grid = p.gx * p.gy;
+  if (shared) {
+    // block -> (channel block, tile block) as conv_wino8_kernel maps it: gy < 8 dividing 8 deals 8 / gy XCDs to each channel block
+    if ((p.gy & 7) != 0 && (8 % p.gy) == 0) grid = 8 * di_div_up(p.gx, 8 / p.gy);
+    // phase-by-phase skipping needs whole 8-channel blocks per input phase, a power of two of them (the phase of a stage is a shift)
+    const int npb = Cin / 32;
+    const bool ph8 = s2d && (Cin % 32) == 0 && (npb & (npb - 1)) == 0 && ctx->wino_s2d_skip;
+    p.lnpb = 0;
+    while (ph8 && (1 << p.lnpb) < npb) ++p.lnpb;
+    if (ph8) {
+      if (out_nc8) conv_wino8_kernel<1, 1><<<grid, 512, 0, ctx->stream>>>(p);
+      else conv_wino8_kernel<0, 1><<<grid, 512, 0, ctx->stream>>>(p);
+    } else {
+      if (out_nc8) conv_wino8_kernel<1, 0><<<grid, 512, 0, ctx->stream>>>(p);
+      else conv_wino8_kernel<0, 0><<<grid, 512, 0, ctx->stream>>>(p);
+    }
+    DI_LAUNCH_CHECK();
+    return 0;
+  }
   // phase-by-phase K loop with the zero positions skipped: needs an even number of 8-channel blocks per input phase
   const bool phases = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
   if (two_wave) {

@@ -13,12 +13,16 @@ cf = ctypes.c_float
 TOL = 1e-5
 
 
-@pytest.fixture(params=[0, 1], ids=["one_wave_per_simd", "two_waves_per_simd"], autouse=True)
+@pytest.fixture(params=["shared", "one_wave", "two_wave"], ids=["shared_transform_8_waves", "one_wave_per_simd", "two_waves_per_simd"],
+                autouse=True)
 def wino_kernel(ctx, request):
-    """Every test on both kernels: the default (one 16-position wave per SIMD) and the optional two-wave form."""
-    lib.deepim_set_option(ctx.handle, b"wino_two_wave", request.param)
+    """Every test on all three kernels: the default (8-wave shared-transform blocks wherever Cout % 64 == 0, the one-wave kernel
+    otherwise), the round-4 one-wave kernel alone, and the optional two-wave form."""
+    lib.deepim_set_option(ctx.handle, b"wino_shared", 1 if request.param == "shared" else 0)
+    lib.deepim_set_option(ctx.handle, b"wino_two_wave", 1 if request.param == "two_wave" else 0)
     yield request.param
     lib.deepim_set_option(ctx.handle, b"wino_two_wave", 0)
+    lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
 
 
 def _to_nc8(x):
@@ -76,13 +80,37 @@ def test_wino_layer_within_1e5_of_the_direct_convolution(ctx, case):
     assert (gw[:, :3] == 7.0).all() and (gw[:, 3 + cout:] == 7.0).all()
 
 
-def test_wino_weight_transform_is_G_g_Gt(ctx):
+@pytest.mark.parametrize("case", [(2, 256, 12, 16, 256), (3, 64, 15, 20, 64), (2, 24, 1, 5, 128), (33, 8, 6, 6, 64), (1, 1024, 8, 10, 1024)])
+def test_shared_transform_kernel_is_bit_identical_to_the_one_wave_kernel(ctx, case, wino_kernel):
+    """conv_wino8_kernel computes the same V, the same per-position fp32 MFMA chains and the same output-transform expression tree
+    as conv_wino_kernel — only who computes what differs — so NC8, space-to-depth and NCHW-slice outputs are the same bits."""
+    if wino_kernel != "shared":
+        pytest.skip("compares the two kernels itself")
+    B, cin, H, W, cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    xin, pk, bias = ctx.array(_to_nc8(x)), _pack(ctx, w), ctx.array(rng.standard_normal(cout).astype(np.float32))
+    modes = [(1, 0, 0)] + ([(3, 0, 0)] if H % 2 == 0 and W % 2 == 0 else []) + [(0, cout + 8, 8)]
+    for out_nc8, ctotal, coff in modes:
+        outs = []
+        for shared in (1, 0):
+            lib.deepim_set_option(ctx.handle, b"wino_shared", shared)
+            o = ctx.array(np.full((B, max(ctotal, cout), H, W), 3.0, np.float32))
+            lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, ctotal, coff)
+            outs.append(o.asnumpy())
+        lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
+        np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_wino_weight_transform_is_G_g_Gt_with_the_last_column_negated(ctx):
     rng = np.random.default_rng(5)
     cout, cin = 32, 16
     w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     pk = _pack(ctx, w).asnumpy().reshape(cout // 32, cin // 8, 16, 2, 32, 4)     # [mb][c8][pos][h][row][s]
     G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
     U = np.einsum("xa,ocab,nb->ocxn", G, w.astype(np.float64), G).astype(np.float32)   # (cout, cin, 4, 4)
+    U[..., 3] = -U[..., 3]      # positions nu = 3 are stored negated (the kernels multiply them with t3 - t1 instead of t1 - t3)
     for c8 in range(cin // 8):
         for h in range(2):
             for s in range(4):
