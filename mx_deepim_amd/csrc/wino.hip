@@ -37,7 +37,6 @@ struct WinoParams {
   unsigned in_bytes, wd_bytes;
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
-  int lnpb;                   // conv_wino8_kernel<., 1>: log2 of the 8-channel blocks per input phase
 };
 
 #ifndef WINO_ABL
@@ -536,39 +535,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shared-transform kernel (round 5, the default wherever Cout % 64 == 0): the same algorithm and the same bits as
-// conv_wino_kernel, re-cut so that the work a lone wave pays for with matrix-pipe time is shared or hidden.
-// What round 4 measured on the one-wave kernel: its 128 transform adds and 32 loads per 64 MFMAs are not hidden behind the fp32
-// matrix pipe (which runs on the fp32 vector lanes) — they add to it (0.68 MFMA-busy against 0.88 of the direct kernel);
-// a second wave per SIMD hides load issue, but the two-wave form above re-loads 3 of 4 patch rows per half and drowns in loads.
-// Here a 512-thread block (8 waves, two per SIMD, 128 + 128 registers) owns 64 output channels x 64 tiles x 16 positions:
+// Shared-transform kernel (round 5, the default wherever Cout % 64 == 0): the same algorithm as conv_wino_kernel (3x3 layers: the same
+// bits), re-cut so that the work a lone wave pays for with matrix-pipe time is shared.
+// What the measurements say (profiles/r05_winograd.md): the fp32 matrix pipe runs on the fp32 vector lanes, and EVERY other
+// instruction of a SIMD's waves — fp32 or integer VALU, moves, LDS and memory instructions — comes out of its time, with one wave
+// per SIMD or with two. So the lever is the instruction count per MFMA: the one-wave kernel spends 128 transform adds and 32 loads per
+// 64 MFMAs (2.5 per MFMA; 0.68 MFMA-busy), this kernel 32 + 24 per 32 (1.75).
+// A 512-thread block (8 waves, two per SIMD, 128 + 128 registers) owns 64 output channels x 64 tiles x 16 positions:
 //   * the input transform of a step (8 input channels x 64 tiles) is computed ONCE per block — a lane owns one patch COLUMN of
 //     one tile and four channels: 4 pixel loads (16 B), row pass in registers, the column pass across the four lanes of a quad
-//     with DPP quad_perm operands, 4 ds_write_b128 of V — 32 fp32 ops and 4 loads per wave per 32 MFMAs where the one-wave
-//     kernel spends 64 and 8 (and every V is multiplied by 64 output channels instead of 32);
-//   * the transformed weights of the step (2 x 16 KB, already in MFMA operand order) come in by LDS-DMA, 4 x 1 KB per wave;
-//   * wave (ph, mh, tg) multiplies positions xi in {2ph, 2ph+1} of channel half mh and tile half tg: operands are one
-//     ds_read_b128 per position and side per step (4 k-steps each), re-read right behind their last use;
-//   * two LDS slots (U 32 KB + V 36.25 KB each); ONE barrier per step, placed after the step's first 8 MFMAs so that the wait for
-//     this wave's own LDS traffic and DMA has been covered; stage s is loaded in step s-3, transformed in step s-2, read into
-//     registers in step s-1 and multiplied in step s;
+//     as ONE v_fmac_f32 with a DPP quad_perm source per value (positions nu = 3 are stored negated on both sides for that),
+//     4 ds_write_b128 of V — and every V is multiplied by 64 output channels instead of 32;
+//   * wave (ph, mh, tg) multiplies positions xi in {2ph, 2ph+1} of channel half mh and tile half tg: V comes from LDS (one
+//     ds_read_b128 per position and step = 4 k-steps), the transformed weights straight from global memory (one 16-byte load per
+//     position and step; the two tile halves read the same bytes, L1 / the XCD's L2 serve them), both re-read right behind their
+//     last use;
+//   * two V slots in LDS (36.25 KB each), ONE barrier per step; stage s is loaded in step s-3, transformed in step s-2, read into
+//     registers in step s-1 and multiplied in step s. The two waves of a SIMD run the same stream 16 MFMAs apart (in lockstep both
+//     would leave the matrix pipe idle at the same time);
 //   * output transform: s[xi][b] per wave, the halves swap 32 values per lane through LDS and each finishes 16 of the 32 channels
-//     in the one-wave kernel's order of operations: results are bit-identical to conv_wino_kernel.
-//   * S2D: the phase structure of the stride-2 layers with the identically-zero positions skipped by wave-uniform branches
-//     (top waves 28, bottom waves 21 of 32 MFMAs per four phases; a top and a bottom wave share each SIMD).
-#ifndef W8_ADIRECT
-#define W8_ADIRECT 1
-#endif
+//     in the one-wave kernel's order of operations: the 3x3 layers are bit-identical to conv_wino_kernel;
+//   * S2D (the 5x5 stride-2 layers): the stages of the four input phases are walked INTERLEAVED — two of phase 0, two of phase 1, … —
+//     so that one loop body of eight steps has a compile-time phase per step and the identically-zero positions are dropped with no
+//     branch at all (wave-uniform branches around MFMAs make the register allocator move accumulator tuples between the arms and
+//     spill them). The channel sum runs in that order, so these layers agree with the one-wave kernel to rounding, not bit for bit.
 #ifndef W8_ABL
-#define W8_ABL 0   // dev ablations (wrong results): 1 no step barriers, 2 no weight DMA, 4 no pixel loads + transform + V stores, 8 no operand reads in the loop, 16 no output transform / stores, 32 no MFMAs
+#define W8_ABL 0   // dev ablations (wrong results): 1 no step barriers, 4 no pixel loads + transform + V stores, 8 no operand reads in the loop, 16 no output transform / stores, 32 no MFMAs
 #endif
 #define W8_QS 2320                       /* V: bytes per position: 2 tile halves x 2 k halves x (512 + 64 pad) + 16 */
 #define W8_HS 576
 #define W8_TGS 1152
-#define W8_USLOT 32768                   /* U: 2 slots of [channel half][position][lane][16 B] */
-#define W8_VOFF (2 * W8_USLOT)           /* then V: 2 slots of 16 positions; every offset of either slot fits the ds 16-bit immediate */
-#define W8_VSLOT (16 * W8_QS)            /* 37 120 B */
-#define W8_LDS_BYTES (W8_VOFF + 2 * W8_VSLOT)   /* 139 776 B */
+#define W8_VSLOT (16 * W8_QS)            /* 37 120 B; every offset of either slot fits the ds instructions' 16-bit immediate */
+#define W8_LDS_BYTES (2 * W8_VSLOT)      /* 74 240 B (the output exchange reuses the first 64 KB) */
 
 // PH: the wave's half (0 top: xi = 0, 1; 1 bottom: xi = 2, 3) as a COMPILE-TIME constant — the two halves run different streams, and
 // with the choice behind run-time branches inside one body the register allocator cannot keep the accumulator tuples in place
@@ -619,19 +617,13 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     }
   }
   const float sgn = j == 1 ? 1.f : -1.f;
-  const unsigned vw = W8_VOFF + (unsigned)((Tl >> 5) * W8_TGS + hT * W8_HS + (Tl & 31) * 16 + j * W8_QS);
+  const unsigned vw = (unsigned)((Tl >> 5) * W8_TGS + hT * W8_HS + (Tl & 31) * 16 + j * W8_QS);
   // ---- multiply role
-  const unsigned ra = (unsigned)(mh * 16384 + ph * 8192 + lane * 16);
-  const unsigned rb = W8_VOFF + (unsigned)(ph * 8 * W8_QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
-  const int ra_g = lane * 16 + ph * 8192;                  // W8_ADIRECT: this lane's 16 bytes of position 8 ph + i at + i * 1024 ...
+  const unsigned rb = (unsigned)(ph * 8 * W8_QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
+  const int ra_g = lane * 16 + ph * 8192;                  // this lane's 16 bytes of position 8 ph + i at + i * 1024 ...
   const int ra_s0 = ((mb2 * 2 + mh) * c8n) * 16384;         // ... of the channel half's 16 KB per 8-channel block
-  // ---- DMA role: pieces wave*4 .. wave*4 + 3 of the step's 32 (1 KB each: [channel half][position])
-  const unsigned dma_v = (unsigned)(lane * 16 + (wave & 3) * 4096);
-  const unsigned dma_l = (unsigned)(size_t)smem + (unsigned)(wave * 4096);
-  const int dma_s0 = ((mb2 * 2 + (wave >> 2)) * c8n) * 16384;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);   // no records: every load returns 0
 
   f32x16 acc[8];
 #pragma unroll
@@ -640,55 +632,32 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   f32x4 raw[4], T[4], A[8], Bv[8];
 
-  // S2D: stage s belongs to input phase s / npb (py = phase >> 1, px = phase & 1): positions xi = 3 (py) / nu = 3 (px) vanish
-  const int lnpb = S2D ? p.lnpb : 0;   // log2(stages per phase): a power of two (the launcher checks), so a phase is a shift
-#define W8_PH(s) (S2D ? min((s) >> lnpb, 3) : 0)
-// position i of this wave in a stage of phase (px_, py_) — wave-uniform; a compile-time `true` wherever the position is never dropped
-#define W8_ACTR(i) (!S2D || !((px_ && ((i) & 3) == 3) || (py_ && ph && (i) >= 4)))
+  // S2D: the s2d tensor holds the input phases (py, px) as four runs of Cin/4 channels = npb 8-channel blocks each; positions xi = 3
+  // (py) / nu = 3 (px) of a phase's blocks vanish. Stage s of the K walk is block W8_CB(s): phases interleaved two blocks at a time,
+  // so that stage s has phase (s >> 1) & 3 — a compile-time constant at every place of the eight-step loop body.
+  const int npb = S2D ? (c8n >> 2) : 0;
+#define W8_CB(s) (S2D ? (((s) >> 1) & 3) * npb + (((s) >> 3) << 1) + ((s) & 1) : (s))
+// position i of this wave in a stage of phase P (compile-time)
+#define W8_ACT(i, P) (!S2D || !((((P) & 1) && ((i) & 3) == 3) || (((P) >> 1) && ph && (i) >= 4)))
 #define W8_LDS4(off) (*reinterpret_cast<f32x4*>(smem + (off)))
-// (one M0 / voffset pair per slot: the instruction offset advances the LDS address and the global address together)
-#define W8_DMA1(i_, soff, slot_)                                                                      \
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds"   \
-               :: "s"(__builtin_amdgcn_readfirstlane(dma_l + (unsigned)((slot_) * W8_USLOT))), "v"(dma_v), "s"(rsrw), "s"(soff), "n"((i_) * 1024) : "memory");
-// the step's 4 weight pieces of this wave (S2D: only those of positions the stage's phase keeps)
-#define W8_DMA(stage, slot_)                                                                          \
-  {                                                                                                   \
-    const int st_ = min((stage), c8n - 1);                                                            \
-    const int so_ = __builtin_amdgcn_readfirstlane(dma_s0 + st_ * 16384);                             \
-    const int ps_ = W8_PH(stage);                                                                     \
-    if (!(W8_ABL & 2) && !W8_ADIRECT) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                             \
-      const int q_ = ((wave & 3) * 4 + i_);                                                           \
-      if (!S2D || !(((ps_ & 1) && (q_ & 3) == 3) || ((ps_ >> 1) && (q_ >> 2) == 3))) { W8_DMA1(i_, so_, slot_) } \
-    }                                                                                                 \
-  }
-// one of them (i_ = 0..3)
-#define W8_DMAP(stage, slot_, i_)                                                                     \
-  if (!(W8_ABL & 2) && !W8_ADIRECT) {                                                                                \
-    const int st_ = min((stage), c8n - 1);                                                            \
-    const int so_ = __builtin_amdgcn_readfirstlane(dma_s0 + st_ * 16384);                             \
-    const int ps_ = W8_PH(stage);                                                                     \
-    const int q_ = ((wave & 3) * 4 + (i_));                                                           \
-    if (!S2D || __builtin_amdgcn_readfirstlane((int)!(((ps_ & 1) && (q_ & 3) == 3) || ((ps_ >> 1) && (q_ >> 2) == 3)))) { W8_DMA1(i_, so_, slot_) } \
-  }
-// the 4 pixel loads of this lane's patch column. S2D: patch row 3 feeds only xi = 3 — where the stage's phase drops those positions the
-// load is still issued (no control flow around register writes) but through an empty descriptor: no memory access, no VALU work.
+// the 4 pixel loads of this lane's patch column for stage `stage` of phase P. S2D: patch row 3 feeds only xi = 3 — where the phase drops
+// those positions neither the load, nor that row of the row pass, nor its column pass and store are issued (compile-time).
 // (Column 3 feeds only nu = 3 as well; masking those lanes would cost 4 vector ORs per step, more than their L1 hits.)
-#define W8_PIX(stage)                                                                                 \
+#define W8_PIX(stage, P)                                                                              \
   if (!(W8_ABL & 4)) {                                                                                \
     const int st_ = min((stage), c8n - 1);                                                            \
-    const int so_ = __builtin_amdgcn_readfirstlane(st_ * hw32);                                       \
+    const int so_ = __builtin_amdgcn_readfirstlane(W8_CB(st_) * hw32);                                \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                                  \
       raw[i_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[i_], so_, 0)); \
-    if (S2D && (W8_PH(stage) >> 1)) raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc0, voffT[3], 0, 0)); \
-    else raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[3], so_, 0)); \
+    if (!(S2D && ((P) >> 1))) raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[3], so_, 0)); \
   }
-#define W8_ROW()                                                                                      \
+#define W8_ROW(P)                                                                                     \
   {                                                                                                   \
-    T[0] = wsub(raw[0], raw[2]); T[1] = wadd(raw[1], raw[2]); T[2] = wsub(raw[2], raw[1]); T[3] = wsub(raw[1], raw[3]); \
+    T[0] = wsub(raw[0], raw[2]); T[1] = wadd(raw[1], raw[2]); T[2] = wsub(raw[2], raw[1]);            \
+    if (!(S2D && ((P) >> 1))) T[3] = wsub(raw[1], raw[3]);                                            \
   }
 // column pass of row xi across the quad, IN PLACE: lane j holds t_j and needs (t0 - t2, t1 + t2, t2 - t1, t3 - t1)[j] (nu = 3 negated, as
-// packed) = self + sgn * T[lane (2, 2, 1, 1)[j]], sgn = (-1, +1, -1, -1): one v_fmac_f32 with a DPP quad_perm source per value
-// (every VALU instruction of either wave — integer, move or fp32 — comes out of the fp32 matrix pipe's time: profiles/r05_winograd.md).
+// packed) = self + sgn * T[lane (2, 2, 1, 1)[j]], sgn = (-1, +1, -1, -1): one v_fmac_f32 with a DPP quad_perm source per value.
 // s_nop 1: a DPP source written by the VALU instruction right before needs two wait states, and the hazard pass cannot see inside the asm
 #define W8_FMACD(t_)                                                                                  \
   asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(sgn));
@@ -698,157 +667,145 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     asm volatile("s_nop 1");                                                                          \
     W8_FMACD(c0_) W8_FMACD(c1_) W8_FMACD(c2_) W8_FMACD(c3_)                                           \
     f32x4 v_; v_.x = c0_; v_.y = c1_; v_.z = c2_; v_.w = c3_;                                         \
-    W8_LDS4(vw + (unsigned)((slot_) * W8_VSLOT + (xi) * 4 * W8_QS)) = v_;                                           \
+    W8_LDS4(vw + (unsigned)((slot_) * W8_VSLOT + (xi) * 4 * W8_QS)) = v_;                              \
   }
-// W8_ADIRECT 1: the weights of position i come straight from global memory (L1 / L2: the two tile halves of a channel half read the
-// same bytes) into the operand registers, rsa_ = the scalar offset of the stage being read; 0: through the LDS-DMA slots
+// operands of position i for the stage whose weights sit at scalar offset rsa_: the weights straight from global memory (L1 / L2:
+// the two tile halves of a channel half read the same bytes), V from LDS slot slot_
 #define W8_RD(i, slot_)                                                                               \
   {                                                                                                   \
-    if (W8_ADIRECT) A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0)); \
-    else A[i] = W8_LDS4(ra + (unsigned)((slot_) * W8_USLOT + (i) * 1024));                             \
+    A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0)); \
     Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * W8_VSLOT + (i) * W8_QS));                               \
   }
 #define W8_MFMA(i, s_)                                                                                \
   acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) == 0 ? A[i].x : (s_) == 1 ? A[i].y : (s_) == 2 ? A[i].z : A[i].w, \
                                                 (s_) == 0 ? Bv[i].x : (s_) == 1 ? Bv[i].y : (s_) == 2 ? Bv[i].z : Bv[i].w, acc[i], 0, 0, 0); \
   asm volatile("" : "+a"(acc[i]));
+// a wave's own LDS traffic is all a barrier has to wait for: the global loads are tracked by the compiler where they are used
 #define W8_SYNC()                                                                                     \
-  if (W8_ADIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
   __builtin_amdgcn_s_barrier();                                                                       \
   asm volatile("" ::: "memory");
 // MFMA blocks: two positions interleaved (i0,s0) (i1,s0) (i0,s1) ... or one position's four k-steps; X(sl) = the slot's share of the
-// other roles. Blocks a phase can drop carry no X and sit behind ONE wave-uniform branch each (branches around single MFMAs, or arms
-// that duplicate the other roles, make the register allocator move accumulator tuples at the joins).
-#define W8_M2X(i0, i1, X)                                                                             \
+// other roles. P: the stage's phase — a block whose positions the phase drops shrinks or vanishes at compile time.
+#define W8_M2X(i0, i1, P, X)                                                                          \
   _Pragma("unroll") for (int sl = 0; sl < 8; ++sl) {                                                  \
-    if (!(W8_ABL & 32)) { if (sl & 1) { W8_MFMA(i1, sl >> 1) } else { W8_MFMA(i0, sl >> 1) } }        \
+    if (!(W8_ABL & 32)) {                                                                             \
+      if (sl & 1) { if (W8_ACT(i1, P)) { W8_MFMA(i1, sl >> 1) } } else { if (W8_ACT(i0, P)) { W8_MFMA(i0, sl >> 1) } } \
+    }                                                                                                 \
     X(sl) __builtin_amdgcn_sched_barrier(0);                                                          \
   }
-#define W8_M1X(i0, X)                                                                                 \
+#define W8_M1X(i0, P, X)                                                                              \
   _Pragma("unroll") for (int sl = 0; sl < 8; sl += 2) {                                               \
-    if (!(W8_ABL & 32)) { W8_MFMA(i0, sl >> 1) }                                                      \
+    if (!(W8_ABL & 32) && W8_ACT(i0, P)) { W8_MFMA(i0, sl >> 1) }                                     \
     X(sl) __builtin_amdgcn_sched_barrier(0);                                                          \
   }
+// the operand reads of positions for the next stage (phase PN: what it drops is not read)
+#define W8_R2(i0, i1, PN, SLR)                                                                        \
+    if (!(W8_ABL & 8)) { if (W8_ACT(i0, PN)) { W8_RD(i0, SLR) } if (W8_ACT(i1, PN)) { W8_RD(i1, SLR) } } \
+    __builtin_amdgcn_sched_barrier(0);
+#define W8_R1(i0, PN, SLR)                                                                            \
+    if (!(W8_ABL & 8) && W8_ACT(i0, PN)) { W8_RD(i0, SLR) }                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define W8_XNONE(sl)
+// slots with the transform of stage xst_ into slot xsl_ and, behind the column pass (the loads' 16 registers are the row pass's), the
+// pixel loads of stage xst_ + 1 (phase xpp_); xtp_ = the phase of stage xst_
+#define W8_XWORK(sl)                                                                                  \
+      if (sl == 0 && !(W8_ABL & 4)) { W8_ROW(xtp_) }                                                  \
+      if (sl >= 1 && sl <= 4 && !(W8_ABL & 4) && !(S2D && sl == 4 && (xtp_ >> 1))) { W8_COL(sl - 1, xsl_) } \
+      if (sl == 5) { W8_PIX(xst_ + 1, xpp_) }
 
-  // ---- prologue: stage 0 into slot 0 and into the operand registers, the weights of stage 1 into slot 1; the top wave also
-  // transforms stage 1 into slot 1 and loads the pixels of stage 2 (the bottom wave does both in its first step)
-  W8_PIX(0)
-  W8_DMA(0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  W8_ROW()
-  W8_PIX(1)
-  W8_DMA(1, 1)
+  // ---- prologue: stage 0 into slot 0 and into the operand registers; the top wave also transforms stage 1 into slot 1 and loads the
+  // pixels of stage 2 (the bottom wave does both in its first step). S2D: stages 0, 1 have phase 0, stages 2, 3 phase 1
+  W8_PIX(0, 0)
+  W8_ROW(0)
+  W8_PIX(1, 0)
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 0)
   W8_SYNC()
   {
-    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0);
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(0) * 16384);
 #pragma unroll
     for (int i = 0; i < 8; ++i) W8_RD(i, 0)
   }
   if (!ph) {
-    W8_ROW()
-    W8_PIX(2)
+    W8_ROW(0)
+    W8_PIX(2, 1)
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 1)
   }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- one step per stage k (SL = k & 1), ONE barrier each: behind barrier k every wave reads stage k + 1 into its operand
-  // registers from slot SL ^ 1 and brings its 4 weight pieces of stage k + 2 into slot SL; between barriers k and k + 1 it transforms
-  // its share of stage k + 2 (pixels loaded a step earlier) into slot SL and loads its pixels of stage k + 3. The two waves of a SIMD
-  // run 16 MFMAs apart — in lockstep both would leave the matrix pipe idle at the same time:
-  //   top    (ph 0): P0(k) | barrier k | R01 | P1(k) + transform k+2 | R23 | P2(k) + DMA | R45 | P3(k) | R67
-  //   bottom (ph 1): P0(k) + transform k+1 | P1(k) | barrier k | R01 R23 | P2(k) + DMA | R45 | P3(k) | R67
-  // (Pn = the 8 MFMAs of positions 2n, 2n+1; Rab = the operand reads of positions a, b for stage k + 1). Between two barriers the
-  // top wave's transform sits in the first quarter and the bottom wave's in the last but one; the bottom wave's barrier leaves its
-  // pixel loads in flight. All MFMAs of a step belong to stage k, so the S2D form specialises the step on the stage's phase.
-// the operand reads of two positions for the next stage (S2D: positions the next stage's phase drops are read all the same — stale
-// bytes that are never multiplied; a branch around register writes costs the allocator more than the read costs the LDS)
-#define W8_R2(i0, i1, SLR)                                                                            \
-    if (!(W8_ABL & 8)) { W8_RD(i0, SLR) W8_RD(i1, SLR) }                                              \
-    __builtin_amdgcn_sched_barrier(0);
-#define W8_R1(i0, SLR)                                                                                \
-    if (!(W8_ABL & 8)) { W8_RD(i0, SLR) }                                                             \
-    __builtin_amdgcn_sched_barrier(0);
-#define W8_XNONE(sl)
-// slots with the transform of stage xst_ into slot xsl_ and the pixel loads of stage xst_ + 1
-#define W8_XWORK(sl)                                                                                  \
-      if (sl == 0 && !(W8_ABL & 4)) { W8_ROW() }                                                      \
-      if (sl >= 1 && sl <= 4 && !(W8_ABL & 4)) { W8_COL(sl - 1, xsl_) }                               \
-      if (sl == 5) { W8_PIX(xst_ + 1) }   /* behind the column pass: the loads' 16 registers are the row pass's */
-// slots with the 4 weight pieces of stage dst_ into slot dsl_, one in every other slot
-#define W8_XDMA(sl)                                                                                   \
-      if (!(sl & 1)) { W8_DMAP(dst_, dsl_, sl >> 1) }
-// the bottom wave's barrier: everything but the 4 pixel loads it has just issued
-#define W8_SYNC_B()                                                                                   \
-  if (W8_ADIRECT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
-  else if (W8_ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                    \
-  else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                    \
-  __builtin_amdgcn_s_barrier();                                                                       \
-  asm volatile("" ::: "memory");
-// top    (positions i = x*4 + nu, xi = x):     always 0 1 2 4 5 6;  nu = 3 (3, 7) unless px
-// bottom (xi = 2 + x):                         always 0 1 2;  3 unless px;  4 5 6 unless py;  7 unless px or py
-#define W8_STEP(k, SL)                                                                                \
+  // registers (V from slot SL ^ 1); between barriers k and k + 1 it transforms its share of stage k + 2 (pixels loaded a step earlier)
+  // into slot SL and loads its pixels of stage k + 3. The two waves of a SIMD run 16 MFMAs apart:
+  //   top    (ph 0): M(0,1) | barrier k | R(0,1) | M(2,4) + transform k+2 | R(2,4) | M(5,6) | R(5,6) | M(3,7) | R(3,7)
+  //   bottom (ph 1): M(0,1) + transform k+1 | M(3) | barrier k | R(0,1) R(3) | M(2) | R(2) | M(4,5) | R(4,5) | M(6,7) | R(6,7)
+  // (M = the MFMAs of the listed positions i = x*4 + nu of stage k, R = their operand reads for stage k + 1). The blocks a phase can
+  // drop — nu = 3 in the top wave; 3, row xi = 3 = {4..7} in the bottom wave — carry none of the other roles.
+  // P0..P3: the phases of stages k .. k + 3 (S2D; compile-time)
+#define W8_STEP(k, SL, P0, P1, P2, P3)                                                                \
   {                                                                                                   \
-    const int pc_ = W8_PH(k);                                                                         \
-    const bool px_ = S2D && (pc_ & 1), py_ = S2D && (pc_ >> 1);                                       \
-    const int dst_ = (k) + 2; constexpr int dsl_ = (SL);                                              \
-    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + min((k) + 1, c8n - 1) * 16384);          \
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(min((k) + 1, c8n - 1)) * 16384);   \
     if (!ph) {                                                                                        \
-      const int xst_ = (k) + 2; constexpr int xsl_ = (SL);                                            \
-      W8_M2X(0, 1, W8_XNONE)                                                                          \
+      const int xst_ = (k) + 2; constexpr int xsl_ = (SL), xtp_ = (P2), xpp_ = (P3);                               \
+      W8_M2X(0, 1, P0, W8_XNONE)                                                                      \
       if (!(W8_ABL & 1)) { W8_SYNC() }                                                                \
-      W8_R2(0, 1, (SL) ^ 1)                                                                           \
-      W8_M2X(2, 4, W8_XWORK)                                                                          \
-      W8_R2(2, 4, (SL) ^ 1)                                                                           \
-      W8_M2X(5, 6, W8_XDMA)                                                                           \
-      W8_R2(5, 6, (SL) ^ 1)                                                                           \
-      if (!px_) { W8_M2X(3, 7, W8_XNONE) }                                                            \
-      W8_R2(3, 7, (SL) ^ 1)                                                                           \
+      W8_R2(0, 1, P1, (SL) ^ 1)                                                                       \
+      W8_M2X(2, 4, P0, W8_XWORK)                                                                      \
+      W8_R2(2, 4, P1, (SL) ^ 1)                                                                       \
+      W8_M2X(5, 6, P0, W8_XNONE)                                                                      \
+      W8_R2(5, 6, P1, (SL) ^ 1)                                                                       \
+      W8_M2X(3, 7, P0, W8_XNONE)                                                                      \
+      W8_R2(3, 7, P1, (SL) ^ 1)                                                                       \
     } else {                                                                                          \
-      const int xst_ = (k) + 1; constexpr int xsl_ = (SL) ^ 1;                                        \
-      W8_M2X(0, 1, W8_XWORK)                                                                          \
-      if (!px_) { W8_M1X(3, W8_XNONE) }                                                               \
-      if (!(W8_ABL & 1)) { W8_SYNC_B() }                                                              \
-      W8_R2(0, 1, (SL) ^ 1)                                                                           \
-      W8_R1(3, (SL) ^ 1)                                                                              \
-      W8_M1X(2, W8_XDMA)                                                                              \
-      W8_R1(2, (SL) ^ 1)                                                                              \
-      if (!py_) { W8_M2X(4, 5, W8_XNONE) }                                                            \
-      W8_R2(4, 5, (SL) ^ 1)                                                                           \
-      if (!py_) { if (!px_) { W8_M2X(6, 7, W8_XNONE) } else { W8_M1X(6, W8_XNONE) } }                 \
-      W8_R2(6, 7, (SL) ^ 1)                                                                           \
+      const int xst_ = (k) + 1; constexpr int xsl_ = (SL) ^ 1, xtp_ = (P1), xpp_ = (P2);                           \
+      W8_M2X(0, 1, P0, W8_XWORK)                                                                      \
+      W8_M1X(3, P0, W8_XNONE)                                                                         \
+      if (!(W8_ABL & 1)) { W8_SYNC() }                                                                \
+      W8_R2(0, 1, P1, (SL) ^ 1)                                                                       \
+      W8_R1(3, P1, (SL) ^ 1)                                                                          \
+      W8_M1X(2, P0, W8_XNONE)                                                                         \
+      W8_R1(2, P1, (SL) ^ 1)                                                                          \
+      W8_M2X(4, 5, P0, W8_XNONE)                                                                      \
+      W8_R2(4, 5, P1, (SL) ^ 1)                                                                       \
+      W8_M2X(6, 7, P0, W8_XNONE)                                                                      \
+      W8_R2(6, 7, P1, (SL) ^ 1)                                                                       \
     }                                                                                                 \
   }
-  {
+  if (!S2D) {
     int k = 0;
     for (; k + 2 <= c8n; k += 2) {
-      W8_STEP(k, 0)
-      W8_STEP(k + 1, 1)
+      W8_STEP(k, 0, 0, 0, 0, 0)
+      W8_STEP(k + 1, 1, 0, 0, 0, 0)
     }
-    if (k < c8n) W8_STEP(k, 0)
+    if (k < c8n) W8_STEP(k, 0, 0, 0, 0, 0)
+  } else {   // c8n % 8 == 0 (the launcher checks): phases 0 0 1 1 2 2 3 3 | 0 0 ...
+    for (int k = 0; k < c8n; k += 8) {
+      W8_STEP(k, 0, 0, 0, 1, 1)
+      W8_STEP(k + 1, 1, 0, 1, 1, 2)
+      W8_STEP(k + 2, 0, 1, 1, 2, 2)
+      W8_STEP(k + 3, 1, 1, 2, 2, 3)
+      W8_STEP(k + 4, 0, 2, 2, 3, 3)
+      W8_STEP(k + 5, 1, 2, 3, 3, 0)
+      W8_STEP(k + 6, 0, 3, 3, 0, 0)
+      W8_STEP(k + 7, 1, 3, 0, 0, 1)
+    }
   }
 #undef W8_STEP
-#undef W8_SYNC_B
-#undef W8_XDMA
 #undef W8_XWORK
 #undef W8_XNONE
 #undef W8_R1
 #undef W8_R2
 #undef W8_M1X
 #undef W8_M2X
-#undef W8_DMAP
 #undef W8_MFMA
 #undef W8_RD
 #undef W8_COL
 #undef W8_FMACD
 #undef W8_ROW
 #undef W8_PIX
-#undef W8_DMA
-#undef W8_DMA1
-#undef W8_PH
+#undef W8_ACT
+#undef W8_CB
 
   // ---- output transform. acc[x*4 + nu][r] with xi = 2ph + x: channel (r&3) + 8(r>>2) + 4·lrow of the wave's 32, tile lcol.
   // s[xi][0] = (m0 + m1) + m2, s[xi][1] = (m1 - m2) - m3; Y[0][b] = ((s0 + s1) + s2) + bias, Y[1][b] = ((s1 - s2) - s3) + bias.
@@ -1054,26 +1011,20 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
   const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
-  // (the stride-2 layers stay on the one-wave kernel: with the zero positions skipped behind wave-uniform branches the compiler moves
-  // this kernel's accumulator tuples between the arms and spills them; ctx->wino_shared == 2 forces it for measurements)
-  const bool shared = !two_wave && (ctx->wino_shared == 2 || (ctx->wino_shared && !s2d)) && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel on 64 channels x 64 tiles
+  const bool shared = !two_wave && ctx->wino_shared && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel on 64 channels x 64 tiles
   p.gx = di_div_up(p.ntiles, (two_wave || shared) ? 64 : 128);
   p.gy = shared ? Cout / 64 : Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
-  p.lnpb = 0;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   int grid = p.gx * p.gy;
   if (shared) {
     // block -> (channel block, tile block) as conv_wino8_kernel maps it: gy < 8 dividing 8 deals 8 / gy XCDs to each channel block
     if ((p.gy & 7) != 0 && (8 % p.gy) == 0) grid = 8 * di_div_up(p.gx, 8 / p.gy);
-    // phase-by-phase skipping needs whole 8-channel blocks per input phase, a power of two of them (the phase of a stage is a shift)
-    const int npb = Cin / 32;
-    const bool ph8 = s2d && (Cin % 32) == 0 && (npb & (npb - 1)) == 0 && ctx->wino_s2d_skip;
-    p.lnpb = 0;
-    while (ph8 && (1 << p.lnpb) < npb) ++p.lnpb;
+    // the zero positions are dropped along an interleaved walk of the four input phases: two 8-channel blocks of each per loop body
+    const bool ph8 = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
     if (ph8) {
       if (out_nc8) conv_wino8_kernel<1, 1><<<grid, 512, 0, ctx->stream>>>(p);
       else conv_wino8_kernel<0, 1><<<grid, 512, 0, ctx->stream>>>(p);
