@@ -565,18 +565,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W8_QS 2320                       /* V: bytes per position: 2 tile halves x 2 k halves x (512 + 64 pad) + 16 */
 #define W8_HS 576
 #define W8_TGS 1152
-#define W8_VSLOT (16 * W8_QS)            /* 37 120 B; every offset of either slot fits the ds instructions' 16-bit immediate */
-#define W8_LDS_BYTES (2 * W8_VSLOT)      /* 74 240 B (the output exchange reuses the first 64 KB) */
+#define W8_QSW 1168                      /* WIDE: one tile half */
+#define W8_LDS_BYTES (2 * 16 * W8_QS)     /* 74 240 B: two V slots of 37 120 B — every offset of either slot fits the ds 16-bit immediate; the output exchange reuses the first 64 KB */
 
 // PH: the wave's half (0 top: xi = 0, 1; 1 bottom: xi = 2, 3) as a COMPILE-TIME constant — the two halves run different streams, and
 // with the choice behind run-time branches inside one body the register allocator cannot keep the accumulator tuples in place
 // across the joins (hundreds of scratch spills); the kernel branches once, at its top, into two complete bodies.
-template <int OUT_NC8, int S2D, int PH>
+// WIDE: the block is 128 output channels x 32 tiles instead of 64 x 64 (every V feeds 128 channels: half the transform work per MFMA,
+// a lane of the transform owns TWO channels of a patch column; the weights of a step are read once per 32 tiles instead of per 64)
+template <int OUT_NC8, int S2D, int PH, int WIDE>
 __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   constexpr int ph = PH;
-  const int mh = wave & 1, tg = (wave >> 1) & 1;
+  constexpr int NSUB = WIDE ? 4 : 2;          // 32-channel sub-blocks of the block
+  constexpr int TB = WIDE ? 32 : 64;          // tiles of the block
+  constexpr int QS = WIDE ? W8_QSW : W8_QS;   // V bytes per position
+  constexpr int VSLOT = 16 * QS;
+  using tvec = typename std::conditional<WIDE != 0, f32x2, f32x4>::type;   // a transform lane's channels
+  const int msub = WIDE ? (wave & 3) : (wave & 1), tg = WIDE ? 0 : (wave >> 1) & 1;
   const int lrow = lane >> 5, lcol = lane & 31;
   int mb2, bx;
   {
@@ -599,11 +606,11 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int c8n = p.Cin >> 3;
   const int hw32 = p.H * p.W * 32;
 
-  // ---- transform role: lane = (tile Tl of the block's 64, k half hT, patch column j)
-  const int j = lane & 3, hT = (lane >> 2) & 1, Tl = wave * 8 + (lane >> 3);
+  // ---- transform role: lane = (tile Tl of the block's TB, channel group cg of the 8 — 2 groups of 4 / WIDE: 4 groups of 2 —, patch column j)
+  const int j = lane & 3, cg = WIDE ? (lane >> 2) & 3 : (lane >> 2) & 1, Tl = WIDE ? wave * 4 + (lane >> 4) : wave * 8 + (lane >> 3);
   int voffT[4];
   {
-    const int tT = bx * 64 + Tl;
+    const int tT = bx * TB + Tl;
     const bool tv = tT < p.ntiles;
     const int n = tv ? tT / tpi : 0;
     const int tr = tv ? tT - n * tpi : 0;
@@ -613,15 +620,17 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     for (int i = 0; i < 4; ++i) {
       const int y = 2 * ty - 1 + i;
       const bool ok = tv && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      voffT[i] = ok ? (((n * c8n) * p.H + y) * p.W + x) * 32 + hT * 16 : (int)0x80000000;
+      voffT[i] = ok ? (((n * c8n) * p.H + y) * p.W + x) * 32 + cg * (WIDE ? 8 : 16) : (int)0x80000000;
     }
   }
   const float sgn = j == 1 ? 1.f : -1.f;
-  const unsigned vw = (unsigned)((Tl >> 5) * W8_TGS + hT * W8_HS + (Tl & 31) * 16 + j * W8_QS);
+  // V of a position: [tile half][k half h][tile][16 B = channels 4h .. 4h+3] (+ pads: the 8 / 16 lanes of a store group hit 32 banks)
+  const unsigned vw = WIDE ? (unsigned)((cg >> 1) * W8_HS + (cg & 1) * 8 + Tl * 16 + j * QS)
+                           : (unsigned)((Tl >> 5) * W8_TGS + cg * W8_HS + (Tl & 31) * 16 + j * QS);
   // ---- multiply role
-  const unsigned rb = (unsigned)(ph * 8 * W8_QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
+  const unsigned rb = (unsigned)(ph * 8 * QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
   const int ra_g = lane * 16 + ph * 8192;                  // this lane's 16 bytes of position 8 ph + i at + i * 1024 ...
-  const int ra_s0 = ((mb2 * 2 + mh) * c8n) * 16384;         // ... of the channel half's 16 KB per 8-channel block
+  const int ra_s0 = ((mb2 * NSUB + msub) * c8n) * 16384;    // ... of the 32-channel sub-block's 16 KB per 8-channel block
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
 
@@ -630,7 +639,8 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   for (int q = 0; q < 8; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-  f32x4 raw[4], T[4], A[8], Bv[8];
+  tvec raw[4], T[4];
+  f32x4 A[8], Bv[8];
 
   // S2D: the s2d tensor holds the input phases (py, px) as four runs of Cin/4 channels = npb 8-channel blocks each; positions xi = 3
   // (py) / nu = 3 (px) of a phase's blocks vanish. Stage s of the K walk is block W8_CB(s): phases interleaved two blocks at a time,
@@ -647,14 +657,16 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   if (!(W8_ABL & 4)) {                                                                                \
     const int st_ = min((stage), c8n - 1);                                                            \
     const int so_ = __builtin_amdgcn_readfirstlane(W8_CB(st_) * hw32);                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                                  \
-      raw[i_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[i_], so_, 0)); \
-    if (!(S2D && ((P) >> 1))) raw[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[3], so_, 0)); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
+      if (i_ < 3 || !(S2D && ((P) >> 1))) {                                                           \
+        if constexpr (WIDE) raw[i_] = __builtin_bit_cast(tvec, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffT[i_], so_, 0)); \
+        else raw[i_] = __builtin_bit_cast(tvec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffT[i_], so_, 0)); \
+      }                                                                                               \
   }
 #define W8_ROW(P)                                                                                     \
   {                                                                                                   \
-    T[0] = wsub(raw[0], raw[2]); T[1] = wadd(raw[1], raw[2]); T[2] = wsub(raw[2], raw[1]);            \
-    if (!(S2D && ((P) >> 1))) T[3] = wsub(raw[1], raw[3]);                                            \
+    T[0] = raw[0] - raw[2]; T[1] = raw[1] + raw[2]; T[2] = raw[2] - raw[1];                           \
+    if (!(S2D && ((P) >> 1))) T[3] = raw[1] - raw[3];                                                 \
   }
 // column pass of row xi across the quad, IN PLACE: lane j holds t_j and needs (t0 - t2, t1 + t2, t2 - t1, t3 - t1)[j] (nu = 3 negated, as
 // packed) = self + sgn * T[lane (2, 2, 1, 1)[j]], sgn = (-1, +1, -1, -1): one v_fmac_f32 with a DPP quad_perm source per value.
@@ -663,18 +675,26 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(sgn));
 #define W8_COL(xi, slot_)                                                                             \
   {                                                                                                   \
-    float c0_ = T[xi].x, c1_ = T[xi].y, c2_ = T[xi].z, c3_ = T[xi].w;                                 \
-    asm volatile("s_nop 1");                                                                          \
-    W8_FMACD(c0_) W8_FMACD(c1_) W8_FMACD(c2_) W8_FMACD(c3_)                                           \
-    f32x4 v_; v_.x = c0_; v_.y = c1_; v_.z = c2_; v_.w = c3_;                                         \
-    W8_LDS4(vw + (unsigned)((slot_) * W8_VSLOT + (xi) * 4 * W8_QS)) = v_;                              \
+    if constexpr (WIDE) {                                                                             \
+      float c0_ = T[xi].x, c1_ = T[xi].y;                                                             \
+      asm volatile("s_nop 1");                                                                        \
+      W8_FMACD(c0_) W8_FMACD(c1_)                                                                     \
+      f32x2 v_; v_.x = c0_; v_.y = c1_;                                                               \
+      *reinterpret_cast<f32x2*>(smem + (vw + (unsigned)((slot_) * VSLOT + (xi) * 4 * QS))) = v_;      \
+    } else {                                                                                          \
+      float c0_ = T[xi][0], c1_ = T[xi][1], c2_ = T[xi][2 % (WIDE ? 2 : 4)], c3_ = T[xi][3 % (WIDE ? 2 : 4)]; \
+      asm volatile("s_nop 1");                                                                        \
+      W8_FMACD(c0_) W8_FMACD(c1_) W8_FMACD(c2_) W8_FMACD(c3_)                                         \
+      f32x4 v_; v_.x = c0_; v_.y = c1_; v_.z = c2_; v_.w = c3_;                                       \
+      W8_LDS4(vw + (unsigned)((slot_) * VSLOT + (xi) * 4 * QS)) = v_;                                 \
+    }                                                                                                 \
   }
 // operands of position i for the stage whose weights sit at scalar offset rsa_: the weights straight from global memory (L1 / L2:
 // the two tile halves of a channel half read the same bytes), V from LDS slot slot_
 #define W8_RD(i, slot_)                                                                               \
   {                                                                                                   \
     A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0)); \
-    Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * W8_VSLOT + (i) * W8_QS));                               \
+    Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * VSLOT + (i) * QS));                                     \
   }
 #define W8_MFMA(i, s_)                                                                                \
   acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) == 0 ? A[i].x : (s_) == 1 ? A[i].y : (s_) == 2 ? A[i].z : A[i].w, \
@@ -820,14 +840,14 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   asm volatile("" : "+s"(bxe), "+s"(mb2e), "+s"(tpie), "+s"(TXe));
   const int lanee = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int lrow_e = lanee >> 5, lcol_e = lanee & 31;
-  const int t = bxe * 64 + tg * 32 + lcol_e;
+  const int t = bxe * TB + tg * 32 + lcol_e;
   const bool tvalid = t < p.ntiles;
   const int n = tvalid ? t / tpie : 0;
   const int trm = tvalid ? t - n * tpie : 0;
   const int ty = trm / TXe, tx = trm - ty * TXe;
   const int y0 = 2 * ty, x0 = 2 * tx;
   const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
-  const int mb = mb2e * 2 + mh;
+  const int mb = mb2e * NSUB + msub;
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
   const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ 4) * 2048 + lanee;
   // whole-vector forms: reading single elements of an AGPR-resident f32x16 makes the compiler copy all 16 registers each time
@@ -899,13 +919,13 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_LDS4
 }
 
-template <int OUT_NC8, int S2D>
+template <int OUT_NC8, int S2D, int WIDE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // waves w and w + 4 share a SIMD: a top and a bottom half each
-  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0>(p, smem, wave);
-  else wino8_body<OUT_NC8, S2D, 1>(p, smem, wave);
+  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, WIDE>(p, smem, wave);
+  else wino8_body<OUT_NC8, S2D, 1, WIDE>(p, smem, wave);
 }
 
 // U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
@@ -1011,9 +1031,10 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
   p.ntiles = B * p.TY * p.TX;
   const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
-  const bool shared = !two_wave && ctx->wino_shared && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel on 64 channels x 64 tiles
-  p.gx = di_div_up(p.ntiles, (two_wave || shared) ? 64 : 128);
-  p.gy = shared ? Cout / 64 : Cout / 32;
+  const bool shared = !two_wave && ctx->wino_shared && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel
+  const bool wide = shared && (Cout & 127) == 0 && ctx->wino_wide != 0;    // on 128 channels x 32 tiles (else 64 x 64)
+  p.gx = di_div_up(p.ntiles, wide ? 32 : (two_wave || shared) ? 64 : 128);
+  p.gy = wide ? Cout / 128 : shared ? Cout / 64 : Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
@@ -1025,13 +1046,15 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     if ((p.gy & 7) != 0 && (8 % p.gy) == 0) grid = 8 * di_div_up(p.gx, 8 / p.gy);
     // the zero positions are dropped along an interleaved walk of the four input phases: two 8-channel blocks of each per loop body
     const bool ph8 = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
+#define W8_LAUNCH(O, S)                                                                               \
+    if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                           \
+    else conv_wino8_kernel<O, S, 0><<<grid, 512, 0, ctx->stream>>>(p);
     if (ph8) {
-      if (out_nc8) conv_wino8_kernel<1, 1><<<grid, 512, 0, ctx->stream>>>(p);
-      else conv_wino8_kernel<0, 1><<<grid, 512, 0, ctx->stream>>>(p);
+      if (out_nc8) { W8_LAUNCH(1, 1) } else { W8_LAUNCH(0, 1) }
     } else {
-      if (out_nc8) conv_wino8_kernel<1, 0><<<grid, 512, 0, ctx->stream>>>(p);
-      else conv_wino8_kernel<0, 0><<<grid, 512, 0, ctx->stream>>>(p);
+      if (out_nc8) { W8_LAUNCH(1, 0) } else { W8_LAUNCH(0, 0) }
     }
+#undef W8_LAUNCH
     DI_LAUNCH_CHECK();
     return 0;
   }

@@ -10,6 +10,8 @@ cf = ctypes.c_float
 rng = np.random.default_rng(0)
 LAYERS = [("conv3_1", 256, 60, 80, 256), ("conv4_1", 512, 30, 40, 512), ("conv5_1", 512, 15, 20, 512), ("conv6_1", 1024, 8, 10, 1024)]
 ROUNDS, REPS = 3, 5
+WIDE0 = int(os.environ.get('WINO_WIDE', '1'))
+lib.deepim_set_option(ctx.handle, b'wino_wide', WIDE0)
 ONLY = os.environ.get("WINO_LAYERS", "").split(",") if os.environ.get("WINO_LAYERS") else None
 for name, cin, H, W, cout in LAYERS:
     if ONLY and name not in ONLY:
@@ -27,8 +29,8 @@ for name, cin, H, W, cout in LAYERS:
     out8 = 0 if name == "conv6_1" else 1
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x, pk, bias, B, cin, H, W, cout, 3, 3, 1, 1, cf(0.1), 0, 0, 1, out8)
     wino = lambda: lib.deepim_conv2d_wino_forward(ctx.handle, o2, x, pw, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
-    def wino1():   # the round-4 one-wave kernel
-        lib.deepim_set_option(ctx.handle, b"wino_shared", 0); wino(); lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
+    def wino1():   # the other block shape (128 channels x 32 tiles if the default is 64 x 64, and vice versa)
+        lib.deepim_set_option(ctx.handle, b"wino_wide", 1 - WIDE0); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
     direct(); wino()
     a, b = o1.asnumpy(), o2.asnumpy()
     err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
@@ -45,7 +47,7 @@ for name, cin, H, W, cout in LAYERS:
     fl = 2.0 * cout * cin * 9 * H * W * B
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
     fle = 2.0 * cout * cin * 16 * tiles
-    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range | one-wave kernel (round 4) %.3f ms"
+    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range | other block shape %.3f ms"
           % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err, w1))
 # the 5x5 stride-2 layers: direct NC8 kernel vs the Winograd kernel over the space-to-depth input (zero positions skipped / not skipped)
 for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 160, 256)]:
@@ -68,8 +70,8 @@ for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 
     o1, o2 = ctx.empty((B, cout, Ho, Wo)), ctx.empty((B, cout, Ho, Wo))
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x8, pk, bias, B, cin, H, W, cout, 5, 5, 2, 2, cf(0.1), 0, 0, 1, 1)
     wino = lambda: lib.deepim_conv2d_wino_forward_s2d(ctx.handle, o2, xs, pw, bias, B, cin, H, W, cout, cf(0.1), 1, 0, 0)
-    def wino_full():   # the round-4 one-wave kernel (zero positions skipped there too)
-        lib.deepim_set_option(ctx.handle, b"wino_shared", 0); wino(); lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
+    def wino_full():   # the other block shape
+        lib.deepim_set_option(ctx.handle, b"wino_wide", 1 - WIDE0); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
     direct(); wino()
     a, b = o1.asnumpy(), o2.asnumpy()
     err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
@@ -84,5 +86,5 @@ for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 
             ts.setdefault(key, []).append(t.elapsed_ms() / REPS)
     d, wv, wf = (float(np.median(ts[k])) for k in ("direct", "wino", "full"))
     fl = 2.0 * cout * cin * 25 * Ho * Wo * B
-    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd over space-to-depth %.3f ms  %5.1f TF algorithmic | x%.2f | max diff %.1e of range | one-wave kernel (round 4) %.3f ms"
+    print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd over space-to-depth %.3f ms  %5.1f TF algorithmic | x%.2f | max diff %.1e of range | other block shape %.3f ms"
           % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, d / wv, err, wf))
