@@ -3,9 +3,12 @@
 // Same fp32 arithmetic as the direct kernels, 2.25x fewer multiplies: per 2x2 output tile and channel the 4x4 input patch d
 // becomes V = B^T d B, the 3x3 kernel g becomes U = G g G^T (packed once), the sixteen positions (xi, nu) are sixteen
 // independent GEMMs M = U·V over the input channels, and the tile is Y = A^T M A. Results differ from the direct sum in the
-// last bits (bounded by the tests at 1e-5 of the layer's range), so the layers take this path only on request
-// (deepim_set_option "conv_winograd" via the host class) and never in the canonical-order parity configuration.
+// last bits (bounded by the tests at 1e-5 of the layer's range). The host class asks deepim_conv_wino_preferred[_s2d] per layer at
+// bind time (network.WINOGRAD_CONV, default on); a context in the canonical-order configuration (conv_max_split = 1: every sum one
+// fmaf chain, bit-exact against the oracle) gets 0 from it. Which layers qualify, and the K-split plan of the shared-transform kernel,
+// depend on the batch size — so does the rounding of a sample's output (never its 1e-5 bound).
 //
+// conv_wino_kernel (round 4; now the fallback for Cout % 64 != 0):
 // One kernel, no LDS, no intermediate tensor in HBM:
 //   * a wave owns 32 output channels x 32 tiles x ALL 16 positions: sixteen 32x32 accumulators = 256 AGPRs, one wave per SIMD
 //     (the 512-register budget of gfx950 at occupancy 1); the MFMAs of one position are independent of the next, so a single
@@ -37,6 +40,10 @@ struct WinoParams {
   unsigned in_bytes, wd_bytes;
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
+  // conv_wino8_kernel, split over the input channels: slice = blockIdx.x / grid0 walks the 8-channel blocks [slice*kslice, +kslice) and
+  // writes its raw sums (no bias, no activation) to out + slice*part_stride — `out` is then the partial buffer, wino_reduce_kernel finishes
+  int grid0, kslice, ksplit;
+  long part_stride;
 };
 
 #ifndef WINO_ABL
@@ -587,7 +594,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int lrow = lane >> 5, lcol = lane & 31;
   int mb2, bx;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int bid = blockIdx.x % p.grid0, xcd = bid & 7, idx = bid >> 3;
     if ((p.gy & 7) == 0) {          // XCD x owns the channel blocks [x·gy/8, (x+1)·gy/8): its slice of U stays in its L2
       const int per = p.gy >> 3;
       mb2 = xcd * per + idx % per;
@@ -603,7 +610,9 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
   if (bx >= p.gx) return;
   const int tpi = p.TY * p.TX;
-  const int c8n = p.Cin >> 3;
+  const int c8n = p.Cin >> 3;                               // 8-channel blocks of the input: strides
+  const int slice = blockIdx.x / p.grid0;                   // this block's share of them: stages [kb, ke)
+  const int kb = slice * p.kslice, ke = min(c8n, kb + p.kslice);
   const int hw32 = p.H * p.W * 32;
 
   // ---- transform role: lane = (tile Tl of the block's TB, channel group cg of the 8 — 2 groups of 4 / WIDE: 4 groups of 2 —, patch column j)
@@ -655,7 +664,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 // (Column 3 feeds only nu = 3 as well; masking those lanes would cost 4 vector ORs per step, more than their L1 hits.)
 #define W8_PIX(stage, P)                                                                              \
   if (!(W8_ABL & 4)) {                                                                                \
-    const int st_ = min((stage), c8n - 1);                                                            \
+    const int st_ = min((stage), ke - 1);                                                             \
     const int so_ = __builtin_amdgcn_readfirstlane(W8_CB(st_) * hw32);                                \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                  \
       if (i_ < 3 || !(S2D && ((P) >> 1))) {                                                           \
@@ -736,20 +745,20 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 
   // ---- prologue: stage 0 into slot 0 and into the operand registers; the top wave also transforms stage 1 into slot 1 and loads the
   // pixels of stage 2 (the bottom wave does both in its first step). S2D: stages 0, 1 have phase 0, stages 2, 3 phase 1
-  W8_PIX(0, 0)
+  W8_PIX(kb, 0)
   W8_ROW(0)
-  W8_PIX(1, 0)
+  W8_PIX(kb + 1, 0)
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 0)
   W8_SYNC()
   {
-    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(0) * 16384);
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(kb) * 16384);
 #pragma unroll
     for (int i = 0; i < 8; ++i) W8_RD(i, 0)
   }
   if (!ph) {
     W8_ROW(0)
-    W8_PIX(2, 1)
+    W8_PIX(kb + 2, 1)
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 1)
   }
@@ -765,7 +774,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   // P0..P3: the phases of stages k .. k + 3 (S2D; compile-time)
 #define W8_STEP(k, SL, P0, P1, P2, P3)                                                                \
   {                                                                                                   \
-    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(min((k) + 1, c8n - 1)) * 16384);   \
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(min((k) + 1, ke - 1)) * 16384);   \
     if (!ph) {                                                                                        \
       const int xst_ = (k) + 2; constexpr int xsl_ = (SL), xtp_ = (P2), xpp_ = (P3);                               \
       W8_M2X(0, 1, P0, W8_XNONE)                                                                      \
@@ -793,14 +802,14 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     }                                                                                                 \
   }
   if (!S2D) {
-    int k = 0;
-    for (; k + 2 <= c8n; k += 2) {
+    int k = kb;   // kb is even (the launcher's slices are): SL = k & 1
+    for (; k + 2 <= ke; k += 2) {
       W8_STEP(k, 0, 0, 0, 0, 0)
       W8_STEP(k + 1, 1, 0, 0, 0, 0)
     }
-    if (k < c8n) W8_STEP(k, 0, 0, 0, 0, 0)
-  } else {   // c8n % 8 == 0 (the launcher checks): phases 0 0 1 1 2 2 3 3 | 0 0 ...
-    for (int k = 0; k < c8n; k += 8) {
+    if (k < ke) W8_STEP(k, 0, 0, 0, 0, 0)
+  } else {   // kb % 8 == 0 and (ke - kb) % 8 == 0 (the launcher checks): phases 0 0 1 1 2 2 3 3 | 0 0 ...
+    for (int k = kb; k < ke; k += 8) {
       W8_STEP(k, 0, 0, 0, 1, 1)
       W8_STEP(k + 1, 1, 0, 1, 1, 2)
       W8_STEP(k + 2, 0, 1, 1, 2, 2)
@@ -848,6 +857,10 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int y0 = 2 * ty, x0 = 2 * tx;
   const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
   const int mb = mb2e * NSUB + msub;
+  // a slice of a split K loop writes raw sums to its own copy of the output; bias and activation wait for wino_reduce_kernel
+  float* const outp = p.out + (long)slice * p.part_stride;
+  const float* const biasp = p.ksplit > 1 ? nullptr : p.bias;
+  const float slope_e = p.ksplit > 1 ? 1.f : p.slope;
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
   const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ 4) * 2048 + lanee;
   // whole-vector forms: reading single elements of an AGPR-resident f32x16 makes the compiler copy all 16 registers each time
@@ -872,7 +885,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   {                                                                                                   \
       float4 bq[2];                                                                                   \
       _Pragma("unroll") for (int gg = 0; gg < 2; ++gg)                                                \
-        bq[gg] = p.bias ? *reinterpret_cast<const float4*>(p.bias + mb * 32 + 8 * ((PHC) * 2 + gg) + 4 * lrow_e) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        bq[gg] = biasp ? *reinterpret_cast<const float4*>(biasp + mb * 32 + 8 * ((PHC) * 2 + gg) + 4 * lrow_e) : make_float4(0.f, 0.f, 0.f, 0.f); \
       _Pragma("unroll") for (int gg = 0; gg < 2; ++gg) {                                              \
         const int g = (PHC) * 2 + gg;                                                                 \
         float o[4][4];                                                                                \
@@ -886,8 +899,8 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
             const float s2 = (PHC) ? mine0 : oth0, s3 = (PHC) ? mine1 : oth1;                         \
             float v0 = ((s0 + s1) + s2) + bv;                                                         \
             float v1 = ((s1 - s2) - s3) + bv;                                                         \
-            o[0 * 2 + b][e] = v0 > 0.f ? v0 : v0 * p.slope;                                           \
-            o[1 * 2 + b][e] = v1 > 0.f ? v1 : v1 * p.slope;                                           \
+            o[0 * 2 + b][e] = v0 > 0.f ? v0 : v0 * slope_e;                                           \
+            o[1 * 2 + b][e] = v1 > 0.f ? v1 : v1 * slope_e;                                           \
           }                                                                                           \
         }                                                                                             \
         _Pragma("unroll") for (int ab = 0; ab < 4; ++ab) {                                            \
@@ -900,10 +913,10 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
               rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * TXe) + ty * TXe + tx; \
             else                                                                                      \
               rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;                         \
-            *reinterpret_cast<float4*>(p.out + rec * 8 + 4 * lrow_e) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]); \
+            *reinterpret_cast<float4*>(outp + rec * 8 + 4 * lrow_e) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]); \
           } else {                                                                                    \
             const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow_e;         \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) p.out[(c0 + e) * p.H * p.W + pix] = o[ab][e]; \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) outp[(c0 + e) * p.H * p.W + pix] = o[ab][e]; \
           }                                                                                           \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -926,6 +939,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // waves w and w + 4 share a SIMD: a top and a bottom half each
   if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, WIDE>(p, smem, wave);
   else wino8_body<OUT_NC8, S2D, 1, WIDE>(p, smem, wave);
+}
+
+// Second pass of a split K loop of conv_wino8_kernel: sums the S raw copies (same layout as the output), adds the bias, applies the
+// LeakyReLU. nc8: channel-blocked output (float4 = 4 consecutive channels; space-to-depth order keeps the channel of a record:
+// C8 = 4 phases x C8mod blocks); else NCHW into channels [coff, coff + Cout) of a ctotal-channel tensor (partials dense).
+__global__ __launch_bounds__(256) void wino_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial, const float* __restrict__ bias,
+                                                          long total, long stride, int S, float slope, int nc8, int C8, int hw, int C8mod,
+                                                          int Cout, int ctotal, int coff) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  if (nc8) {
+    float4 v = reinterpret_cast<const float4*>(partial)[i];
+    for (int s = 1; s < S; ++s) {
+      const float4 w = reinterpret_cast<const float4*>(partial + (long)s * stride)[i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const int c = (int)(((i / (2L * hw)) % C8) % C8mod) * 8 + (int)(i & 1) * 4;
+    const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0, 0, 0, 0);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+    reinterpret_cast<float4*>(out)[i] = v;
+  } else {
+    float v = partial[i];
+    for (int s = 1; s < S; ++s) v += partial[(long)s * stride + i];
+    const int r = (int)(i % hw), c = (int)((i / hw) % Cout);
+    const long n = i / ((long)hw * Cout);
+    v += bias ? bias[c] : 0.f;
+    out[(n * ctotal + coff + c) * hw + r] = v > 0.f ? v : v * slope;
+  }
+}
+
+// K-split plan of conv_wino8_kernel for a grid of `blocks` full-K blocks of nK steps on the chip's 256 CUs (one block per CU at a
+// time): S slices of ks steps each so that blocks x S fills whole rounds; cost model = rounds x (steps + per-block prologue/epilogue,
+// ~6 steps' worth) + the second pass (S + 1 passes over the output at ~4 TB/s, in steps of ~1.7 us). Deterministic: a function of
+// the geometry only. step_granule: 2 (slot parity) or 8 (the stride-2 form's loop body).
+static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb, int max_split, int* kslice) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int S = 1; S <= 16; ++S) {
+    if (max_split > 0 && S > max_split) break;
+    int ks = di_div_up(di_div_up(nK, S), step_granule) * step_granule;
+    if (S > 1 && ks < 8) break;
+    const int Seff = di_div_up(nK, ks);
+    if (Seff != S) continue;
+    const double rounds = (double)di_div_up(blocks * S, 256);
+    double cost = rounds * (ks + 6.0);
+    if (S > 1) cost += (S + 1) * out_mb / 4000.0 / 1.7e-3 + 1.5;   // MB / (MB per ms) -> ms -> steps; + a launch boundary
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = S; *kslice = ks; }
+  }
+  if (best == 1) *kslice = nK;
+  return best;
 }
 
 // U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
@@ -963,33 +1028,40 @@ extern "C" size_t deepim_conv_wino_packed_size(int Cout, int Cin) {
   return (size_t)Cout * Cin * 16 * sizeof(float);
 }
 
-// Whether the layer should take this kernel: it needs enough 32-channel x 128-tile blocks to occupy the chip — there is no split
-// over the input channels, a block walks all of Cin (measured, tools/bench_wino.py: 160 blocks and more win 1.3-1.9x over the
-// direct kernel, 48 and fewer lose to its split-K plans).
+// Whether the layer should take the Winograd path. Cout % 64 == 0 (every encoder layer): the shared-transform kernel splits the input
+// channels where the grid would not fill the chip, so it pays from two tile blocks on (measured at B = 4 / 8 / 32, tools/bench_wino.py:
+// 1.45-2.1x over the direct kernels on every layer, conv5_1 / conv6_1 at B = 4 included); other channel counts fall back to the
+// one-wave kernel, which walks all of Cin per block and needs >= 128 (stride-2 form: 256) blocks of 32 channels x 128 tiles.
+// conv_max_split == 1 is the canonical-summation-order configuration (bit-exact against the oracle's default order): no Winograd there.
 #ifndef WINO_MIN_BLOCKS
 #define WINO_MIN_BLOCKS 128
 #endif
-// (stride-2 layers over the space-to-depth input: 2.04x fewer multiplies with the zero positions skipped; measured with 1024 and
-// 256: at B = 4 — conv2 600 blocks, conv3 304 — 2 935 vs 3 117 it/s, at B = 8 3 519 vs 3 753)
 #ifndef WINO_MIN_BLOCKS_S2D
 #define WINO_MIN_BLOCKS_S2D 256
+#endif
+#ifndef WINO_MIN_TILES
+#define WINO_MIN_TILES 64
 #endif
 static long wino_blocks(int B, int H, int W, int Cout) {
   const long tiles = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
   return (long)di_div_up(tiles, 128) * (Cout / 32);
 }
+static int wino_pays(deepim_ctx* ctx, int B, int H, int W, int Cout, long min_blocks) {
+  if (ctx && ctx->conv_max_split == 1) return 0;
+  if ((!ctx || (ctx->wino_shared && !ctx->wino_two_wave)) && (Cout & 63) == 0)   // (no context: the defaults)
+    return (long)B * ((H + 1) / 2) * ((W + 1) / 2) >= WINO_MIN_TILES ? 1 : 0;
+  return wino_blocks(B, H, W, Cout) >= min_blocks ? 1 : 0;
+}
 extern "C" int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
-  (void)ctx;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7)) return 0;
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;   // one buffer descriptor per launch: larger inputs stay on the direct kernels (sub-batched there)
-  return wino_blocks(B, H, W, Cout) >= WINO_MIN_BLOCKS ? 1 : 0;
+  return wino_pays(ctx, B, H, W, Cout, WINO_MIN_BLOCKS);
 }
 // the same question for a 5x5 stride-2 pad-2 layer with input (B, Cin, H, W) run over its space-to-depth form
 extern "C" int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
-  (void)ctx;
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7) || ((H | W) & 1)) return 0;
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;
-  return wino_blocks(B, H / 2, W / 2, Cout) >= WINO_MIN_BLOCKS_S2D ? 1 : 0;
+  return wino_pays(ctx, B, H / 2, W / 2, Cout, WINO_MIN_BLOCKS_S2D);
 }
 
 extern "C" int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin) {
@@ -1039,6 +1111,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
+  p.grid0 = 1; p.kslice = Cin / 8; p.ksplit = 1; p.part_stride = 0;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   int grid = p.gx * p.gy;
   if (shared) {
@@ -1046,6 +1119,21 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     if ((p.gy & 7) != 0 && (8 % p.gy) == 0) grid = 8 * di_div_up(p.gx, 8 / p.gy);
     // the zero positions are dropped along an interleaved walk of the four input phases: two 8-channel blocks of each per loop body
     const bool ph8 = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
+    // under-filled grids split the input channels (conv5_1 / conv6_1 at B = 32, every layer at the per-GPU shares of an 8-GPU node)
+    const int nK = Cin / 8;
+    const size_t out_elems = (size_t)B * Cout * H * W;
+    int ks = nK;
+    const int S = ctx->wino_split == 1 ? 1 : wino8_split_plan(grid, nK, ph8 ? 8 : 2, out_elems * 4 / 1e6, ctx->wino_split, &ks);
+    p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0;
+    float* final_out = out;
+    if (S > 1) {
+      void* scr = nullptr;
+      if (deepim_scratch(ctx, (size_t)S * out_elems * 4, &scr) != 0) return -1;
+      p.out = (float*)scr;
+      p.part_stride = (long)out_elems;
+      if (!out_nc8) { p.out_ctotal = Cout; p.out_coff = 0; }   // dense NCHW partials
+      grid *= S;
+    }
 #define W8_LAUNCH(O, S)                                                                               \
     if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                           \
     else conv_wino8_kernel<O, S, 0><<<grid, 512, 0, ctx->stream>>>(p);
@@ -1055,6 +1143,13 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
       if (out_nc8) { W8_LAUNCH(1, 0) } else { W8_LAUNCH(0, 0) }
     }
 #undef W8_LAUNCH
+    if (S > 1) {
+      const long total = out_nc8 ? (long)(out_elems / 4) : (long)out_elems;
+      const int hw = p.out_s2d ? H * W / 4 : H * W;
+      wino_reduce_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(final_out, p.out, bias, total, p.part_stride, S, slope, out_nc8 ? 1 : 0,
+                                                                           (Cout >> 3) * (p.out_s2d ? 4 : 1), hw, Cout >> 3, Cout,
+                                                                           out_ctotal > 0 ? out_ctotal : Cout, out_coff);
+    }
     DI_LAUNCH_CHECK();
     return 0;
   }

@@ -88,6 +88,7 @@ def test_shared_transform_kernel_is_bit_identical_to_the_one_wave_kernel(ctx, ca
     as conv_wino_kernel — only who computes what differs — so NC8, space-to-depth and NCHW-slice outputs are the same bits."""
     if wino_kernel != "shared":
         pytest.skip("compares the two kernels itself")
+    lib.deepim_set_option(ctx.handle, b"wino_split", 1)      # one block walks all input channels: the same summation order
     B, cin, H, W, cout = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
@@ -103,6 +104,34 @@ def test_shared_transform_kernel_is_bit_identical_to_the_one_wave_kernel(ctx, ca
             outs.append(o.asnumpy())
         lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
         np.testing.assert_array_equal(outs[0], outs[1])
+    lib.deepim_set_option(ctx.handle, b"wino_split", 0)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 12, 16, 256), (1, 1024, 8, 10, 1024), (3, 64, 15, 20, 128), (4, 512, 15, 20, 512)])
+@pytest.mark.parametrize("slices", [0, 2, 3])
+def test_shared_transform_kernel_split_over_the_input_channels(ctx, case, slices, wino_kernel):
+    """Under-filled grids split the input channels over several blocks (raw sums per slice, second pass adds bias + LeakyReLU):
+    the planner's own choice (0) and forced slice counts, NC8 / space-to-depth / NCHW-slice outputs, against the unsplit kernel."""
+    if wino_kernel != "shared":
+        pytest.skip("the shared-transform kernel's own path")
+    B, cin, H, W, cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    xin, pk, bias = ctx.array(_to_nc8(x)), _pack(ctx, w), ctx.array(rng.standard_normal(cout).astype(np.float32))
+    modes = [(1, 0, 0)] + ([(3, 0, 0)] if H % 2 == 0 and W % 2 == 0 else []) + [(0, cout + 8, 8)]
+    for out_nc8, ctotal, coff in modes:
+        outs = []
+        for split in (1, slices):
+            lib.deepim_set_option(ctx.handle, b"wino_split", split)
+            o = ctx.array(np.full((B, max(ctotal, cout), H, W), 3.0, np.float32))
+            lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, ctotal, coff)
+            outs.append(o.asnumpy())
+        lib.deepim_set_option(ctx.handle, b"wino_split", 0)
+        scale = max(1.0, float(np.abs(outs[0]).max()))
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * scale
+        if out_nc8 == 0:
+            assert (outs[1][:, :coff] == 3.0).all()
 
 
 def test_wino_weight_transform_is_G_g_Gt_with_the_last_column_negated(ctx):

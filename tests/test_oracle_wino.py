@@ -65,12 +65,12 @@ def test_layer_selection_rule():
     def chosen(B):
         s = {n for n, (ci, h, w, co) in k3.items() if L.deepim_conv_wino_preferred(None, B, ci, h, w, co)}
         return s | {n for n, (ci, h, w, co) in k5.items() if L.deepim_conv_wino_preferred_s2d(None, B, ci, h, w, co)}
-    assert chosen(32) == set(k3) | set(k5)
-    assert chosen(16) == {"conv2", "conv3", "conv3_1", "conv4_1", "conv5_1"}
-    assert chosen(8) == {"conv2", "conv3", "conv3_1", "conv4_1"}
-    assert chosen(4) == {"conv2", "conv3", "conv3_1", "conv4_1"}
-    assert chosen(2) == {"conv2", "conv3_1"}
-    assert chosen(1) == set()
+    # the shared-transform kernel (Cout % 64 == 0) splits the input channels where the grid is small: it pays from 64 tiles on
+    for B in (32, 16, 8, 4):
+        assert chosen(B) == set(k3) | set(k5)
+    assert chosen(2) == chosen(1) == (set(k3) | set(k5)) - {"conv6_1"}       # 20 tiles per sample
+    assert not L.deepim_conv_wino_preferred(None, 2, 256, 60, 80, 96)         # Cout % 64 != 0: the one-wave kernel's rule, 19 x 3 blocks ...
+    assert L.deepim_conv_wino_preferred(None, 32, 256, 60, 80, 96)            # ... from 128 blocks of 32 channels x 128 tiles on
     assert not L.deepim_conv_wino_preferred(None, 32, 12, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 32, 256, 60, 80, 48)
     assert not L.deepim_conv_wino_preferred_s2d(None, 32, 64, 241, 320, 128)          # odd height: no space-to-depth form
     assert L.deepim_conv_wino_packed_size(256, 256) == 256 * 256 * 64

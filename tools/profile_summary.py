@@ -24,7 +24,7 @@ def short(name):
 
 
 def is_conv(n):
-    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "conv_wino_kernel", "splitk_reduce", "tail_reduce",
+    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "conv_wino_kernel", "conv_wino8_kernel", "conv_wino2_kernel", "splitk_reduce", "tail_reduce",
                          "conv_f16", "conv1_x3", "splitk_x3", "splitk_f16", "tail_f16", "split16_to_nchw", "nchw_to_split16",
                          "_ZN12_GLOBAL__N_123splitk_x3", "_ZN12_GLOBAL__N_122split16_to"))
 
@@ -107,6 +107,135 @@ def cmd_traffic(a):
     print("\n".join(lines))
 
 
+# ---- per-kernel roofline table: bench.py reads the JSON this writes, like hbm_traffic.json -------------------
+# encoder layers of deepim/symbols/deepIM_flownet.py:63-107 on the 8-channel FAST_TEST input: (name, Cin, H, W, Cout, k, s, p)
+ENC_GEOM = [("conv1", 8, 480, 640, 64, 7, 2, 3), ("conv2", 64, 240, 320, 128, 5, 2, 2), ("conv3", 128, 120, 160, 256, 5, 2, 2),
+            ("conv3_1", 256, 60, 80, 256, 3, 1, 1), ("conv4", 256, 60, 80, 512, 3, 2, 1), ("conv4_1", 512, 30, 40, 512, 3, 1, 1),
+            ("conv5", 512, 30, 40, 512, 3, 2, 1), ("conv5_1", 512, 15, 20, 512, 3, 1, 1), ("conv6", 512, 15, 20, 1024, 3, 2, 1),
+            ("conv6_1", 1024, 8, 10, 1024, 3, 1, 1)]
+FP32_PEAK_TF, HBM_PEAK_GBS = 157.3, 8000.0
+
+
+def layer_flops(geom, kernel, batch):
+    """(algorithmic, executed) FLOPs of one launch: the Winograd kernels execute 16 multiply-adds per 2x2 output tile, input and output
+    channel (49 of the 4 x 16 (position, phase) pairs on the 5x5 stride-2 layers over the space-to-depth input)."""
+    name, cin, h, w, cout, k, s, p = geom
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    alg = 2.0 * cout * cin * k * k * ho * wo * batch
+    if kernel.startswith("conv_wino"):
+        pos_ch = (49 if s == 2 else 16) * cin
+        return alg, 2.0 * cout * pos_ch * ((ho + 1) // 2) * ((wo + 1) // 2) * batch
+    return alg, alg
+
+
+def iteration_slices(rows, names, iters):
+    marks = [i for i, n in enumerate(names) if n.startswith(("rt_transform_kernel", "pose_tail_kernel"))]
+    assert len(marks) > iters, "trace holds fewer iterations than --iters (+ a priming pass)"
+    return [(marks[-i - 2] + 1, marks[-i - 1] + 1) for i in range(iters)][::-1]
+
+
+def load_trace(path):
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    return rows, [short(r["Kernel_Name"]) for r in rows]
+
+
+def hbm_bytes(kernel, occ, batch, H=480, W=640):
+    """Algorithmic HBM bytes of one launch of the Z / F / H kernels SURVEY 8(d) lists (what the kernel must read + write once)."""
+    px = batch * H * W
+    if kernel.startswith("flow_kernel"):          # lib/flow_c/gpu_flow_kernel.cu:32-69: depth_src + depth_tgt in, flow (2) + valid out
+        return 20.0 * px, "20 B/px: two depth maps read, flow (2 ch) + valid written"
+    if kernel.startswith("resolve_kernel"):       # z-buffer read + re-armed (8 + 8), RGB (12) + depth (4) + mask (4) written
+        return 36.0 * px, "36 B/px: 64-bit z-buffer read and re-armed, image (3 ch) + depth + mask_rendered written"
+    if kernel.startswith("upsample16_kernel"):    # Deconvolution k32 s16 + Crop of the 30x40 head output: occurrence 0 = mask (1 ch), 1 = flow (2 ch)
+        c = 1 if occ == 0 else 2
+        return 4.0 * c * (px + batch * 30 * 40), "%d-channel full-resolution output written, 30x40 input read" % c
+    if kernel.startswith("resample4_kernel"):     # ZoomMaskWithFactor (1 ch) / ZoomFlow (2 ch) back to the camera frame: read + write once
+        c = 1 if occ == 0 else 2
+        return 8.0 * c * px, "%d channel(s) read and written once at 480x640" % c
+    if kernel.startswith("conv_fewout_kernel"):   # flow6 (1024 ch, 8x10), flow5 (1026, 15x20), mask head (770, 30x40), flow4 head (770, 30x40)
+        cin, h, w = [(1024, 8, 10), (1026, 15, 20), (770, 30, 40), (770, 30, 40)][min(occ, 3)]
+        return 4.0 * batch * cin * h * w, "input stream: %d channels at %dx%d read once" % (cin, h, w)
+    return None, None
+
+
+def cmd_perkernel(a):
+    import os
+    out = {"source": "tools/profile_summary.py perkernel: rocprofv3 --kernel-trace of `bench.py --no-cpu-baseline --no-other-configs --verify 0 "
+                     "--steps %d --warmup 2 --batch %d` (and --heads / tools/bench_train.py for the H / F kernels), last %d iterations; "
+                     "mfma_busy from a separate --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128))" % (a.iters // 4, a.batch, a.iters),
+           "batch": a.batch, "peak_tflops": FP32_PEAK_TF, "hbm_peak_gbs": HBM_PEAK_GBS}
+    rows, names = load_trace(a.trace)
+    acc = [[g[0], None, 0, 0.0, 0.0] for g in ENC_GEOM]       # layer, kernel, launches, conv ns, reduce ns
+    for lo, hi in iteration_slices(rows, names, a.iters):
+        li = -1
+        for r, n in zip(rows[lo:hi], names[lo:hi]):
+            if not is_conv(n):
+                continue
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if n.startswith(("splitk_reduce", "tail_reduce")):
+                acc[li][4] += d
+            else:
+                li += 1
+                acc[li][1], acc[li][2], acc[li][3] = n, acc[li][2] + 1, acc[li][3] + d
+        assert li == len(ENC_GEOM) - 1, "an iteration of the trace does not hold the 10 encoder layers"
+    busy = {}
+    if a.pmc and os.path.exists(a.pmc):
+        prow, pnames = load_trace(a.pmc)
+        disp = OrderedDict()
+        for r in prow:
+            d = disp.setdefault(r["Dispatch_Id"], {"name": short(r["Kernel_Name"]), "t": int(r["Start_Timestamp"])})
+            d[r["Counter_Name"]] = float(r["Counter_Value"])
+        seq = sorted(disp.values(), key=lambda d: d["t"])
+        marks = [i for i, d in enumerate(seq) if d["name"].startswith(("rt_transform_kernel", "pose_tail_kernel"))]
+        li = -1
+        for d in seq[marks[-2] + 1:marks[-1] + 1]:            # the last iteration of the PMC run
+            if is_conv(d["name"]) and not d["name"].startswith(("splitk_reduce", "tail_reduce")):
+                li += 1
+                busy[ENC_GEOM[li][0]] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (max(1.0, d.get("GRBM_GUI_ACTIVE", 0.0)) * 128)
+    per, tot_ms = [], 0.0
+    for geom, (layer, kern, calls, ns, rns) in zip(ENC_GEOM, acc):
+        ms, rms = ns / 1e6 / a.iters, rns / 1e6 / a.iters
+        alg, ex = layer_flops(geom, kern, a.batch)
+        per.append({"layer": layer, "kernel": kern, "calls_per_iter": calls // a.iters, "ms": ms, "split_k_reduce_ms": rms,
+                    "algorithmic_tflops": alg / (ms + rms) / 1e9, "executed_tflops": ex / (ms + rms) / 1e9,
+                    "frac": ex / (ms + rms) / 1e9 / FP32_PEAK_TF, "mfma_busy": busy.get(layer)})
+        tot_ms += ms + rms
+    out["per_kernel"] = per
+    out["sum_ms"] = tot_ms
+    bench = re.search(r'"ms_per_launch_group": ([0-9.]+)', open(a.bench).read()) if a.bench else None
+    out["bench_ms_per_launch_group_same_run"] = float(bench.group(1)) if bench else None
+    hbm = []
+    for path, batch, it in ((a.heads_trace, a.batch, a.iters), (a.train_trace, a.train_batch, None)):
+        if not path or not os.path.exists(path):
+            continue
+        hr, hn = load_trace(path)
+        if it:
+            slices = iteration_slices(hr, hn, min(it, 8))
+        else:
+            slices = [(0, len(hr))]
+        agg = OrderedDict()
+        for lo, hi in slices:
+            occ = defaultdict(int)
+            for r, n in zip(hr[lo:hi], hn[lo:hi]):
+                base = re.sub(r"<.*$", "", n)
+                if base not in ("flow_kernel", "resolve_kernel", "upsample16_kernel", "resample4_kernel", "conv_fewout_kernel"):
+                    continue
+                o = occ[base] if it else 0
+                occ[base] += 1
+                c, t = agg.get((n, o), (0, 0))
+                agg[(n, o)] = (c + 1, t + int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for (n, o), (c, t) in agg.items():
+            us = t / 1e3 / c
+            b, what = hbm_bytes(n, o, batch)
+            if b is None:
+                continue
+            hbm.append({"kernel": n, "call": o, "batch": batch, "us": us, "algorithmic_bytes": b, "achieved_gbs": b / us / 1e3,
+                        "frac": b / us / 1e3 / HBM_PEAK_GBS, "bytes": what})
+    out["roofline_hbm"] = hbm
+    json.dump(out, open(a.json, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 ap = argparse.ArgumentParser()
 sub = ap.add_subparsers(dest="cmd", required=True)
 s = sub.add_parser("stats"); s.add_argument("trace"); s.add_argument("stats"); s.add_argument("bench", nargs="?")
@@ -114,5 +243,9 @@ s.add_argument("--iters", type=int, default=20); s.add_argument("--batch", type=
 t = sub.add_parser("traffic"); t.add_argument("fetch"); t.add_argument("write"); t.add_argument("--iters", type=int, default=8)
 t.add_argument("--batch", type=int, default=16); t.add_argument("--md", required=True); t.add_argument("--json", required=True)
 t.add_argument("--note", default=""); t.add_argument("--key", default="", help="JSON key instead of B<batch> (e.g. x3_B32)")
+k = sub.add_parser("perkernel"); k.add_argument("trace"); k.add_argument("bench", nargs="?"); k.add_argument("--pmc", default="")
+k.add_argument("--heads-trace", dest="heads_trace", default=""); k.add_argument("--train-trace", dest="train_trace", default="")
+k.add_argument("--train-batch", dest="train_batch", type=int, default=4)
+k.add_argument("--iters", type=int, default=80); k.add_argument("--batch", type=int, default=32); k.add_argument("--json", required=True)
 a = ap.parse_args()
-{"stats": cmd_stats, "traffic": cmd_traffic}[a.cmd](a)
+{"stats": cmd_stats, "traffic": cmd_traffic, "perkernel": cmd_perkernel}[a.cmd](a)

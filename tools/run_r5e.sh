@@ -2,5 +2,4 @@
 cd /root/repo
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_wino.py -x -q 2>&1 | tail -5
-timeout 300 python tools/bench_wino.py 32 2>&1 | tee gpurun_out/r5e_bench_wino_b32.log
-timeout 300 python tools/bench_wino.py 8 2>&1 | tee gpurun_out/r5e_bench_wino_b8.log
+for b in 32 8 4; do timeout 300 python tools/bench_wino.py $b 2>&1 | cut -c1-150 | tee gpurun_out/r5e_bench_wino_b$b.log; done
