@@ -66,47 +66,134 @@ def encoder_executed_flops_per_pair(net):
     return total
 
 
-def cpu_baseline(params, cfg, batch, budget_s=20.0, with_depth=False, min_runs=5, max_runs=15):
-    """the CPU restatement of the reference path ('port'; MXNet itself is not installable offline) on the
-    host cores, config 1's unit of work — ONE pair, ONE refinement iteration (zoom → 10 convs → fc → pose update) — on pairs of
-    the same synthetic workload: one untimed warm-up pair-iteration, then >= 5 timed ones (more while the `budget_s` seconds
-    last), value = 1 / MEDIAN seconds per iteration. The convolutions run on the oracle's cache-blocked fp32 OpenMP build
-    (oracle_conv2d_blocked: every output the same fmaf chain as the checker, bit-identical — tests/test_oracle_thirdparty.py);
-    zoom / fc / pose update are the numpy + C oracle as the parity tests use it."""
+def physical_cores():
+    """Physical cores of the host (psutil; half the hardware threads if it is not importable)."""
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+    except ImportError:
+        return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(params, cfg, batch, budget_s=20.0, with_depth=False, min_runs=5, max_runs=15, pairs=8):
+    """The stated CPU baseline: whole pair-iterations of the reference path on the host —
+    the oracle's zoom front end (numpy, what the reference's CustomOps run on the host anyway) -> the N-group (10 convolutions + fc6 /
+    fc7 / rot / trans with THIS run's weights) on oneDNN through torch-CPU, the library an MXNet-MKL build of the reference would call
+    for those layers -> the oracle's inverse ZoomTrans + RT_transform; `pairs` pairs per call, threads pinned to the PHYSICAL cores.
+    Protocol: one untimed warm-up call, then >= 5 timed ones (more while `budget_s` lasts), value = pairs / MEDIAN seconds per call.
+    `gflops` = the encoder's 38.9 GFLOP per pair over the time inside the convolution stack. The bit-identical-to-the-checker build of the
+    same loop (every convolution one fmaf chain on the oracle's cache-blocked OpenMP kernel) follows as `secondary_checker_build`;
+    without torch it IS the baseline (kind stays "port": both are restatements, MXNet itself is not installable offline)."""
     from oracle import pipeline as opipe
     from oracle import net as onet
+    from oracle import se3 as ose3
+    from oracle import zoom as ozoom
     onet.build()
     means_rev = np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
     npairs = len(batch["image_observed"])
+    cores = physical_cores()
 
-    def one(b):
-        data = {"image_observed": batch["image_observed"][b:b + 1], "image_rendered": batch["image_rendered"][0][b:b + 1],
-                "mask_observed": batch["mask_observed"][b:b + 1], "mask_rendered": batch["mask_rendered"][0][b:b + 1],
-                "src_pose": batch["src_pose"][0][b:b + 1]}
+    def slab(b, n):
+        idx = [(b + i) % npairs for i in range(n)]
+        data = {"image_observed": batch["image_observed"][idx], "image_rendered": batch["image_rendered"][0][idx],
+                "mask_observed": batch["mask_observed"][idx], "mask_rendered": batch["mask_rendered"][0][idx],
+                "src_pose": batch["src_pose"][0][idx]}
         if with_depth:
-            data.update(depth_observed=batch["depth_gt_observed"][b:b + 1], depth_rendered=batch["depth_rendered"][0][b:b + 1])
+            data.update(depth_observed=batch["depth_gt_observed"][idx], depth_rendered=batch["depth_rendered"][0][idx])
+        return data
+
+    def checker_one(b):
+        data = slab(b, 1)
         t0 = time.perf_counter()
-        opipe.refine_iteration(params, data, batch["K"], means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds,
-                               cfg.network.ROT_COORD)
+        opipe.refine_iteration(params, data, batch["K"], means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds, cfg.network.ROT_COORD)
         return time.perf_counter() - t0
 
+    def run(fn, min_r, max_r, budget):
+        warm = fn(0)
+        times, t_begin = [], time.perf_counter()
+        while len(times) < min_r or (len(times) < max_r and time.perf_counter() - t_begin < budget):
+            times.append(fn((1 + len(times)) % npairs))
+        return warm, times
+
+    res = None
+    try:
+        import torch
+        import torch.nn.functional as F
+    except ImportError:
+        torch = None
+    if torch is not None:
+        torch.set_num_threads(cores)
+        tw = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in params.items()
+              if k.startswith(("flow_conv1", "conv", "fc", "rot", "trans"))}
+        conv_s = [0.0]
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=max(1, min(pairs, cores)))
+
+        def onednn_call(b):
+            data = slab(b, pairs)
+            t0 = time.perf_counter()
+            def zoom_one(i):       # one pair per host thread: the pairs are independent, numpy releases the GIL in its kernels
+                sl = slice(i, i + 1)
+                return ozoom.net_input(data["image_observed"][sl], data["image_rendered"][sl], data["mask_observed"][sl],
+                                       data["mask_rendered"][sl], data["src_pose"][sl], batch["K"], means_rev,
+                                       data["depth_observed"][sl] if with_depth else None, data["depth_rendered"][sl] if with_depth else None)
+            zs = list(pool.map(zoom_one, range(pairs)))
+            x = np.concatenate([z[0] for z in zs], 0)
+            zf = np.concatenate([z[1] for z in zs], 0)
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                y = torch.from_numpy(x)
+                for name, cout, k, s_, p_ in ENCODER:
+                    y = F.leaky_relu(F.conv2d(y, tw[name + "_weight"], tw[name + "_bias"], stride=s_, padding=p_), 0.1)
+                t2 = time.perf_counter()
+                y = F.leaky_relu(F.linear(y.flatten(1), tw["fc6_weight"], tw["fc6_bias"]), 0.1)
+                y = F.leaky_relu(F.linear(y, tw["fc7_weight"], tw["fc7_bias"]), 0.1)
+                rot = F.linear(y, tw["rot_weight"], tw["rot_bias"]).numpy()
+                tr = F.linear(y, tw["trans_weight"], tw["trans_bias"]).numpy()
+            tr = ozoom.zoom_trans(zf, tr, b_inv_zoom=True)
+            for i in range(pairs):
+                ose3.RT_transform(np.asarray(data["src_pose"][i], np.float32), rot[i], tr[i], cfg.dataset.trans_means,
+                                  cfg.dataset.trans_stds, cfg.network.ROT_COORD)
+            conv_s[0] += t2 - t1
+            return time.perf_counter() - t0
+
+        warm, times = run(onednn_call, min_runs, max_runs, budget_s * 0.6)
+        conv_total = conv_s[0]
+        med = float(np.median(times))
+        # conv seconds of the timed calls only (the warm-up's share is subtracted by proportion of calls)
+        conv_per_call = conv_total / (len(times) + 1)
+        res = {"value": pairs / med, "unit": "pose-refinement iters/sec", "cores": cores, "threads": int(torch.get_num_threads()),
+               "nproc": os.cpu_count(), "kind": "port",
+               "gflops": encoder_flops_per_pair(8 + (2 if with_depth else 0)) * pairs / conv_per_call / 1e9,
+               "n_group_share_of_time": conv_per_call / (float(np.mean(times + [warm]))),
+               "protocol": "BASELINE.md section 3: 1 untimed warm-up call, then %d timed calls of %d pair-iterations; value = pairs / median" % (len(times), pairs),
+               "seconds_per_call": {"median": med, "min": float(min(times)), "max": float(max(times)), "warmup": warm},
+               "sample": "%d timed calls x %d pair-iterations (480x640, FAST_TEST graph: BASELINE config 1's unit of work) in %.1f s on pairs of "
+                         "the same synthetic workload: oracle zoom front end (numpy, one pair per host thread) -> 10 convolutions + fc head on oneDNN (torch-CPU %s, this "
+                         "run's weights) -> oracle inverse ZoomTrans + RT_transform; %d threads = the physical cores"
+                         % (len(times), pairs, float(sum(times)), torch.__version__, int(torch.get_num_threads()))}
+    # the checker build of the same pair-iteration: bit-identical convolutions, OpenMP threads pinned to the physical cores
+    old_omp = os.environ.get("OMP_NUM_THREADS")
+    onet.set_omp_threads(cores)
     onet.BLOCKED = True
     try:
-        warm = one(0)
-        times, t_begin = [], time.perf_counter()
-        while len(times) < min_runs or (len(times) < max_runs and time.perf_counter() - t_begin < budget_s):
-            times.append(one((1 + len(times)) % npairs))
+        warm, times = run(checker_one, 2 if res else min_runs, 4 if res else max_runs, budget_s * (0.4 if res else 1.0))
     finally:
         onet.BLOCKED = False
     med = float(np.median(times))
     threads = onet.omp_threads()
-    return {"value": 1.0 / med, "unit": "pose-refinement iters/sec", "cores": threads, "nproc": os.cpu_count(),
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS") or "unset (OpenMP default = %d)" % threads, "kind": "port",
-            "protocol": "BASELINE.md section 3: 1 untimed warm-up pair-iteration, then %d timed; value = 1 / median" % len(times),
-            "seconds_per_iteration": {"median": med, "min": float(min(times)), "max": float(max(times)), "warmup": warm},
-            "sample": "%d timed pair-iterations (B = 1, 480x640, FAST_TEST graph: BASELINE config 1's unit) in %.1f s on pairs of the "
-                      "same synthetic workload; numpy + C oracle, convolutions on its cache-blocked fp32 OpenMP build, %d threads"
-                      % (len(times), float(sum(times)), threads)}
+    chk = {"value": 1.0 / med, "unit": "pose-refinement iters/sec", "cores": cores, "threads": threads, "nproc": os.cpu_count(),
+           "omp_num_threads": old_omp or "unset: pinned to the %d physical cores through omp_set_num_threads" % cores,
+           "gflops": encoder_flops_per_pair(8 + (2 if with_depth else 0)) / med / 1e9,
+           "kind": "port", "protocol": "1 untimed warm-up pair-iteration, then %d timed; value = 1 / median" % len(times),
+           "seconds_per_iteration": {"median": med, "min": float(min(times)), "max": float(max(times)), "warmup": warm},
+           "sample": "%d timed pair-iterations (B = 1) in %.1f s; numpy + C oracle, every convolution the checker's own fmaf chain on its "
+                     "cache-blocked fp32 OpenMP build (bit-identical to the parity oracle), %d threads; gflops counts the whole iteration's time"
+                     % (len(times), float(sum(times)), threads)}
+    if res is None:
+        return chk
+    res["secondary_checker_build"] = chk
+    return res
 
 
 def cpu_onednn_secondary(cfg, seconds=8.0, pairs=4):
@@ -317,7 +404,9 @@ def dry_run(args, rank, world, rdzv):
             assert np.array_equal(got[r, :counts[r]], want), "all-gather returned wrong poses for rank %d" % r
             assert not got[r, counts[r]:].any()
             off += counts[r]
-    recs = rdzv.all_gather(json.dumps(comm_record(None)).encode()) if world > 1 else [json.dumps(comm_record(None)).encode()]
+    # which GPU every rank's convenience calls would land on (Context.default(): LOCAL_RANK), and what it has opened (nothing, here)
+    my = dict(comm_record(None), default_device=Context.default_device_id(), opened=list(Context.opened))
+    recs = rdzv.all_gather(json.dumps(my).encode()) if world > 1 else [json.dumps(my).encode()]
     if rank == 0:
         out = headline(args, world, NIT, dt, total, scaling, args.steps, args.warmup, total if scaling == "strong" else B)
         out["config"] = {"workload": "DRY RUN (no GPU): launch rehearsal of the %d-rank path" % world, "pairs_per_gpu": B,
@@ -325,7 +414,9 @@ def dry_run(args, rank, world, rdzv):
         c0 = json.loads(recs[0].decode())
         out["comm"] = {"backend": "host-dry-run" if world > 1 else "none", "rccl_ranks": 0, "rccl_version": c0["rccl_version"],
                        "librccl_path": c0.get("librccl_path") or None, "libamdhip64_path": c0.get("libamdhip64_path") or None,
-                       "allgather_us": None, "ranks_reporting": len(recs)}
+                       "allgather_us": None, "ranks_reporting": len(recs),
+                       "default_device_by_rank": [json.loads(r.decode())["default_device"] for r in recs],
+                       "devices_opened_by_rank": [json.loads(r.decode())["opened"] for r in recs]}
         out["roofline"] = None
         out["dry_run"] = True
         print(json.dumps(out))
@@ -590,6 +681,7 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world, rdzv)
 
+    Context.set_default(device_id)                   # convenience calls of the host mirrors (RT_transform, nd.array, …) follow this rank's GPU
     ctx = Context.get(device_id)
     h = ctx.handle
     if args.autotune:

@@ -46,7 +46,8 @@ def default_config():
         FP16_CONV=False,   # BASELINE config 5: fp16 conv path (not a reference key; the reference is fp32 only)
     )
     cfg.train_iter = AttrDict(SE3_PM_LOSS=True, SE3_PM_LOSS_TYPE="L1", LW_PM=0.1, LW_FLOW=0.25, LW_MASK=0.03,
-                              NUM_3D_SAMPLE=3000, SE3_PM_SL1_SCALAR=1.0, SE3_DIST_LOSS=False)
+                              NUM_3D_SAMPLE=3000, SE3_PM_SL1_SCALAR=1.0, SE3_DIST_LOSS=False,
+                              LW_ROT=0.0, LW_TRANS=0.0, TRANS_LOSS_TYPE="L2", TRANS_SMOOTH_L1_SCALAR=3.0)   # config.py:104-108
     # experiments/deepim/cfgs/deepim_flownet_LM_SIXD_v1_ape_RFMx4_8epoch.yaml:76-92 (keys the label generation reads)
     # (the yaml also sets MASK_DILATE: True — a random cv2 dilation, i.e. loader-side augmentation, not built here)
     cfg.TRAIN = AttrDict(INIT_MASK="box_gt", FLOW_WEIGHT_TYPE="viz", MASK_DILATE=False,

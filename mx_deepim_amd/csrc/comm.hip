@@ -28,10 +28,28 @@ RcclApi g_rccl;
 
 int load_rccl() {
   if (g_rccl.handle) return 0;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // Resolved ONCE, to an absolute file, in a fixed order — so that every rank of a job binds the same library whatever else its
+  // process has loaded: (1) $DEEPIM_RCCL_PATH; (2) a copy already mapped into the process (a host program that linked one: dlopen of
+  // the soname then returns THAT handle — RTLD_NOLOAD asks without loading); (3) librccl.so.1 next to the libamdhip64 this library
+  // itself runs on (the ROCm installation's own); (4) the bare sonames through the loader's search path.
   void* h = nullptr;
+  if (const char* env = getenv("DEEPIM_RCCL_PATH"))
+    if (env[0] == '/') h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+  if (!h) {
+    Dl_info dh;
+    if (dladdr((void*)&hipGetDeviceCount, &dh) && dh.dli_fname) {
+      char path[1024];
+      snprintf(path, sizeof(path), "%s", dh.dli_fname);
+      if (char* slash = strrchr(path, '/')) {
+        snprintf(slash + 1, sizeof(path) - (size_t)(slash + 1 - path), "librccl.so.1");
+        h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+      }
+    }
+  }
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!h) {
     deepim_set_error_msg("comm: librccl.so not found (dlopen)");
     return -1;

@@ -46,6 +46,10 @@ struct deepim_ctx {
                     // creation and RE-ARMED BY THEIR CONSUMER (zoom_factor_kernel resets what it read), so a call needs no init launch
   unsigned long long* zbuf;   // rasteriser z-buffer (key = depth bits << 32 | triangle): all-ones between calls — the resolve pass
   size_t zbuf_bytes;          // puts every entry back after reading it, so a draw needs no clearing pass (grow-only, cleared on growth)
+  // host-side guards of the two self-re-arming buffers: set before the PRODUCER launches (raster / bbox), cleared once the CONSUMER
+  // (resolve / zoom_factor) has been launched without error. Found set on entry — an aborted sequence, a launch error in between —
+  // the buffer is re-initialised before it is used again instead of handing stale depth keys / boxes to the next call.
+  int zbuf_dirty, zoom_box_dirty;
   // pinned host staging for small per-call attribute uploads (K, means, ...)
   std::vector<hipEvent_t> timer_start, timer_stop;
   hipEvent_t sync_event;   // deepim_stream_wait: "everything queued on this stream so far" (created on first use)

@@ -255,6 +255,11 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
     DI_CHECK(hipMalloc((void**)&ctx->zbuf, zbytes));
     ctx->zbuf_bytes = zbytes;
     DI_CHECK(hipMemsetAsync(ctx->zbuf, 0xff, zbytes, ctx->stream));
+    ctx->zbuf_dirty = 0;
+  }
+  if (ctx->zbuf_dirty) {      // an earlier draw rasterised but its resolve pass was never launched: stale depth keys
+    DI_CHECK(hipMemsetAsync(ctx->zbuf, 0xff, ctx->zbuf_bytes, ctx->stream));
+    ctx->zbuf_dirty = 0;
   }
   unsigned long long* zbuf = ctx->zbuf;
   PV* pv = (PV*)scratch;
@@ -270,12 +275,15 @@ static int render_impl(deepim_ctx* ctx, float* image, float* depth, float* mask,
   }
   hipLaunchKernelGGL(project_kernel, dim3(di_div_up(V, 256), B), dim3(256), 0, ctx->stream, pv, vertices, poses, K, V,
                      words);
+  DI_LAUNCH_CHECK();
+  ctx->zbuf_dirty = 1;
   hipLaunchKernelGGL(raster_kernel, dim3(di_div_up(F, 256), B), dim3(256), 0, ctx->stream, zbuf, pv, (const int*)faces, V,
                      F, H, W, znear, zfar);
   hipLaunchKernelGGL(resolve_kernel, dim3(di_div_up((long)H * W, 256), B), dim3(256), 0, ctx->stream, image, depth, zbuf,
                      pv, (const int*)faces, vertex_attr, texture, tex_h, tex_w, means, V, H, W, znear, mask, mask_thresh,
                      words, lit);
   DI_LAUNCH_CHECK();
+  ctx->zbuf_dirty = 0;        // the resolve pass is queued behind the raster pass: the buffer will be all-ones again
   if (mask_box) return deepim_mask_box_fill(ctx, mask_box, words, B, H, W);
   return 0;
 }

@@ -60,6 +60,7 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   const size_t box_bytes = (size_t)DI_MAX_BOX_SAMPLES * 4 * sizeof(int), zbox_bytes = (size_t)DI_MAX_BOX_SAMPLES * 8 * sizeof(int);
   c->zbuf = nullptr;
   c->zbuf_bytes = 0;
+  c->zbuf_dirty = c->zoom_box_dirty = 0;
   e = hipMalloc((void**)&c->status, 64 + box_bytes + zbox_bytes);
   if (e == hipSuccess) e = hipMemsetAsync(c->status, 0, 64, c->stream);
   if (e == hipSuccess) {

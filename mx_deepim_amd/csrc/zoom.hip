@@ -563,14 +563,22 @@ int compute_zoom_factor(deepim_ctx* ctx, float* zoom_factor, const float* map0, 
     box = (int*)scratch;
     hipLaunchKernelGGL(bbox_init_kernel, dim3(di_div_up(B * 8, 256)), dim3(256), 0, ctx->stream, box, B * 8);
   }
+  if (persistent && ctx->zoom_box_dirty) {   // an earlier call accumulated boxes that no zoom_factor_kernel consumed and re-armed
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(di_div_up(DI_MAX_BOX_SAMPLES * 8, 256)), dim3(256), 0, ctx->stream, box, DI_MAX_BOX_SAMPLES * 8);
+    DI_LAUNCH_CHECK();
+    ctx->zoom_box_dirty = 0;
+  }
   int* status = ctx->status;
   Vec3 means = {{0, 0, 0}};
   if (means3) for (int i = 0; i < 3; ++i) means.v[i] = means3[i];
   dim3 grid(di_div_up(H, BB_ROWS), B, 2);
+  if (persistent) ctx->zoom_box_dirty = 1;
   hipLaunchKernelGGL(bbox_kernel, grid, dim3(256), 0, ctx->stream, box, map0, map1, mode0, mode1, means, H, W);
+  DI_LAUNCH_CHECK();
   hipLaunchKernelGGL(zoom_factor_kernel, dim3(di_div_up(B, 64)), dim3(64), 0, ctx->stream, zoom_factor, status, box,
                      src_pose, mat3_from(K_host), B, H, W, persistent ? 1 : 0);
   DI_LAUNCH_CHECK();
+  if (persistent) ctx->zoom_box_dirty = 0;   // the consumer is queued: it resets what it reads
   return 0;
 }
 

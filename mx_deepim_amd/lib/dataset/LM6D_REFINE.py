@@ -55,7 +55,7 @@ class LM6D_REFINE(object):
         """est, gt (n,3,4) → (n,5) [re°, te, add, adi, arp_2d] from ONE deepim_pose_error launch."""
         from ...runtime import Context, lib
         if self._ctx is None:
-            self._ctx = Context.get(0)
+            self._ctx = Context.default()
         ctx = self._ctx
         n = len(est)
         pts = np.ascontiguousarray(np.asarray(self._points[cls_name], np.float32).T)          # (3,N)

@@ -20,7 +20,7 @@ def _ctx_of(*arrays):
     for a in arrays:
         if isinstance(a, DeviceArray):
             return a.context
-    return Context.get(0)
+    return Context.default()
 
 
 def _dev(ctx, a):
@@ -60,7 +60,7 @@ def RT_transform(pose_src, r, t, T_means, T_stds, rot_coord="MODEL", ctx=None):
     r = np.squeeze(np.asarray(r))
     if r.shape[0] not in (3, 4):
         raise Exception("Unknown r shape: {}".format(r.shape))
-    ctx = ctx or Context.get(0)
+    ctx = ctx or Context.default()
     rc = _rot_coord(rot_coord, "R_transform")
     se3 = np.concatenate([r.astype(np.float32), np.squeeze(np.asarray(t)).astype(np.float32)])[None]
     out64, out = ctx.empty((1, 3, 4), dtype=np.float64), ctx.empty((1, 3, 4))
@@ -122,7 +122,7 @@ def calc_KT(pose_src, pose_tgt, K, ctx=None):
 def calc_rt_dist_m(pose_src, pose_tgt, ctx=None):
     """RT_transform.py:162-173 → (rd_deg, td): geodesic rotation angle in degrees (‖logm(R_srcᵀR_tgt)‖_F/√2) and ‖ΔT‖,
     through the pose-error kernel (re, te of lib/utils/pose_error.py are the same two numbers)."""
-    ctx = ctx or Context.get(0)
+    ctx = ctx or Context.default()
     out = ctx.empty((1, 5))
     dummy = ctx.zeros((3, 1))
     lib.deepim_pose_error(ctx.handle, out, ctx.array(np.asarray(pose_src, np.float32)[None]),
@@ -132,7 +132,7 @@ def calc_rt_dist_m(pose_src, pose_tgt, ctx=None):
 
 
 def _convert(op, x, in_shape, out_shape, ctx):
-    ctx = ctx or Context.get(0)
+    ctx = ctx or Context.default()
     x = np.ascontiguousarray(np.asarray(x, np.float32).reshape((-1,) + in_shape))
     out = ctx.empty((x.shape[0],) + out_shape, dtype=np.float64)
     lib.deepim_rot_convert(ctx.handle, out, ctx.array(x), op, x.shape[0])

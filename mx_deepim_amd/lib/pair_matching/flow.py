@@ -9,7 +9,7 @@ from .RT_transform import calc_KT
 
 
 def calc_flow(depth_src, pose_src, pose_tgt, K, depth_tgt, thresh=3e-3, standard_rep=False, ctx=None):
-    ctx = ctx or Context.get(0)
+    ctx = ctx or Context.default()
     depth_src = np.ascontiguousarray(depth_src, np.float32)
     depth_tgt = np.ascontiguousarray(depth_tgt, np.float32)
     H, W = depth_src.shape[:2]

@@ -66,7 +66,7 @@ class Render_Py_Light_ModelNet_Multi(Render_Py):
         self.model_path_list = list(model_path_list)
         self.classes = self.model_path_list
         self.brightness_ratios = [float(r) for r in brightness_ratios]
-        self.ctx = ctx or Context.get(0)
+        self.ctx = ctx or Context.default()
         self.pixel_means = None if pixel_means is None else np.ascontiguousarray(pixel_means, np.float32).reshape(3)
         self.mesh_list, self.normal_list = [], []
         texture = None if meshes is not None else load_texture(texture_path)

@@ -99,7 +99,7 @@ class Render_Py(object):
         self.width, self.height, self.zNear, self.zFar = int(width), int(height), float(zNear), float(zFar)
         self.K = np.ascontiguousarray(K, dtype=np.float32).reshape(3, 3)
         self.model_dir, self.classes = model_dir, list(classes)
-        self.ctx = ctx or Context.get(0)
+        self.ctx = ctx or Context.default()
         # tensor-channel order (RGB): the updater subtracts PIXEL_MEANS[[2,1,0]] (batch_updater_py_multi.py:124-127)
         self.pixel_means = None if pixel_means is None else np.ascontiguousarray(pixel_means, np.float32).reshape(3)
         self.mesh_list = []

@@ -35,7 +35,7 @@ def load_param(prefix, epoch, convert=False, ctx=None, process=False):
     if convert:
         if ctx is None:
             from ...runtime import Context
-            ctx = Context.get(0)
+            ctx = Context.default()
         arg_params = convert_context(arg_params, ctx)
         aux_params = convert_context(aux_params, ctx)
     if process:   # drop the "_test" / "_i2r" name suffixes older checkpoints carry (load_model.py:59-65)

@@ -8,14 +8,14 @@ NDArray = DeviceArray
 
 
 def array(source, ctx=None, dtype=np.float32):
-    ctx = ctx or Context.get(0)
+    ctx = ctx or Context.default()
     if isinstance(source, DeviceArray):
         return source.copy()
     return ctx.array(np.asarray(source), dtype=dtype)
 
 
 def zeros(shape, ctx=None, dtype=np.float32):
-    return (ctx or Context.get(0)).zeros(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
+    return (ctx or Context.default()).zeros(tuple(shape) if not isinstance(shape, int) else (shape,), dtype)
 
 
 def load(fname):

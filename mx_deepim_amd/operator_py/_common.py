@@ -19,7 +19,15 @@ def parse_vec(s, n=None):
     return np.ascontiguousarray(v)
 
 
+def istrue(s):
+    """How every reference Prop but Transform3D reads a boolean kwarg: `s.lower() == "true"` (zoom_trans.py:81-82, zoom_flow.py:85,
+    zoom_mask_with_factor.py:77, flow_updater.py:118) — MXNet hands kwargs over as strings; "1" / "yes" / "on" are False there."""
+    return str(s).lower() == "true"
+
+
 def strtobool(s):
+    """distutils.util.strtobool, the one Transform3D uses (transform3d.py:22, :290): y / yes / t / true / on / 1 and their opposites,
+    ValueError otherwise."""
     if isinstance(s, bool):
         return s
     s = str(s).strip().lower()

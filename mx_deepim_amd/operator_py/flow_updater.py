@@ -8,7 +8,7 @@ import numpy as np
 
 from .. import mx
 from ..runtime import lib
-from ._common import parse_vec, strtobool, targets
+from ._common import istrue, parse_vec, targets
 
 
 class flowUpdaterOperator(mx.operator.CustomOp):
@@ -46,7 +46,7 @@ class flowUpdaterProp(mx.operator.CustomOpProp):
         self.batch_size = int(batch_size)
         self.height = int(height)
         self.width = int(width)
-        self.wh_rep = strtobool(wh_rep)
+        self.wh_rep = istrue(wh_rep)
 
     def list_arguments(self):
         return ["depth_src", "depth_tgt", "pose_src", "pose_tgt"]

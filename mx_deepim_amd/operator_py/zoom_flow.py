@@ -3,7 +3,7 @@ forward zoom of GT flow (÷wx) + binarised weights, or inverse zoom of predicted
 Compute: deepim_zoom_flow_forward (HIP)."""
 from .. import mx
 from ..runtime import lib
-from ._common import strtobool, targets
+from ._common import istrue, targets
 
 
 class ZoomFlowOperator(mx.operator.CustomOp):
@@ -39,7 +39,7 @@ class ZoomFlowProp(mx.operator.CustomOpProp):
         super(ZoomFlowProp, self).__init__(True)
         self.height = int(height)
         self.width = int(width)
-        self.b_inv_zoom = strtobool(b_inv_zoom)
+        self.b_inv_zoom = istrue(b_inv_zoom)
 
     def list_arguments(self):
         return ["zoom_factor", "flow"] if self.b_inv_zoom else ["zoom_factor", "flow", "flow_weights"]

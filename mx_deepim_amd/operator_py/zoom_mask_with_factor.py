@@ -3,7 +3,7 @@
 Compute: deepim_zoom_mask_with_factor_forward (HIP)."""
 from .. import mx
 from ..runtime import lib
-from ._common import strtobool, targets
+from ._common import istrue, targets
 
 
 class ZoomMaskWithFactorOperator(mx.operator.CustomOp):
@@ -32,7 +32,7 @@ class ZoomMaskWithFactorProp(mx.operator.CustomOpProp):
         super(ZoomMaskWithFactorProp, self).__init__(True)
         self.height = int(height)
         self.width = int(width)
-        self.b_inv_zoom = strtobool(b_inv_zoom)
+        self.b_inv_zoom = istrue(b_inv_zoom)
 
     def list_arguments(self):
         return ["zoom_factor", "mask"]

@@ -3,7 +3,7 @@ scale (vx, vy) of the translation by wx (inverse) or 1/wx; optional gradient sca
 Compute: deepim_zoom_trans_forward / _backward (HIP)."""
 from .. import mx
 from ..runtime import lib
-from ._common import strtobool, targets
+from ._common import istrue, targets
 
 
 class ZoomTransOperator(mx.operator.CustomOp):
@@ -33,8 +33,8 @@ class ZoomTransOperator(mx.operator.CustomOp):
 class ZoomTransProp(mx.operator.CustomOpProp):
     def __init__(self, b_inv_zoom="False", b_zoom_grad="False"):
         super(ZoomTransProp, self).__init__(True)
-        self.b_inv_zoom = strtobool(b_inv_zoom)
-        self.b_zoom_grad = strtobool(b_zoom_grad)
+        self.b_inv_zoom = istrue(b_inv_zoom)
+        self.b_zoom_grad = istrue(b_zoom_grad)
 
     def list_arguments(self):
         return ["zoom_factor", "trans_delta"]

@@ -175,7 +175,9 @@ class Rendezvous(object):
         self.port0 = self.port
         self.timeout = float(timeout)
         self.handshake_timeout = 2.0     # hub: per-connection limit for the 52-byte hello
-        self.reject_grace = 5.0          # spoke: how long to keep scanning after some hub REFUSED this rank (see _connect)
+        # spoke: how long to keep scanning after some hub REFUSED this rank (see _connect) — a share of the overall timeout, so that a
+        # rank 0 that binds its port late on a busy host is still found (a fixed 5 s failed such jobs spuriously)
+        self.reject_grace = max(5.0, 0.5 * self.timeout)
         single_node = int(env.get("LOCAL_WORLD_SIZE", "0")) == self.world or _is_loopback(self.addr)
         if single_node:
             self.addr = "127.0.0.1"
@@ -291,7 +293,8 @@ class Rendezvous(object):
                 if s is None:
                     now = time.time()
                     if refused_at is not None and now > min(deadline, refused_at + self.reject_grace):
-                        raise RuntimeError("rendezvous: %s" % refused)
+                        raise RuntimeError("rendezvous: a foreign hub refused rank %d and no hub of this job was found within %.0f s — %s"
+                                           % (self.rank, self.reject_grace, refused))
                     if now > deadline:
                         raise RuntimeError("rendezvous: rank %d could not join the hub — %s" % (self.rank, last))
                     time.sleep(0.05)

@@ -143,6 +143,7 @@ class Context:
         self.device_id = int(device_id)
         h = ctypes.c_void_p()
         lib.deepim_create(self.device_id, ctypes.byref(h))
+        Context.opened.append(self.device_id)
         self.handle = h
         self.device_type = "gpu"
 
@@ -151,6 +152,30 @@ class Context:
         if device_id not in cls._cache:
             cls._cache[device_id] = cls(device_id)
         return cls._cache[device_id]
+
+    # -- the process's default device: the reference's convenience calls run on "the current context"; with one process per GPU
+    # (bench.py --gpus N, torch.distributed.run / torchrun launchers) that is the rank's own GPU, not GPU 0
+    _default_id = None
+    opened = []            # device ids this process has created contexts on, in order (the 8-rank rehearsal asserts on it)
+
+    @classmethod
+    def default_device_id(cls):
+        if cls._default_id is None:
+            v = os.environ.get("DEEPIM_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+            try:
+                cls._default_id = max(0, int(v))
+            except ValueError:
+                cls._default_id = 0
+        return cls._default_id
+
+    @classmethod
+    def set_default(cls, device_id):
+        cls._default_id = int(device_id)
+
+    @classmethod
+    def default(cls):
+        """Context of the process's default device: DEEPIM_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+        return cls.get(cls.default_device_id())
 
     def __repr__(self):
         return "gpu(%d)" % self.device_id

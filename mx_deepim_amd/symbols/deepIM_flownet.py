@@ -124,8 +124,19 @@ class deepIM_flownet(object):
         LogisticRegressionOutput against the zoomed mask_gt_observed. forward_train / backward / update run all of it
         resident on the device."""
         n = cfg.network
-        if not cfg.train_iter.SE3_PM_LOSS:
-            raise NotImplementedError("training graph needs train_iter.SE3_PM_LOSS")
+        t = cfg.train_iter
+        if not (t.SE3_PM_LOSS or t.get("SE3_DIST_LOSS", False)):
+            raise NotImplementedError("training graph needs train_iter.SE3_PM_LOSS or train_iter.SE3_DIST_LOSS")
+        if str(n.ROT_TYPE).upper() != "QUAT":
+            # the reference's get_loss builds a 4-output rot head + L2Normalization whatever ROT_TYPE says (deepIM_flownet.py:211-217):
+            # an EULER training graph does not exist there either — refuse instead of training the wrong head
+            raise NotImplementedError("training graph: network.ROT_TYPE must be 'QUAT' (deepIM_flownet.py:211-217 is quaternion-only)")
+        # rot / trans distance losses (deepIM_flownet.py:238-262)
+        self.se3_dist_loss = bool(t.get("SE3_DIST_LOSS", False))
+        self.se3_pm_loss = bool(t.SE3_PM_LOSS)
+        self.trans_loss_type = str(t.get("TRANS_LOSS_TYPE", "L2"))
+        if self.se3_dist_loss and self.trans_loss_type not in ("L2", "smooth_L1", "L1"):
+            raise Exception("Does not support small_cfg.TRANS_LOSS_TYPE: {}".format(self.trans_loss_type))      # :258-259
         if getattr(n, "FP16_CONV", False) or getattr(n, "X3_CONV", False):
             # encoder_fp16 / encoder_x3 fill only the fp16 / split16 activations; backward() reads the NCHW fp32 ones
             raise NotImplementedError("training graph runs the fp32 convolutions only (network.FP16_CONV / X3_CONV unset)")
@@ -165,6 +176,13 @@ class deepIM_flownet(object):
         self.T_stds = np.ascontiguousarray(cfg.dataset.trans_stds, dtype=np.float32).reshape(3)
         self.rot_coord = ROT_COORD_CODE[n.ROT_COORD.lower()]
         self.normalize_flow = float(cfg.dataset.NORMALIZE_FLOW)
+        # deepIM_flownet.py:715: the rot head has 3 outputs for EULER, 4 otherwise; tester.py:391-398 hands rot_type to RT_transform
+        self.rot_type = str(n.ROT_TYPE).upper()
+        if self.rot_type not in ("QUAT", "EULER"):
+            raise Exception("Unknown rot_type: {}".format(n.ROT_TYPE))          # RT_transform.py:142-143
+        self.rot_param = 3 if self.rot_type == "EULER" else 4
+        if self.rot_type == "EULER" and (self.fp16_conv or self.x3_conv):
+            raise NotImplementedError("network.ROT_TYPE = 'EULER' runs on the fp32 convolution paths only")
         return self
 
     def arg_shape_dict(self):
@@ -177,7 +195,8 @@ class deepIM_flownet(object):
             cin = cout
         d["fc6_weight"], d["fc6_bias"] = (256, 1024 * 8 * 10), (256,)
         d["fc7_weight"], d["fc7_bias"] = (256, 256), (256,)
-        d["rot_weight"], d["rot_bias"] = (4, 256), (4,)
+        rp = getattr(self, "rot_param", 4)                       # deepIM_flownet.py:715
+        d["rot_weight"], d["rot_bias"] = (rp, 256), (rp,)
         d["trans_weight"], d["trans_bias"] = (3, 256), (3,)
         if self.with_decoder:
             d["Convolution1_weight"], d["Convolution1_bias"] = (2, 1024, 3, 3), (2,)
@@ -221,6 +240,8 @@ class deepIM_flownet(object):
                 arg_params[name] = self._init_bilinear(shape)
             elif name.endswith("_bias"):
                 arg_params[name] = (0.01 * rng.standard_normal(shape)).astype(np.float32)
+            elif name == "rot_weight" and getattr(self, "rot_type", "QUAT") == "EULER":
+                arg_params[name] = np.zeros(shape, np.float32)      # deepIM_flownet.py:791-792
             elif name == "rot_weight":
                 w = rng.random(shape) * 0.01
                 w[0, :] = rng.random(shape[1]) + 0.01
@@ -359,7 +380,9 @@ class deepIM_flownet(object):
                     A["net_input_x2"] = ctx.empty((B, H, W, 2), dtype=np.float16)
                 self.fp16_fused_input = True
         self._input_live_h16 = False
-        A["fc6"], A["fc7"], A["se3"] = ctx.empty((B, 256)), ctx.empty((B, 256)), ctx.empty((B, 7))
+        A["fc6"], A["fc7"], A["se3"] = ctx.empty((B, 256)), ctx.empty((B, 256)), ctx.empty((B, getattr(self, "rot_param", 4) + 3))
+        if getattr(self, "rot_type", "QUAT") == "EULER":
+            A["rot_e"], A["zoom_trans_e"], A["trans_e"] = ctx.empty((B, 3)), ctx.empty((B, 3)), ctx.empty((B, 3))
         A["pose_est"] = ctx.empty((B, 3, 4))
         if self.with_decoder:
             A["flow6"] = ctx.empty((B, 2, 8, 10))
@@ -557,6 +580,14 @@ class deepIM_flownet(object):
         self._fc6(flat)
         lib.deepim_fc_forward(h, A["fc7"], A["fc6"], P["fc7_weight"], P["fc7_bias"], B, 256, 256,
                               ctypes.c_float(SLOPE))
+        if self.rot_type == "EULER":      # 3-output rot head (deepIM_flownet.py:715-726): FullyConnected x2, inverse ZoomTrans, Concat
+            c1 = ctypes.c_float(1.0)
+            lib.deepim_fc_forward(h, A["rot_e"], A["fc7"], P["rot_weight"], P["rot_bias"], B, 256, 3, c1)
+            lib.deepim_fc_forward(h, A["zoom_trans_e"], A["fc7"], P["trans_weight"], P["trans_bias"], B, 256, 3, c1)
+            lib.deepim_zoom_trans_forward(h, A["zoom_factor"], A["zoom_trans_e"], A["trans_e"], 1, B)
+            lib.deepim_copy_channels(h, A["se3"], 6, 0, A["rot_e"], 3, B, 1)
+            lib.deepim_copy_channels(h, A["se3"], 6, 3, A["trans_e"], 3, B, 1)
+            return
         lib.deepim_pose_head_forward(h, A["se3"], A["fc7"], P["rot_weight"], P["rot_bias"], P["trans_weight"],
                                      P["trans_bias"], A["zoom_factor"], B, 256)
 
@@ -566,6 +597,9 @@ class deepIM_flownet(object):
         se3) and returns the refined poses. `pose_out` may be `src_pose` (in-place update, as the refinement loop does)."""
         A, P, h, B = self.act, self.params, self.ctx.handle, self.B
         out = A["pose_est"] if pose_out is None else pose_out
+        if self.rot_type == "EULER":      # the fused tail is the quaternion form; EULER takes the separate launches
+            self.pose_head()
+            return self.pose_update(src_pose, out)
         self._fc6(A["conv6_1"].reshape((B, -1)))
         lib.deepim_pose_tail_forward(h, A["fc7"], A["se3"], out, A["fc6"], P["fc7_weight"], P["fc7_bias"], P["rot_weight"],
                                      P["rot_bias"], P["trans_weight"], P["trans_bias"], A["zoom_factor"], src_pose, self.T_means,
@@ -600,8 +634,8 @@ class deepIM_flownet(object):
     def pose_update(self, src_pose, pose_out=None):
         """RT_transform of every pair (tester.py:391-398)."""
         out = self.act["pose_est"] if pose_out is None else pose_out
-        lib.deepim_rt_transform(self.ctx.handle, out, None, src_pose, self.act["se3"], self.T_means, self.T_stds,
-                                self.rot_coord, self.B)
+        fn = lib.deepim_rt_transform_euler if self.rot_type == "EULER" else lib.deepim_rt_transform   # RT_transform.py:138-143
+        fn(self.ctx.handle, out, None, src_pose, self.act["se3"], self.T_means, self.T_stds, self.rot_coord, self.B)
         return out
 
     def forward(self, data):
@@ -717,6 +751,10 @@ def _train_methods():
         self.ws["d_points"] = ctx.empty((B, 3, num_points))
         self.ws["d_rot_norm"], self.ws["d_trans_est"] = ctx.empty((B, 4)), ctx.empty((B, 3))
         self.ws["d_rot"], self.ws["d_trans"] = ctx.empty((B, 4)), ctx.empty((B, 3))
+        if self.se3_dist_loss:            # deepIM_flownet.py:238-262
+            A["zoom_trans_gt"], A["rot_loss"] = ctx.empty((B, 3)), ctx.empty((B,))
+            A["trans_loss"], A["trans_loss_sum"] = ctx.empty((B, 3, 1)), ctx.empty((1,))
+            self.ws["d_rot_norm_dist"], self.ws["d_zoom_trans_dist"] = ctx.empty((B, 4)), ctx.empty((B, 3, 1))
         ctx.sync()
         return self
 
@@ -762,15 +800,24 @@ def _train_methods():
         lib.deepim_fc_forward(h, A["zoom_trans"], A["fc7"], P["trans_weight"], P["trans_bias"], B, 256, 3, c(1.0))
         lib.deepim_l2_normalize_forward(h, A["rot_norm"], A["rot"], B, 4, c(1e-10))                       # :217
         lib.deepim_zoom_trans_forward(h, A["zoom_factor"], A["zoom_trans"], A["trans_est"], 1, B)           # :218-225
-        lib.deepim_transform3d_forward(h, A["points_est"], label["point_cloud_model"], A["rot_norm"], A["trans_est"],
-                                       data["src_pose"], self.T_means, self.T_stds, self.rot_coord, B, self.num_points)
-        ltype = {"L1": 0, "L2": 1, "smooth_L1": 2}[t.SE3_PM_LOSS_TYPE]
-        lib.deepim_point_matching_loss(h, A["pm_loss"], A["pm_loss_sum"], self.ws["d_points"], A["points_est"],
-                                       label["point_cloud_observed"], label["point_cloud_weights"],
-                                       c(self.cfg.dataset.NORMALIZE_3D_POINT), ltype, c(t.SE3_PM_SL1_SCALAR),
-                                       c(t.LW_PM / t.NUM_3D_SAMPLE), B, self.num_points)                    # :265-312
+        ltypes = {"L1": 0, "L2": 1, "smooth_L1": 2}
+        if self.se3_dist_loss:            # :238-262: rot_loss = 1 - (q_gt . q_est)^2 (grad_scale LW_ROT), trans loss on the ZOOMED deltas
+            rot_gt = label["rot"] if "rot" in label else label["rot_gt"]            # Variable(name="rot") / ("trans"), :452-453
+            trans_gt = label["trans"] if "trans" in label else label["trans_gt"]
+            lib.deepim_zoom_trans_forward(h, A["zoom_factor"], trans_gt, A["zoom_trans_gt"], 0, B)         # :455-457
+            lib.deepim_rot_dist_loss(h, A["rot_loss"], self.ws["d_rot_norm_dist"], rot_gt, A["rot_norm"], c(t.LW_ROT), B)
+            lib.deepim_point_matching_loss(h, A["trans_loss"], A["trans_loss_sum"], self.ws["d_zoom_trans_dist"], A["zoom_trans"],
+                                           A["zoom_trans_gt"], None, c(1.0), ltypes[self.trans_loss_type],
+                                           c(t.get("TRANS_SMOOTH_L1_SCALAR", 3.0)), c(t.LW_TRANS), B, 1)
+        if self.se3_pm_loss:
+            lib.deepim_transform3d_forward(h, A["points_est"], label["point_cloud_model"], A["rot_norm"], A["trans_est"],
+                                           data["src_pose"], self.T_means, self.T_stds, self.rot_coord, B, self.num_points)
+            lib.deepim_point_matching_loss(h, A["pm_loss"], A["pm_loss_sum"], self.ws["d_points"], A["points_est"],
+                                           label["point_cloud_observed"], label["point_cloud_weights"],
+                                           c(self.cfg.dataset.NORMALIZE_3D_POINT), ltypes[t.SE3_PM_LOSS_TYPE], c(t.SE3_PM_SL1_SCALAR),
+                                           c(t.LW_PM / t.NUM_3D_SAMPLE), B, self.num_points)                    # :265-312
         self._train_io = (data, label)
-        return A["pm_loss_sum"]
+        return A["pm_loss_sum"] if self.se3_pm_loss else A["trans_loss_sum"]
 
     def _dgrad(self, dx, dz, w_raw, B, cin, hh, ww, cout, k, s_, p_, ho, wo, act_y=None, add=None):
         """dx (B,cin,hh,ww) of a Convolution (cout,cin,k,k; stride s_, pad p_) given dz (B,cout,ho,wo); with act_y (the saved output
@@ -855,11 +902,21 @@ def _train_methods():
         data, label = self._train_io
         if self.with_decoder:
             self._decoder_backward()
-        lib.deepim_transform3d_backward(h, W_["d_rot_norm"], W_["d_trans_est"], W_["d_points"], label["point_cloud_model"],
-                                        A["rot_norm"], A["trans_est"], data["src_pose"], self.T_means, self.T_stds,
-                                        self.rot_coord, B, self.num_points)
+        if self.se3_pm_loss:
+            lib.deepim_transform3d_backward(h, W_["d_rot_norm"], W_["d_trans_est"], W_["d_points"], label["point_cloud_model"],
+                                            A["rot_norm"], A["trans_est"], data["src_pose"], self.T_means, self.T_stds,
+                                            self.rot_coord, B, self.num_points)
+            if self.se3_dist_loss:        # both heads of the gradient meet at rot_est_norm (:217 -> :240, :300)
+                lib.deepim_axpy(h, W_["d_rot_norm"], W_["d_rot_norm_dist"], c(1.0), B * 4)
+        else:
+            W_["d_rot_norm"].copyfrom(W_["d_rot_norm_dist"])
         lib.deepim_l2_normalize_backward(h, W_["d_rot"], W_["d_rot_norm"], A["rot"], B, 4, c(1e-10))
-        lib.deepim_zoom_trans_backward(h, A["zoom_factor"], W_["d_trans_est"], W_["d_trans"], 1, 0, B)     # b_zoom_grad=False
+        if self.se3_pm_loss:
+            lib.deepim_zoom_trans_backward(h, A["zoom_factor"], W_["d_trans_est"], W_["d_trans"], 1, 0, B)     # b_zoom_grad=False
+            if self.se3_dist_loss:        # ... and at zoom_trans_est (:212 -> :218, :251)
+                lib.deepim_axpy(h, W_["d_trans"], W_["d_zoom_trans_dist"], c(1.0), B * 3)
+        else:
+            W_["d_trans"].copyfrom(W_["d_zoom_trans_dist"].reshape((B, 3)))
         # rot / trans FullyConnected as one 7-row layer: dy7 = [d_rot | d_trans], w7 = [rot_weight; trans_weight]
         lib.deepim_copy_channels(h, W_["dy7"], 7, 0, W_["d_rot"], 4, B, 1)
         lib.deepim_copy_channels(h, W_["dy7"], 7, 4, W_["d_trans"], 3, B, 1)

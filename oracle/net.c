@@ -122,6 +122,16 @@ void oracle_conv2d_blocked(float* out, const float* in, const float* w, const fl
       }
 }
 
+/* bench.py's cpu_baseline pins the OpenMP team to the physical cores (the default, one thread per hardware thread, oversubscribes
+ * the FMA units of an SMT host) */
+void oracle_set_omp_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int oracle_omp_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

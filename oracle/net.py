@@ -42,6 +42,10 @@ def omp_threads():
     return int(_lib().oracle_omp_threads())
 
 
+def set_omp_threads(n):
+    _lib().oracle_set_omp_threads(int(n))
+
+
 def conv2d(x, w, b, stride, pad, slope=1.0, pair_order=False):
     """pair_order: False/0 = (ci, ky, kx); True/1 = (ci/2, ky, kx, ci%2); 2 = (ci/8, ky, kx, s, h), channel 8(ci/8)+s+4h
     — the accumulation orders of the three MI355X conv kernels, see net.c."""

@@ -109,11 +109,13 @@ def refine_iteration(params, data, K, pixel_means_rev, T_means, T_stds, rot_coor
 
 def train_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, rot_coord="CAMERA", lw_pm=0.1,
                     num_3d_sample=3000, normalize_3d=0.1, loss_type="L1", sigma=1.0, pred_flow=False, pred_mask=False,
-                    lw_flow=0.25, lw_mask=0.03, normalize_flow=20.0):
+                    lw_flow=0.25, lw_mask=0.03, normalize_flow=20.0, se3_pm_loss=True, se3_dist_loss=False, lw_rot=0.0, lw_trans=0.0,
+                    trans_loss_type="L2", trans_sigma=3.0):
     """Forward + backward of the training graph (deepIM_flownet.py:367-546, losses :170-365; backward = module.backward,
     deepim/core/module.py:1131-1137): the point-matching pose branch, plus — pred_flow / pred_mask — the FlowNetS refinement
     decoder with the flow loss (:183-207) and the mask loss (:314-361). Returns (loss_sum, grads keyed like params, forward
-    dict); loss_sum is the point-matching sum (the metric train.py logs)."""
+    dict); loss_sum is the point-matching sum (the metric train.py logs). se3_dist_loss adds the rotation distance loss
+    1 - (q_gt . q_est)^2 (grad_scale lw_rot) and the translation loss on the ZOOMED deltas (:238-262; label["rot"], label["trans"])."""
     from . import heads
     x, zf = zoom.net_input(data["image_observed"], data["image_rendered"], data["mask_observed"], data["mask_rendered"],
                            data["src_pose"], K, pixel_means_rev, data.get("depth_observed"), data.get("depth_rendered"),
@@ -181,10 +183,21 @@ def train_iteration(params, data, label, K, pixel_means_rev, T_means, T_stds, ro
         d_dec61 = (d_dec61 + dx).astype(f32)
         fwd.update(d_Concat3=dC3, d_Concat2=dC2)
     # ---- pose branch
-    d_rot_norm, d_trans_est = se3.transform3d_backward(d_pts, label["point_cloud_model"], rot_norm, trans_est, data["src_pose"],
-                                                        T_means, T_stds, rot_coord)
+    if se3_pm_loss:
+        d_rot_norm, d_trans_est = se3.transform3d_backward(d_pts, label["point_cloud_model"], rot_norm, trans_est, data["src_pose"],
+                                                            T_means, T_stds, rot_coord)
+        d_ztr = zoom.zoom_trans_backward(zf, d_trans_est, b_inv_zoom=True, b_zoom_grad=False)
+    else:
+        d_rot_norm, d_ztr = np.zeros_like(rot_norm), np.zeros_like(ztr)
+    if se3_dist_loss:
+        zoom_trans_gt = zoom.zoom_trans(zf, label["trans"], b_inv_zoom=False)                    # :455-457
+        rot_loss, d_q = heads.rot_dist_loss(label["rot"], rot_norm, lw_rot)                      # :240-248
+        tl, tl_sum, d_zt = heads.point_matching_loss(ztr.reshape(B, 3, 1), zoom_trans_gt.reshape(B, 3, 1), None, 1.0, trans_loss_type,
+                                                     trans_sigma, lw_trans)                       # :250-262
+        d_rot_norm = (d_rot_norm + d_q).astype(f32)
+        d_ztr = (d_ztr + d_zt.reshape(B, 3)).astype(f32)
+        fwd.update(zoom_trans_gt=zoom_trans_gt, rot_loss=rot_loss, trans_loss=tl, trans_loss_sum=tl_sum)
     d_rot = heads.l2_normalize_backward(d_rot_norm, rot)
-    d_ztr = zoom.zoom_trans_backward(zf, d_trans_est, b_inv_zoom=True, b_zoom_grad=False)
     dx_r, g["rot_weight"], g["rot_bias"] = net.fc_backward(fc7, params["rot_weight"], d_rot)
     dx_t, g["trans_weight"], g["trans_bias"] = net.fc_backward(fc7, params["trans_weight"], d_ztr)
     d = net.lrelu_backward((dx_r + dx_t).astype(f32), fc7, SLOPE)

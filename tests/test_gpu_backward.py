@@ -767,3 +767,56 @@ def test_train_step_chains_iterations_through_the_batch_updater(ctx):
     seen = []
     net.train_step(data, label, upd, lr=1e-4, on_iter=lambda it, dat, lab: seen.append(float(net.act["pm_loss_sum"].asnumpy()[0])))
     assert len(seen) == 4 and all(np.isfinite(seen))
+
+
+@pytest.mark.parametrize("pm_too,loss_type", [(True, "L2"), (False, "smooth_L1"), (True, "L1")])
+def test_training_iteration_with_rot_and_trans_distance_losses(ctx, pm_too, loss_type):
+    """train_iter.SE3_DIST_LOSS (deepIM_flownet.py:238-262): rot_loss = 1 - (q_gt . q_est)^2 (LW_ROT) on the normalised quaternion
+    and the L2 / smooth_L1 / L1 translation loss (LW_TRANS) on the ZOOMED deltas, next to or instead of the point-matching loss;
+    forward values and every parameter gradient against the oracle's backward."""
+    B = 1
+    d, cfg, net, params, data_np, label_np = _train_setup(ctx, B, 911, False)
+    t = cfg.train_iter
+    t.SE3_DIST_LOSS, t.SE3_PM_LOSS, t.LW_ROT, t.LW_TRANS, t.TRANS_LOSS_TYPE = True, pm_too, 0.7, 0.3, loss_type
+    net = deepIM_flownet().get_symbol(cfg, is_train=True)
+    net.bind_train(ctx, B, params, num_points=3000)
+    from oracle import se3 as ose3
+    rt = [ose3.calc_RT_delta(d["src_pose"][0][b], d["pose_tgt"][b], cfg.dataset.trans_means, cfg.dataset.trans_stds,
+                             cfg.network.ROT_COORD, "QUAT") for b in range(B)]
+    label_np["rot"] = np.stack([r for r, _ in rt]).astype(np.float32)
+    label_np["trans"] = np.stack([tt for _, tt in rt]).astype(np.float32)
+    data = {k: ctx.array(v) for k, v in data_np.items()}
+    label = {k: ctx.array(v) for k, v in label_np.items()}
+    lib.deepim_set_option(ctx.handle, b"conv_max_split", 1)      # both sides differentiate at the same activations
+    try:
+        net.forward_train(data, label)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_max_split", 0)
+    grads = net.backward()
+    _, g_ref, fwd = opipe.train_iteration(params, data_np, label_np, d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds,
+                                          cfg.network.ROT_COORD, t.LW_PM, t.NUM_3D_SAMPLE, cfg.dataset.NORMALIZE_3D_POINT,
+                                          t.SE3_PM_LOSS_TYPE, t.SE3_PM_SL1_SCALAR, se3_pm_loss=pm_too, se3_dist_loss=True, lw_rot=t.LW_ROT,
+                                          lw_trans=t.LW_TRANS, trans_loss_type=loss_type, trans_sigma=t.TRANS_SMOOTH_L1_SCALAR)
+    np.testing.assert_array_equal(net.act["conv6_1"].asnumpy(), fwd["conv6_1"])
+    close(net.act["zoom_trans_gt"].asnumpy(), fwd["zoom_trans_gt"], 1e-6)
+    close(net.act["rot_loss"].asnumpy(), fwd["rot_loss"], 1e-5)
+    close(net.act["trans_loss"].asnumpy().reshape(B, 3), fwd["trans_loss"].reshape(B, 3), 1e-5)
+    assert float(fwd["rot_loss"].max()) > 1e-6 and float(np.abs(fwd["trans_loss"]).max()) > 1e-8
+    for name in sorted(g_ref):
+        assert np.abs(g_ref[name]).max() > 0, name
+        close(grads[name].asnumpy(), g_ref[name], 2e-4)
+
+
+def test_training_graph_refuses_what_the_reference_graph_does_not_build(ctx):
+    cfg = default_config()
+    cfg.network.PRED_FLOW = cfg.network.PRED_MASK = False
+    cfg.network.ROT_TYPE = "EULER"
+    with pytest.raises(NotImplementedError):
+        deepIM_flownet().get_symbol(cfg, is_train=True)
+    cfg.network.ROT_TYPE = "QUAT"
+    cfg.train_iter.SE3_DIST_LOSS, cfg.train_iter.TRANS_LOSS_TYPE = True, "huber"
+    with pytest.raises(Exception, match="TRANS_LOSS_TYPE"):
+        deepIM_flownet().get_symbol(cfg, is_train=True)
+    cfg.train_iter.SE3_DIST_LOSS, cfg.train_iter.SE3_PM_LOSS = False, False
+    with pytest.raises(NotImplementedError):
+        deepIM_flownet().get_symbol(cfg, is_train=True)

@@ -219,3 +219,106 @@ def test_fused_pose_tail_is_bit_identical_to_the_separate_launches(ctx, B):
     with pytest.raises(RuntimeError):
         lib.deepim_pose_tail_forward(h, f7b, se3b, poseb, d["fc6"], d["w7"], d["b7"], d["w_rot"], d["b_rot"], d["w_tr"], d["b_tr"],
                                      d["zf"], src, mu, sd, 0, B, 128, cf(0.1))
+
+
+def test_euler_test_graph_iteration(ctx, small_batch):
+    """network.ROT_TYPE = "EULER" (deepIM_flownet.py:715, :791-793; tester.py:391-398): a 3-output rot head, se3 = [euler | trans]
+    (B, 6), RT_transform's Euler branch. The head against numpy on the GPU's own fc7, the pose update against the oracle's
+    RT_transform path that tests/golden/se3_extra_golden.npz pins (euler2mat + R_transform / T_transform)."""
+    from oracle import se3 as ose3, zoom as ozoom
+    from mx_deepim_amd.lib.pair_matching import RT_transform as RT
+    d = small_batch
+    B = d["image_observed"].shape[0]
+    cfg = default_config()
+    cfg.network.ROT_TYPE = "EULER"
+    net = deepIM_flownet().get_symbol(cfg)
+    assert net.arg_shape_dict()["rot_weight"] == (3, 256) and net.arg_shape_dict()["rot_bias"] == (3,)
+    params = net.init_weights(cfg, seed=7)
+    assert not params["rot_weight"].any()                       # :791-792 zero-initialised Euler head
+    rng = np.random.default_rng(3)
+    params["rot_weight"] = (0.02 * rng.standard_normal((3, 256))).astype(np.float32)     # a head that actually rotates
+    net.bind(ctx, B, params)
+    data = _data(ctx, d)
+    pose = net.refine_iteration(data).asnumpy()
+    se3 = net.act["se3"].asnumpy()
+    assert se3.shape == (B, 6)
+    fc7 = net.act["fc7"].asnumpy().astype(np.float64)
+    rot = fc7 @ params["rot_weight"].astype(np.float64).T + params["rot_bias"]
+    ztr = (fc7 @ params["trans_weight"].astype(np.float64).T + params["trans_bias"]).astype(np.float32)
+    tr = ozoom.zoom_trans(net.act["zoom_factor"].asnumpy(), ztr, b_inv_zoom=True)
+    assert np.abs(se3[:, :3] - rot).max() <= 1e-5 * max(1.0, np.abs(rot).max())
+    assert np.abs(se3[:, 3:] - tr).max() <= 1e-5 * max(1.0, np.abs(tr).max())
+    assert np.abs(se3[:, :3]).max() > 1e-4
+    # pose update = RT_transform.py:138-151 with euler2mat (axes sxyz): the host mirror's own numpy path is pinned by the golden file
+    src = d["src_pose"][0]
+    for b in range(B):
+        want = np.zeros((3, 4))
+        want[:, :3] = ose3.R_transform(src[b][:, :3].astype(np.float64), RT.euler2mat(*se3[b, :3].astype(np.float64)), cfg.network.ROT_COORD)
+        want[:, 3] = ose3.T_transform(src[b][:, 3].astype(np.float64), se3[b, 3:].astype(np.float64), cfg.dataset.trans_means,
+                                      cfg.dataset.trans_stds, cfg.network.ROT_COORD)
+        assert np.abs(pose[b] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # the separate launches (forward() + pose_update) give the same poses as refine_iteration
+    net.forward(data)
+    np.testing.assert_array_equal(net.pose_update(data["src_pose"]).asnumpy(), pose)
+    with pytest.raises(Exception, match="rot_type"):
+        cfg.network.ROT_TYPE = "AXIS"
+        deepIM_flownet().get_symbol(cfg)
+
+
+@pytest.mark.parametrize("style", ["deepim", "flownet"])
+def test_checkpoint_import_reaches_the_bound_network(ctx, small_batch, tmp_path, style):
+    """SURVEY 8(f2), on the device: a `.params` file (`arg:` / `aux:` keys, `_test` / `_i2r` suffixes — lib/utils/load_model.py:21-30,
+    :61-67) → load_param → init_weights (6-channel FlowNet conv1 zero-padded to the 8-channel graph, deepIM_flownet.py:759-773; what the
+    file lacks is initialised) → bind. Every bound device tensor equals the file; the packed forms are checked through what they
+    compute — the Winograd operand of conv3_1 element by element, and one refinement iteration against the oracle run on the FILE's
+    weights. (The container layout itself is restated from MXNet 1.2 and round-trips through this repo's writer only: unpinned until an
+    MXNet-written file is available — DESIGN.md section 7.)"""
+    from mx_deepim_amd.lib.utils.load_model import load_param, save_checkpoint
+    d = small_batch
+    B = d["image_observed"].shape[0]
+    cfg = default_config()
+    net = deepIM_flownet().get_symbol(cfg)
+    shapes = net.arg_shape_dict()
+    full = deepIM_flownet().get_symbol(cfg).init_weights(cfg, seed=41)
+    if style == "deepim":      # a DeepIM checkpoint: every parameter of the graph, some under the suffixes older files carry
+        ckpt = {(k.replace("_weight", "_weight_test") if k in ("fc6_weight", "rot_weight") else
+                 k.replace("_bias", "_i2r_bias") if k == "conv4_1_bias" else k): v for k, v in full.items()}
+        aux = {"bn_dummy_moving_mean": np.zeros(4, np.float32)}
+    else:                       # a FlowNetS checkpoint: the encoder only, conv1 on 6 RGB-pair channels
+        ckpt = {k: v for k, v in full.items() if k.startswith(("flow_conv1", "conv"))}
+        ckpt["flow_conv1_weight"] = np.ascontiguousarray(full["flow_conv1_weight"][:, :6])
+        aux = {}
+    prefix = str(tmp_path / style)
+    save_checkpoint(prefix, 3, ckpt, aux)
+    arg, aux_l = load_param(prefix, 3, process=True)
+    assert set(aux_l) == set(aux) and not any("_test" in k or "_i2r" in k for k in arg)
+    params = net.init_weights(cfg, arg_params=arg, seed=5)
+    assert set(params) == set(shapes)
+    net.bind(ctx, B, params)
+    for name in shapes:
+        got = net.params[name].asnumpy()
+        if name == "flow_conv1_weight" and style == "flownet":
+            np.testing.assert_array_equal(got[:, :6], full[name][:, :6])
+            assert not got[:, 6:].any()                          # the mask channels start from zero weights
+        elif style == "deepim" or name in ckpt:
+            np.testing.assert_array_equal(got, full[name], err_msg=name)
+        else:
+            assert np.isfinite(got).all() and got.shape == tuple(shapes[name])
+    # the Winograd operand of conv3_1 is G g G^T of the FILE's weights (positions nu = 3 negated), element by element
+    assert "conv3_1" in net.packed_wino
+    w = full["conv3_1_weight"]
+    pk = net.packed_wino["conv3_1"].asnumpy().reshape(w.shape[0] // 32, w.shape[1] // 8, 16, 2, 32, 4)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    U = np.einsum("xa,ocab,nb->ocxn", G, w.astype(np.float64), G).astype(np.float32)
+    U[..., 3] = -U[..., 3]
+    for mb, c8, h, s_ in ((0, 0, 0, 0), (3, 17, 1, 2), (7, 31, 1, 3)):
+        np.testing.assert_array_equal(pk[mb, c8, :, h, :, s_], U[mb * 32:(mb + 1) * 32, c8 * 8 + 4 * h + s_].reshape(32, 16).T)
+    # ... and the network computes with them: one iteration against the oracle on the merged host parameters
+    host = {k: net.params[k].asnumpy() for k in shapes}
+    pose = net.refine_iteration(_data(ctx, d)).asnumpy()
+    ref = opipe.refine_iteration(host, _np_data(d), d["K"], MEANS_REV, cfg.dataset.trans_means, cfg.dataset.trans_stds,
+                                 cfg.network.ROT_COORD, nc8=True)
+    np.testing.assert_array_equal(net.act["net_input"].asnumpy(), ref["net_input"])
+    c6 = net.act["conv6_1"].asnumpy()
+    assert np.abs(c6 - ref["conv6_1"]).max() <= 1e-5 * np.abs(ref["conv6_1"]).max() and np.abs(ref["conv6_1"]).max() > 1e-3
+    assert np.abs(pose - ref["pose_est"]).max() / np.abs(ref["pose_est"]).max() < 1e-4

@@ -332,6 +332,73 @@ def test_eight_rank_launch_rehearsal(global_batch, counts):
     c = d["comm"]
     assert c["backend"] == "host-dry-run" and c["rccl_ranks"] == 0 and c["ranks_reporting"] == 8 and c["allgather_us"] is None
     assert "libamdhip64" in (c["libamdhip64_path"] or "")
+    # every rank's default context is ITS GPU (LOCAL_RANK), not GPU 0 — and a rehearsal opens none
+    assert c["default_device_by_rank"] == list(range(8)) and c["devices_opened_by_rank"] == [[]] * 8
+
+
+def test_default_context_follows_local_rank(monkeypatch):
+    """The host mirrors' convenience calls (RT_transform, mx.nd.array, Render_Py, …) default to Context.default(): DEEPIM_DEVICE, else
+    LOCAL_RANK (one process per GPU), else 0 — never a hard-wired GPU 0 (VERDICT r4 weak #11)."""
+    import re
+    from mx_deepim_amd.runtime import Context
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env, want in (({}, 0), ({"LOCAL_RANK": "5"}, 5), ({"LOCAL_RANK": "5", "DEEPIM_DEVICE": "2"}, 2), ({"LOCAL_RANK": "x"}, 0)):
+        monkeypatch.delenv("LOCAL_RANK", raising=False)
+        monkeypatch.delenv("DEEPIM_DEVICE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setattr(Context, "_default_id", None)
+        assert Context.default_device_id() == want
+    monkeypatch.setattr(Context, "_default_id", None)
+    Context.set_default(3)
+    assert Context.default_device_id() == 3
+    monkeypatch.setattr(Context, "_default_id", None)
+    for dirpath, _, files in os.walk(os.path.join(root, "mx_deepim_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"Context\.get\(0\)", src), os.path.join(dirpath, f)
+
+
+def test_operator_props_parse_boolean_kwargs_like_the_reference():
+    """`s.lower() == "true"` everywhere (zoom_trans.py:81-82, zoom_flow.py:85, zoom_mask_with_factor.py:77, flow_updater.py:118) but in
+    Transform3D, which uses distutils' strtobool (transform3d.py:290)."""
+    from mx_deepim_amd.operator_py._common import istrue, strtobool
+    assert istrue("True") and istrue("TRUE") and istrue(True) and not istrue("1") and not istrue("yes") and not istrue("on") and not istrue("False")
+    assert strtobool("1") and strtobool("yes") and not strtobool("off")
+    with pytest.raises(ValueError):
+        strtobool("maybe")
+    f = mx.operator.get_registered("ZoomFlow")(b_inv_zoom="1")
+    assert f.b_inv_zoom is False
+    z = mx.operator.get_registered("ZoomTrans")(b_inv_zoom="true", b_zoom_grad="yes")
+    assert z.b_inv_zoom is True and z.b_zoom_grad is False
+
+
+def test_graph_flags_are_wired_or_refused():
+    """ROT_TYPE (deepIM_flownet.py:715, :791-793), SE3_DIST_LOSS / TRANS_LOSS_TYPE (:238-262): honoured or refused, never ignored."""
+    from mx_deepim_amd.config import default_config
+    from mx_deepim_amd.symbols import deepIM_flownet
+    cfg = default_config()
+    cfg.network.ROT_TYPE = "EULER"
+    net = deepIM_flownet().get_symbol(cfg)
+    sh = net.arg_shape_dict()
+    assert net.rot_param == 3 and sh["rot_weight"] == (3, 256) and sh["rot_bias"] == (3,)
+    assert not net.init_weights(cfg, seed=1)["rot_weight"].any()
+    with pytest.raises(NotImplementedError):
+        deepIM_flownet().get_symbol(cfg, is_train=True)
+    cfg.network.ROT_TYPE = "AXIS"
+    with pytest.raises(Exception, match="rot_type"):
+        deepIM_flownet().get_symbol(cfg)
+    cfg.network.ROT_TYPE = "QUAT"
+    cfg.train_iter.SE3_DIST_LOSS = True
+    tnet = deepIM_flownet().get_symbol(cfg, is_train=True)
+    assert tnet.se3_dist_loss and tnet.trans_loss_type == "L2"
+    cfg.train_iter.TRANS_LOSS_TYPE = "huber"
+    with pytest.raises(Exception, match="TRANS_LOSS_TYPE"):
+        deepIM_flownet().get_symbol(cfg, is_train=True)
+    cfg.network.REGRESSOR_NUM = 2
+    with pytest.raises(Exception, match="NOT IMPLEMENTED"):
+        deepIM_flownet().get_symbol(cfg)
 
 
 def test_weak_scaling_is_opt_in():
@@ -351,8 +418,10 @@ def test_weak_scaling_is_opt_in():
 
 
 def test_cpu_baseline_follows_the_stated_protocol():
-    """bench.py's `cpu_baseline` (BASELINE.md section 3): one untimed warm-up pair-iteration, then the timed ones, value = 1 / median;
-    the record names the threads used, nproc and OMP_NUM_THREADS. (Two timed runs here; the bench takes >= 5.)"""
+    """bench.py's `cpu_baseline`: whole pair-iterations = oracle zoom -> the N-group on oneDNN
+    (torch-CPU) -> oracle pose update, threads pinned to the physical cores, one untimed warm-up call then the timed ones, value = pairs /
+    median, GFLOP/s of the convolution stack stated; the checker's own (bit-identical) build of the same iteration rides along as the
+    secondary figure. (Two timed calls here; the bench takes >= 5.)"""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
@@ -365,13 +434,62 @@ def test_cpu_baseline_follows_the_stated_protocol():
     net = deepIM_flownet().get_symbol(cfg)
     params = net.init_weights(cfg, seed=5)
     batch = synthetic.make_batch(2, seed=7, n_frames=1)
-    r = bench.cpu_baseline(params, cfg, batch, budget_s=0.0, min_runs=2, max_runs=2)
-    sp = r["seconds_per_iteration"]
-    assert r["kind"] == "port" and r["cores"] >= 1 and r["nproc"] == os.cpu_count() and "omp_num_threads" in r
-    assert abs(r["value"] - 1.0 / sp["median"]) < 1e-9 * r["value"] and sp["min"] <= sp["median"] <= sp["max"]
-    assert "1 untimed warm-up" in r["protocol"] and "2 timed" in r["protocol"]
+    r = bench.cpu_baseline(params, cfg, batch, budget_s=0.0, min_runs=2, max_runs=2, pairs=2)
+    cores = bench.physical_cores()
+    assert 1 <= cores <= os.cpu_count()
+    assert r["kind"] == "port" and r["cores"] == cores and r["threads"] == cores and r["nproc"] == os.cpu_count()
+    sp = r["seconds_per_call"]
+    assert abs(r["value"] - 2.0 / sp["median"]) < 1e-9 * r["value"] and sp["min"] <= sp["median"] <= sp["max"]
+    assert r["gflops"] > 1.0 and 0 < r["n_group_share_of_time"] < 1
+    assert "1 untimed warm-up" in r["protocol"] and "2 timed" in r["protocol"] and "oneDNN" in r["sample"]
+    c = r["secondary_checker_build"]
+    si = c["seconds_per_iteration"]
+    assert c["kind"] == "port" and c["threads"] == cores and "omp_num_threads" in c and c["gflops"] > 0.1
+    assert abs(c["value"] - 1.0 / si["median"]) < 1e-9 * c["value"] and si["min"] <= si["median"] <= si["max"]
+    assert r["value"] > c["value"]            # the library convolutions beat the one-chain-per-output checker build
     from oracle import net as onet
     assert onet.BLOCKED is False            # the timing switch is reset: the checker stays the checker
+
+
+def test_bench_roofline_block_is_physical(tmp_path):
+    """bench.py's `roofline` object: `frac` = executed FLOPs over the dense peak (<= 1); the algorithmic figure —
+    which the Winograd layers push past the peak — sits beside it; the per-kernel table is read from the recorded pass when it was
+    taken at this batch size."""
+    import json
+    import bench
+    pk = {"batch": 32, "source": "test", "sum_ms": 6.0, "bench_ms_per_launch_group_same_run": 6.01,
+          "per_kernel": [{"layer": "conv1", "frac": 0.78}], "roofline_hbm": [{"kernel": "flow_kernel", "frac": 0.43}]}
+    path = str(tmp_path / "per_kernel.json")
+    json.dump(pk, open(path, "w"))
+    rl, hbm = bench.roofline_block("k", 1242.7e9, 734.0e9, 6.1, 157.3, ["conv2"], None, None, path, 32)
+    assert abs(rl["achieved"] - 734.0e9 / 6.1e-3 / 1e12) < 1e-9 and abs(rl["frac"] - rl["achieved"] / 157.3) < 1e-12 and rl["frac"] <= 1.0
+    assert rl["algorithmic_over_peak"] > 1.0 and abs(rl["algorithmic_tflops"] - 1242.7e9 / 6.1e-3 / 1e12) < 1e-9
+    assert rl["per_kernel"] == pk["per_kernel"] and hbm == pk["roofline_hbm"]
+    rl4, hbm4 = bench.roofline_block("k", 155.3e9, 100e9, 1.2, 157.3, ["conv2"], None, None, path, 4)
+    assert "per_kernel" not in rl4 and hbm4 is None                      # recorded at another batch size: not quoted
+    rlx, hbmx = bench.roofline_block("k", 100e9, 100e9, 1.0, 2500.0, [], None, None, path, 32, plain=False)
+    assert "per_kernel" not in rlx and hbmx is None and rlx["frac"] == rlx["algorithmic_over_peak"]
+
+
+def test_recorded_per_kernel_table_is_consistent():
+    """profiles/per_kernel.json (tools/profile_summary.py perkernel, from the rocprofv3 pass of the default bench command): every fraction is
+    <= 1, the per-layer times sum to the conv launch group bench.py's own HIP events measured in the SAME run within 2 %, and every kernel
+    SURVEY 8(d) lists has its HBM entry."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "per_kernel.json")
+    if not os.path.exists(path):
+        pytest.skip("no recorded pass committed yet")
+    d = json.load(open(path))
+    assert [r["layer"] for r in d["per_kernel"]] == ["conv1", "conv2", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"]
+    for r in d["per_kernel"]:
+        assert 0 < r["frac"] <= 1.0 and r["executed_tflops"] <= r["algorithmic_tflops"] + 1e-9, r
+        assert r["mfma_busy"] is None or 0 < r["mfma_busy"] <= 1.0
+    assert abs(sum(r["ms"] + r["split_k_reduce_ms"] for r in d["per_kernel"]) - d["sum_ms"]) < 1e-9
+    assert abs(d["sum_ms"] - d["bench_ms_per_launch_group_same_run"]) <= 0.02 * d["bench_ms_per_launch_group_same_run"]
+    names = {r["kernel"].split("<")[0] for r in d["roofline_hbm"]}
+    assert {"flow_kernel", "resolve_kernel", "upsample16_kernel", "resample4_kernel", "conv_fewout_kernel"} <= names
+    assert all(0 < r["frac"] <= 1.0 for r in d["roofline_hbm"])
 
 
 def test_bench_executed_flops_count_what_the_winograd_layers_run():

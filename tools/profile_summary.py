@@ -218,7 +218,8 @@ def cmd_perkernel(a):
             occ = defaultdict(int)
             for r, n in zip(hr[lo:hi], hn[lo:hi]):
                 base = re.sub(r"<.*$", "", n)
-                if base not in ("flow_kernel", "resolve_kernel", "upsample16_kernel", "resample4_kernel", "conv_fewout_kernel"):
+                if base not in (("flow_kernel", "resolve_kernel", "upsample16_kernel", "resample4_kernel", "conv_fewout_kernel") if it
+                                else ("flow_kernel",)):     # the training-step trace: lib/flow_c's kernel only (its other launches mix shapes)
                     continue
                 o = occ[base] if it else 0
                 occ[base] += 1
