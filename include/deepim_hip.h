@@ -291,6 +291,9 @@ int deepim_conv2d_forward_ex(deepim_ctx* ctx, float* out, const float* in, const
                              const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                              int stride, int pad, float slope, int out_ctotal, int out_coff, int in_nc8, int out_nc8);
 int deepim_relayout_nc8(deepim_ctx* ctx, float* dst, const float* src, int B, int C, size_t hw, int to_nc8);
+/* The same conversion (NC8 -> NCHW) written into channels [dst_coff, dst_coff + C) of a dst_ctotal-channel NCHW tensor: the encoder
+ * skip connections of the refinement decoder (Concat, deepim/symbols/deepIM_flownet.py:128-131, :143-146) in one pass. */
+int deepim_relayout_nc8_slice(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff, const float* src_nc8, int B, int C, size_t hw);
 /* The encoder's 3x3 stride-1 pad-1 layers (conv3_1 / conv4_1 / conv5_1 / conv6_1, deepIM_flownet.py:69-101) as fp32 Winograd
  * F(2x2,3x3): the same fp32 arithmetic with 2.25x fewer multiplies, a different summation (NOT the direct kernels' fmaf chain:
  * within 1e-5 of the layer's range, tests/test_gpu_wino.py). `in` is NC8; `out` NC8 (out_nc8 = 1) or channels [out_coff,

@@ -1143,8 +1143,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_nc8_kernel(float* __restric
 }
 
 // NC8 <-> NCHW re-layout of an activation tensor (decoder skip connections, tests)
+// (ctotal / coff: the NCHW side is channels [coff, coff + C) of a ctotal-channel tensor — a decoder concat buffer)
 __global__ __launch_bounds__(256) void relayout_nc8_kernel(float* __restrict__ dst, const float* __restrict__ src, int C,
-                                                           int hw, long total, int to_nc8) {
+                                                           int hw, long total, int to_nc8, int ctotal = 0, int coff = 0) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;   // index in the NC8 tensor
   if (i >= total) return;
   const int q = (int)(i & 7);
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(256) void relayout_nc8_kernel(float* __restrict__ d
   const int C8 = C >> 3;
   const long n = nc8 / C8;
   const int c = (int)(nc8 % C8) * 8 + q;
-  const long j = (n * C + c) * hw + pix;                 // index in the NCHW tensor
+  const long j = ctotal ? (n * ctotal + coff + c) * hw + pix : (n * C + c) * hw + pix;                 // index in the NCHW tensor
   if (to_nc8) dst[i] = src[j]; else dst[j] = src[i];
 }
 
@@ -1309,6 +1310,43 @@ __global__ __launch_bounds__(256) void upsample16_kernel(float* __restrict__ out
     }
   }
   out[((long)bc * Ho + yo) * Wo + xo] = acc * scale;
+}
+
+// the same, four consecutive outputs of a row per thread (Wo % 4 == 0, crop_x % 4 == 0: they share the <= 2x2 contributing inputs, their
+// weights are one aligned float4 per input, the store is 16 bytes; every output sums in the scalar kernel's order: bit-identical).
+// The one-output kernel moved 0.15-0.16 of the HBM rate at B = 32 (profiles/per_kernel.json): instruction-bound, not byte-bound.
+__global__ __launch_bounds__(256) void upsample16x4_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                           const float* __restrict__ w, int C, int H, int W, int Ho, int Wo,
+                                                           int crop_y, int crop_x, float scale, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // (bc, yo, xo / 4)
+  if (i >= total) return;
+  const int wq = Wo >> 2;
+  const int xq = (int)(i % wq);
+  const long r = i / wq;
+  const int yo = (int)(r % Ho);
+  const long bc = r / Ho;
+  const int c = (int)(bc % C);
+  const int y = yo + crop_y, x0 = 4 * xq + crop_x;
+  const float* ip = in + bc * H * W;
+  const float* wp = w + (long)c * 1024;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int iy_hi = y >> 4, ix_hi = x0 >> 4;
+#pragma unroll
+  for (int dy = 1; dy >= 0; --dy) {
+    const int iy = iy_hi - dy;
+    const int ky = y - iy * 16;
+    if (iy < 0 || iy >= H || ky >= 32) continue;
+#pragma unroll
+    for (int dx = 1; dx >= 0; --dx) {
+      const int ix = ix_hi - dx;
+      const int kx = x0 - ix * 16;
+      if (ix < 0 || ix >= W || kx + 3 >= 32) continue;
+      const float v = ip[iy * W + ix];
+      const float4 wv = *reinterpret_cast<const float4*>(wp + ky * 32 + kx);
+      acc.x = fmaf(v, wv.x, acc.x); acc.y = fmaf(v, wv.y, acc.y); acc.z = fmaf(v, wv.z, acc.z); acc.w = fmaf(v, wv.w, acc.w);
+    }
+  }
+  *reinterpret_cast<float4*>(out + (bc * Ho + yo) * Wo + 4 * xq) = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
 }
 
 struct TileChoice { int bm, bn, ksplit, tail_s; };
@@ -2085,9 +2123,15 @@ extern "C" int deepim_upsample16_crop_forward(deepim_ctx* ctx, float* out, const
                                               float scale) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
-  dim3 grid(di_div_up(Wo, 256), Ho, B * C);
-  hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
-                     scale);
+  if ((Wo & 3) == 0 && (crop_x & 3) == 0 && crop_x >= 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+    const long total = (long)B * C * Ho * (Wo >> 2);      // four outputs of a row per thread
+    hipLaunchKernelGGL(upsample16x4_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y,
+                       crop_x, scale, total);
+  } else {
+    dim3 grid(di_div_up(Wo, 256), Ho, B * C);
+    hipLaunchKernelGGL(upsample16_kernel, grid, dim3(256), 0, ctx->stream, out, in, w, C, H, W, Ho, Wo, crop_y, crop_x,
+                       scale);
+  }
   DI_LAUNCH_CHECK();
   return 0;
 }
@@ -2112,6 +2156,20 @@ extern "C" int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float*
   DI_REQUIRE((C & 7) == 0 && ((H | W) & 1) == 0, "relayout_nc8_s2d: C % 8 == 0, even H and W");
   const long total = (long)B * C * H * W;
   hipLaunchKernelGGL(relayout_s2d_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dst, src, C, H, W, total, to_s2d);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
+// NC8 -> NCHW straight into channels [dst_coff, dst_coff + C) of a dst_ctotal-channel tensor: the skip connections of the refinement
+// decoder (Concat2 / Concat3, deepIM_flownet.py:128-131, :143-146) without the intermediate NCHW copy and its 2-D blit
+extern "C" int deepim_relayout_nc8_slice(deepim_ctx* ctx, float* dst, int dst_ctotal, int dst_coff, const float* src_nc8, int B, int C,
+                                         size_t hw) {
+  DI_DEVICE(ctx);
+  if (B == 0 || C == 0) return 0;
+  DI_REQUIRE((C & 7) == 0 && dst_ctotal >= dst_coff + C && dst_coff >= 0, "relayout_nc8_slice: C % 8 == 0 and the slice inside the tensor");
+  const long total = (long)B * C * (long)hw;
+  hipLaunchKernelGGL(relayout_nc8_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, dst, src_nc8, C, (int)hw, total, 0,
+                     dst_ctotal, dst_coff);
   DI_LAUNCH_CHECK();
   return 0;
 }

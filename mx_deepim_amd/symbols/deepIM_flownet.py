@@ -606,15 +606,26 @@ class deepIM_flownet(object):
                                      self.T_stds, self.rot_coord, B, 256, ctypes.c_float(SLOPE))
         return out
 
+    def _skip_into(self, cat, ctotal, name, C, hw):
+        """Concat's first input: encoder activation `name` into channels [0, C) of the concat tensor — straight from the channel-blocked
+        tensor where the encoder ran channel-blocked (one pass instead of relayout + 2-D blit), else a slice copy."""
+        A, h, B = self.act, self.ctx.handle, self.B
+        names = [g[0] for g in self.enc_geom]
+        if (getattr(self, "act_layout", "nchw") == "nc8" and not self.fp16_conv and name in names[:-1]
+                and self._enc_out_mode(names.index(name)) != 3):
+            lib.deepim_relayout_nc8_slice(h, A[cat], ctotal, 0, A[name], B, C, hw)
+        else:
+            lib.deepim_copy_channels(h, A[cat], ctotal, 0, self.activation_nchw(name), C, B, hw)
+
     def decoder(self):
         """FlowNetS refinement (deepIM_flownet.py:120-167)."""
         A, h, B = self.act, self.ctx.handle, self.B
         self._conv("Convolution1", A["conv6_1"], A["flow6"], B, 1024, 8, 10, 2, 3, 1, 1, 1.0)
-        lib.deepim_copy_channels(h, A["Concat2"], 1026, 0, self.activation_nchw("conv5_1"), 512, B, 15 * 20)
+        self._skip_into("Concat2", 1026, "conv5_1", 512, 15 * 20)
         self._deconv("deconv5", A["conv6_1"], A["Concat2"], B, 1024, 8, 10, 512, 15, 20, SLOPE, 1026, 512)
         self._deconv("upsample_flow6to5", A["flow6"], A["Concat2"], B, 2, 8, 10, 2, 15, 20, 1.0, 1026, 1024)
         self._conv("Convolution2", A["Concat2"], A["flow5"], B, 1026, 15, 20, 2, 3, 1, 1, 1.0)
-        lib.deepim_copy_channels(h, A["Concat3"], 770, 0, self.activation_nchw("conv4_1"), 512, B, 30 * 40)
+        self._skip_into("Concat3", 770, "conv4_1", 512, 30 * 40)
         self._deconv("deconv4", A["Concat2"], A["Concat3"], B, 1026, 15, 20, 256, 30, 40, SLOPE, 770, 512)
         self._deconv("upsample_flow5to4", A["flow5"], A["Concat3"], B, 2, 15, 20, 2, 30, 40, 1.0, 770, 768)
 

@@ -392,7 +392,10 @@ def test_upsample16_crop(ctx):
     w = onet.bilinear_upsample_weights(2)
     out = ctx.empty((2, 2, 480, 640))
     lib.deepim_upsample16_crop_forward(ctx.handle, out, ctx.array(x), ctx.array(w), 2, 2, 30, 40, 480, 640, 8, 8, cf(20.0))
-    np.testing.assert_array_equal(out.asnumpy(), onet.upsample16_crop(x, w, 480, 640, (8, 8), 20.0))
+    np.testing.assert_array_equal(out.asnumpy(), onet.upsample16_crop(x, w, 480, 640, (8, 8), 20.0))      # four outputs per thread
+    out2 = ctx.empty((2, 2, 470, 638))      # a width / crop the 16-byte form does not take: the one-output kernel, the same bits
+    lib.deepim_upsample16_crop_forward(ctx.handle, out2, ctx.array(x), ctx.array(w), 2, 2, 30, 40, 470, 638, 5, 9, cf(1.0))
+    np.testing.assert_array_equal(out2.asnumpy(), onet.upsample16_crop(x, w, 470, 638, (5, 9), 1.0))
 
 
 @pytest.mark.parametrize("shape", [(16, 81920, 256), (3, 256, 256), (2, 256, 4), (17, 1024, 40)])

@@ -75,3 +75,25 @@ def test_layer_selection_rule():
     assert not L.deepim_conv_wino_preferred_s2d(None, 32, 64, 241, 320, 128)          # odd height: no space-to-depth form
     assert L.deepim_conv_wino_packed_size(256, 256) == 256 * 256 * 64
     assert L.deepim_conv_wino_preferred(None, 64, 256, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 512, 256, 60, 80, 256)   # >= 2 GiB input
+
+
+def test_f4x4_3x3_in_float32_misses_the_layer_bar():
+    """VERDICT r4 item 4 (exploratory, kill criterion "every layer <= 1e-5 of its range"): F(4x4, 3x3) is the same convolution in exact
+    arithmetic, but carried in float32 its interpolation points +-2 and 1/24 cost an order of magnitude over F(2x2, 3x3) — at the
+    bar on conv3_1's 256 input channels, over it on conv4_1's 512 — before a kernel's longer sequential MFMA chains add theirs. Killed
+    on this evidence without a GPU session; F(2x2, 3x3) stays the fp32 Winograd form."""
+    from oracle import wino
+    rng = np.random.default_rng(0)
+    errs = {}
+    for cin in (256, 512):
+        x = rng.standard_normal((1, cin, 12, 16)).astype(np.float32)
+        x *= rng.uniform(size=x.shape) > 0.3
+        w = (rng.standard_normal((64, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+        ref = wino.winograd_f2x2_3x3(x.astype(np.float64), w.astype(np.float64))
+        assert np.abs(wino.winograd_f4x4_3x3(x.astype(np.float64), w.astype(np.float64)) - ref).max() < 1e-12      # the identity
+        scale = np.abs(ref).max()
+        errs[cin] = (np.abs(wino.winograd_f2x2_3x3(x, w, np.float32) - ref).max() / scale,
+                     np.abs(wino.winograd_f4x4_3x3(x, w, np.float32) - ref).max() / scale)
+    assert errs[256][0] < 2e-6 and errs[512][0] < 2e-6            # F(2x2): a comfortable factor inside the bar
+    assert errs[256][1] > 5e-6 and errs[512][1] > 1e-5            # F(4x4): at the bar / over it
+    assert errs[512][1] > 10 * errs[512][0]

@@ -1,0 +1,7 @@
+#!/bin/bash
+# A/B of library builds in ONE box (boxes differ by a few per cent): variants/lib_<name>.so, interleaved, twice
+cd /root/repo
+for rep in 1 2; do for v in $(ls variants | sed 's/lib_//; s/.so//'); do
+  echo "== $v (pass $rep)"
+  DEEPIM_LIB=variants/lib_$v.so WINO_LAYERS=${WINO_LAYERS:-conv3_1,conv4_1,conv2,conv3} timeout 200 python tools/bench_wino.py ${AB_BATCH:-32} 2>&1 | cut -c1-75
+done; done | tee gpurun_out/ab.log
