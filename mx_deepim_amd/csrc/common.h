@@ -70,7 +70,7 @@ struct deepim_ctx {
   int wgrad_lds;         // 1 (default): LDS-staged weight-gradient kernel; 0: the round-2 register-fed kernel (A/B measurements)
   int wino_s2d_skip;     // 1 (default): stride-2 Winograd layers skip the positions whose weights are identically zero; 0: all 16 (A/B measurements)
   int wino_shared;       // 1 (default): Winograd layers with Cout % 64 == 0 on the 8-wave shared-transform kernel (conv_wino8_kernel); 0: the round-4 one-wave kernel
-  int wino_wide;         // 1 (default): shared-transform blocks of 128 channels x 32 tiles where Cout % 128 == 0 (measured 2-4 % faster on every encoder layer); 0: 64 x 64 everywhere
+  int wino_wide;         // block shape of the shared-transform kernel: 1 (default) = per layer by the work per CU, 0 = 64 ch x 64 tiles, 3 = 128 x 32, 2 = 64 x 32 on four waves (two blocks per CU)
   int wino_split;        // K-split of the shared-transform kernel: 0 (default) = the plan of wino8_split_plan, 1 = never, n = at most n slices
   int wino_two_wave;     // 0 (default): Winograd layers on the one-wave 16-position kernel; 1: the two-waves-per-SIMD kernel (measured slower on the big layers)
   int f16_dev_flags;     // dev: DI_F16_* bits — alternative tilings of the fp16 / x3 conv kernels (default 0)

@@ -201,7 +201,7 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "wgrad_lds") == 0) { ctx->wgrad_lds = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_two_wave") == 0) { ctx->wino_two_wave = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_split") == 0) { ctx->wino_split = value < 0 ? 0 : value; return 0; }
-  if (strcmp(name, "wino_wide") == 0) { ctx->wino_wide = value ? 1 : 0; return 0; }
+  if (strcmp(name, "wino_wide") == 0) { ctx->wino_wide = (value >= 0 && value <= 3) ? value : 1; return 0; }
   if (strcmp(name, "wino_shared") == 0) { ctx->wino_shared = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_s2d_skip") == 0) { ctx->wino_s2d_skip = value ? 1 : 0; return 0; }
   if (strcmp(name, "f16_dev_flags") == 0) { DI_REQUIRE(value >= 0 && value < 32, "f16_dev_flags: bits 0..4"); ctx->f16_dev_flags = value; return 0; }

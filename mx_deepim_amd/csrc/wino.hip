@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W8_HS 576
 #define W8_TGS 1152
 #define W8_QSW 1168                      /* WIDE: one tile half */
+#define W8_LDS_HALF_BYTES (2 * 16 * W8_QSW)   /* 37 376 B: two slots of one tile half (SHAPE 2; its output exchange takes 32 KB) */
 #define W8_LDS_BYTES (2 * 16 * W8_QS)     /* 74 240 B: two V slots of 37 120 B — every offset of either slot fits the ds 16-bit immediate; the output exchange reuses the first 64 KB */
 
 // PH: the wave's half (0 top: xi = 0, 1; 1 bottom: xi = 2, 3) as a COMPILE-TIME constant — the two halves run different streams, and
@@ -580,17 +581,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // across the joins (hundreds of scratch spills); the kernel branches once, at its top, into two complete bodies.
 // WIDE: the block is 128 output channels x 32 tiles instead of 64 x 64 (every V feeds 128 channels: half the transform work per MFMA,
 // a lane of the transform owns TWO channels of a patch column; the weights of a step are read once per 32 tiles instead of per 64)
-template <int OUT_NC8, int S2D, int PH, int WIDE>
+// SHAPE 2: the block is 64 channels x 32 tiles on FOUR waves (one per SIMD), two blocks per CU: each SIMD then runs a wave of either
+// block, the blocks run independently — one block's prologue / output transform / stores under the other's MFMAs, and a last partial
+// round of lone blocks runs faster instead of idling half the chip's issue slots.
+template <int OUT_NC8, int S2D, int PH, int SHAPE>
 __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave) {
+  constexpr int WIDE = SHAPE == 1, HALF = SHAPE == 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   constexpr int ph = PH;
   constexpr int NSUB = WIDE ? 4 : 2;          // 32-channel sub-blocks of the block
-  constexpr int TB = WIDE ? 32 : 64;          // tiles of the block
-  constexpr int QS = WIDE ? W8_QSW : W8_QS;   // V bytes per position
+  constexpr int TB = (WIDE || HALF) ? 32 : 64;          // tiles of the block
+  constexpr int QS = (WIDE || HALF) ? W8_QSW : W8_QS;   // V bytes per position
   constexpr int VSLOT = 16 * QS;
   using tvec = typename std::conditional<WIDE != 0, f32x2, f32x4>::type;   // a transform lane's channels
-  const int msub = WIDE ? (wave & 3) : (wave & 1), tg = WIDE ? 0 : (wave >> 1) & 1;
+  const int msub = WIDE ? (wave & 3) : (wave & 1), tg = (WIDE || HALF) ? 0 : (wave >> 1) & 1;
   const int lrow = lane >> 5, lcol = lane & 31;
   int mb2, bx;
   {
@@ -634,7 +639,8 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
   const float sgn = j == 1 ? 1.f : -1.f;
   // V of a position: [tile half][k half h][tile][16 B = channels 4h .. 4h+3] (+ pads: the 8 / 16 lanes of a store group hit 32 banks)
-  const unsigned vw = WIDE ? (unsigned)((cg >> 1) * W8_HS + (cg & 1) * 8 + Tl * 16 + j * QS)
+  const unsigned vw = WIDE ? (unsigned)((cg >> 1) * W8_HS + (cg & 1) * 8 + Tl * 16 + j * QS) :
+                      HALF ? (unsigned)(cg * W8_HS + Tl * 16 + j * QS)
                            : (unsigned)((Tl >> 5) * W8_TGS + cg * W8_HS + (Tl & 31) * 16 + j * QS);
   // ---- multiply role
   const unsigned rb = (unsigned)(ph * 8 * QS + tg * W8_TGS + lrow * W8_HS + lcol * 16);
@@ -862,7 +868,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const float* const biasp = p.ksplit > 1 ? nullptr : p.bias;
   const float slope_e = p.ksplit > 1 ? 1.f : p.slope;
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
-  const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ 4) * 2048 + lanee;
+  const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ (HALF ? 2 : 4)) * 2048 + lanee;
   // whole-vector forms: reading single elements of an AGPR-resident f32x16 makes the compiler copy all 16 registers each time
   f32x16 sx[2][2];   // [x][b], all 16 rows
 #pragma unroll
@@ -932,13 +938,22 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_LDS4
 }
 
-template <int OUT_NC8, int S2D, int WIDE>
+template <int OUT_NC8, int S2D, int SHAPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // waves w and w + 4 share a SIMD: a top and a bottom half each
-  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, WIDE>(p, smem, wave);
-  else wino8_body<OUT_NC8, S2D, 1, WIDE>(p, smem, wave);
+  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, SHAPE>(p, smem, wave);
+  else wino8_body<OUT_NC8, S2D, 1, SHAPE>(p, smem, wave);
+}
+
+// SHAPE 2: four waves, two blocks per CU (the register file holds two waves of 256 registers per SIMD: one of each block)
+template <int OUT_NC8, int S2D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(WinoParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[W8_LDS_HALF_BYTES];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (((wave >> 1) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, 2>(p, smem, wave);
+  else wino8_body<OUT_NC8, S2D, 1, 2>(p, smem, wave);
 }
 
 // Second pass of a split K loop of conv_wino8_kernel: sums the S raw copies (same layout as the output), adds the bias, applies the
@@ -975,7 +990,7 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(float* __restrict__ ou
 // time): S slices of ks steps each so that blocks x S fills whole rounds; cost model = rounds x (steps + per-block prologue/epilogue,
 // ~6 steps' worth) + the second pass (S + 1 passes over the output at ~4 TB/s, in steps of ~1.7 us). Deterministic: a function of
 // the geometry only. step_granule: 2 (slot parity) or 8 (the stride-2 form's loop body).
-static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb, int max_split, int* kslice) {
+static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb, int max_split, int* kslice, int slots = 256) {
   int best = 1;
   double best_cost = 1e30;
   for (int S = 1; S <= 16; ++S) {
@@ -984,7 +999,7 @@ static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb
     if (S > 1 && ks < 8) break;
     const int Seff = di_div_up(nK, ks);
     if (Seff != S) continue;
-    const double rounds = (double)di_div_up(blocks * S, 256);
+    const double rounds = (double)di_div_up(blocks * S, slots);
     double cost = rounds * (ks + 6.0);
     if (S > 1) cost += (S + 1) * out_mb / 4000.0 / 1.7e-3 + 1.5;   // MB / (MB per ms) -> ms -> steps; + a launch boundary
     if (cost < best_cost - 1e-9) { best_cost = cost; best = S; *kslice = ks; }
@@ -1104,8 +1119,17 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.ntiles = B * p.TY * p.TX;
   const bool two_wave = ctx->wino_two_wave != 0;   // dev option: two 8-position waves per SIMD on 64-tile blocks instead of one 16-position wave
   const bool shared = !two_wave && ctx->wino_shared && (Cout & 63) == 0;   // default: the 8-wave shared-transform kernel
-  const bool wide = shared && (Cout & 127) == 0 && ctx->wino_wide != 0;    // on 128 channels x 32 tiles (else 64 x 64)
-  p.gx = di_div_up(p.ntiles, wide ? 32 : (two_wave || shared) ? 64 : 128);
+  // block shape (ctx->wino_wide): 0 = 64 x 64; 3 = 128 channels x 32 tiles where Cout % 128 == 0; 2 = 64 x 32 on four waves, two blocks
+  // per CU; 1 (default) = by the work per CU: the wide blocks share each V among 128 channels and win the long grids (2-4 %), the
+  // four-wave blocks overlap one block's prologue / epilogue with the other's loop and win where a CU sees few blocks — measured
+  // (tools/bench_wino.py at B = 4 / 8 / 32, both forms): the crossover sits near 100 steps of 8 input channels per CU
+  bool half = shared && ctx->wino_wide == 2;
+  if (shared && ctx->wino_wide == 1) {
+    const long wide_blocks = (long)di_div_up(p.ntiles, 32) * di_div_up(Cout, 128);
+    half = wide_blocks * (Cin / 8) <= 100L * 256 || (Cout & 127) != 0;
+  }
+  const bool wide = shared && !half && (Cout & 127) == 0 && ctx->wino_wide != 0;
+  p.gx = di_div_up(p.ntiles, (wide || half) ? 32 : (two_wave || shared) ? 64 : 128);
   p.gy = wide ? Cout / 128 : shared ? Cout / 64 : Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
@@ -1123,7 +1147,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     const int nK = Cin / 8;
     const size_t out_elems = (size_t)B * Cout * H * W;
     int ks = nK;
-    const int S = ctx->wino_split == 1 ? 1 : wino8_split_plan(grid, nK, ph8 ? 8 : 2, out_elems * 4 / 1e6, ctx->wino_split, &ks);
+    const int S = ctx->wino_split == 1 ? 1 : wino8_split_plan(grid, nK, ph8 ? 8 : 2, out_elems * 4 / 1e6, ctx->wino_split, &ks, half ? 512 : 256);
     p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0;
     float* final_out = out;
     if (S > 1) {
@@ -1135,7 +1159,8 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
       grid *= S;
     }
 #define W8_LAUNCH(O, S)                                                                               \
-    if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                           \
+    if (half) conv_wino4_kernel<O, S><<<grid, 256, 0, ctx->stream>>>(p);                              \
+    else if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                      \
     else conv_wino8_kernel<O, S, 0><<<grid, 512, 0, ctx->stream>>>(p);
     if (ph8) {
       if (out_nc8) { W8_LAUNCH(1, 1) } else { W8_LAUNCH(0, 1) }

@@ -13,13 +13,14 @@ cf = ctypes.c_float
 TOL = 1e-5
 
 
-@pytest.fixture(params=["shared", "shared_wide", "one_wave", "two_wave"],
-                ids=["shared_transform_64x64", "shared_transform_128x32", "one_wave_per_simd", "two_waves_per_simd"], autouse=True)
+@pytest.fixture(params=["shared", "shared_wide", "shared_half", "one_wave", "two_wave"],
+                ids=["shared_transform_64x64", "shared_transform_128x32", "shared_transform_64x32_two_blocks_per_cu", "one_wave_per_simd",
+                     "two_waves_per_simd"], autouse=True)
 def wino_kernel(ctx, request):
     """Every test on all kernels: the 8-wave shared-transform blocks (64 channels x 64 tiles wherever Cout % 64 == 0, 128 x 32 wherever
-    Cout % 128 == 0; the one-wave kernel otherwise), the round-4 one-wave kernel alone, and the optional two-wave form."""
+    Cout % 128 == 0, 64 x 32 on four waves with two blocks per CU; the one-wave kernel otherwise), the round-4 one-wave kernel alone, and the optional two-wave form."""
     lib.deepim_set_option(ctx.handle, b"wino_shared", 1 if request.param.startswith("shared") else 0)
-    lib.deepim_set_option(ctx.handle, b"wino_wide", 1 if request.param == "shared_wide" else 0)
+    lib.deepim_set_option(ctx.handle, b"wino_wide", {"shared_wide": 3, "shared_half": 2}.get(request.param, 0))
     lib.deepim_set_option(ctx.handle, b"wino_two_wave", 1 if request.param == "two_wave" else 0)
     yield "shared" if request.param.startswith("shared") else request.param
     lib.deepim_set_option(ctx.handle, b"wino_two_wave", 0)

@@ -10,7 +10,7 @@ cf = ctypes.c_float
 rng = np.random.default_rng(0)
 LAYERS = [("conv3_1", 256, 60, 80, 256), ("conv4_1", 512, 30, 40, 512), ("conv5_1", 512, 15, 20, 512), ("conv6_1", 1024, 8, 10, 1024)]
 ROUNDS, REPS = 3, 5
-WIDE0 = int(os.environ.get('WINO_WIDE', '1'))
+WIDE0, WIDE1 = (int(v) for v in os.environ.get('WINO_SHAPES', '1,3').split(','))   # block shapes: the timed one, the other one (1 auto, 0 64x64, 3 128x32, 2 64x32 x2)
 lib.deepim_set_option(ctx.handle, b'wino_wide', WIDE0)
 ONLY = os.environ.get("WINO_LAYERS", "").split(",") if os.environ.get("WINO_LAYERS") else None
 for name, cin, H, W, cout in LAYERS:
@@ -30,7 +30,7 @@ for name, cin, H, W, cout in LAYERS:
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x, pk, bias, B, cin, H, W, cout, 3, 3, 1, 1, cf(0.1), 0, 0, 1, out8)
     wino = lambda: lib.deepim_conv2d_wino_forward(ctx.handle, o2, x, pw, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
     def wino1():   # the other block shape (128 channels x 32 tiles if the default is 64 x 64, and vice versa)
-        lib.deepim_set_option(ctx.handle, b"wino_wide", 1 - WIDE0); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
+        lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE1); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
     direct(); wino()
     a, b = o1.asnumpy(), o2.asnumpy()
     err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
@@ -71,7 +71,7 @@ for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x8, pk, bias, B, cin, H, W, cout, 5, 5, 2, 2, cf(0.1), 0, 0, 1, 1)
     wino = lambda: lib.deepim_conv2d_wino_forward_s2d(ctx.handle, o2, xs, pw, bias, B, cin, H, W, cout, cf(0.1), 1, 0, 0)
     def wino_full():   # the other block shape
-        lib.deepim_set_option(ctx.handle, b"wino_wide", 1 - WIDE0); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
+        lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE1); wino(); lib.deepim_set_option(ctx.handle, b"wino_wide", WIDE0)
     direct(); wino()
     a, b = o1.asnumpy(), o2.asnumpy()
     err = float(np.abs(a - b).max() / max(1.0, np.abs(a).max()))
