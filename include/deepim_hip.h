@@ -65,7 +65,12 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * parity classes of deepim_conv2d_dgrad_s2 share one launch, 0 = class by class (A/B measurements). "wino_two_wave": 0 (default) =
  * the Winograd layers on the one-wave-per-SIMD kernel (16 positions per wave), 1 = the two-wave form (8 positions per wave, LDS
  * hand-over; measured slower on the big layers); "wino_s2d_skip": 1 (default) = deepim_conv2d_wino_forward_s2d skips the positions
- * whose transformed weights are identically zero, 0 = runs all 16 (same bits; A/B measurements). Unknown names fail. */
+ * whose transformed weights are identically zero, 0 = runs all 16 (A/B measurements). "wino_shared": 1 (default) = Winograd layers with
+ * Cout % 64 == 0 run on the shared-transform kernel (8- or 4-wave blocks, the input transform computed once per block and handed over
+ * through LDS), 0 = the round-4 one-wave kernel. "wino_wide": block shape of that kernel — 1 (default) = per layer by the work per CU,
+ * 0 = 64 channels x 64 tiles, 3 = 128 x 32 (Cout % 128 == 0), 2 = 64 x 32 on four waves, two blocks per CU. "wino_split": its split
+ * over the input channels where the grid does not fill the chip — 0 (default) = the deterministic plan of the geometry, 1 = never
+ * (one block walks all of Cin: the 3x3 layers are then bit-identical to the one-wave kernel), n = at most n slices. Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */
@@ -300,9 +305,12 @@ int deepim_relayout_nc8_slice(deepim_ctx* ctx, float* dst, int dst_ctotal, int d
  * out_coff + Cout) of an NCHW tensor with out_ctotal channels (0 = Cout). Cout % 32 == 0, Cin % 8 == 0. packed_w: U = G g G^T
  * from deepim_conv_wino_pack_weights (16 floats per weight tap set: Cout*Cin*64 bytes). */
 size_t deepim_conv_wino_packed_size(int Cout, int Cin);
-/* 1 when the layer has enough 32-channel x 128-tile blocks for this kernel to beat the direct one (no split over Cin) */
+/* 1 when the layer should take the Winograd path: Cout % 64 == 0 (shared-transform kernel, splits the input channels on small grids)
+ * from 64 tiles on; other channel counts (one-wave kernel, no split) from 128 blocks of 32 channels x 128 tiles on; always 0 on a
+ * context in the canonical-summation-order configuration ("conv_max_split" = 1). ctx may be NULL (the defaults). Which layers
+ * qualify — and the split plan — depend on B: so does the rounding of a sample's output, never its 1e-5-of-range bound. */
 int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
-/* the same for a 5x5 stride-2 pad-2 layer (B, Cin, H, W) run over its space-to-depth form (needs several full rounds of blocks) */
+/* the same for a 5x5 stride-2 pad-2 layer (B, Cin, H, W) run over its space-to-depth form (one-wave kernel: from 256 blocks on) */
 int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
 int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
 /* The 5x5 stride-2 pad-2 layers (conv2 / conv3, deepIM_flownet.py:65-68) on the same kernel: a stride-2 convolution is a stride-1
@@ -313,7 +321,10 @@ int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float*
  * deepim_conv2d_wino_forward(ctx, out, in_s2d, packed, bias, B, 4*Cin, H/2, W/2, Cout, ...). 1.56x fewer multiplies than direct. */
 int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,5,5 dev*/, int Cout, int Cin);
 /* the stride-2 layer in one call: (B, Cin, H, W) input given in its space-to-depth NC8 form, output (B, Cout, H/2, W/2); the positions
- * whose transformed weights are identically zero (third kernel row / column of the odd input phases) are skipped: 49 of 64 MFMAs */
+ * whose transformed weights are identically zero (third kernel row / column of the odd input phases) are skipped: 49 of 64 MFMAs.
+ * The shared-transform kernel (Cout % 64 == 0, 4 Cin % 64 == 0) walks the four input phases interleaved — two 8-channel blocks of each
+ * per loop body — so that the skipped positions are a compile-time property of every step: the same products, the channel sum in
+ * that order (2e-6 of range from the one-wave kernel's natural order). */
 int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const float* in_s2d, const float* packed_w, const float* bias,
                                    int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
 int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float* src, int B, int C, int H, int W, int to_s2d);

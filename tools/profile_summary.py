@@ -24,7 +24,7 @@ def short(name):
 
 
 def is_conv(n):
-    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "conv_wino_kernel", "conv_wino8_kernel", "conv_wino2_kernel", "splitk_reduce", "tail_reduce",
+    return n.startswith(("conv_mfma_kernel", "conv_direct_kernel", "conv_nc8_kernel", "conv_wino_kernel", "conv_wino8_kernel", "conv_wino4_kernel", "conv_wino2_kernel", "wino_reduce_kernel", "splitk_reduce", "tail_reduce",
                          "conv_f16", "conv1_x3", "splitk_x3", "splitk_f16", "tail_f16", "split16_to_nchw", "nchw_to_split16",
                          "_ZN12_GLOBAL__N_123splitk_x3", "_ZN12_GLOBAL__N_122split16_to"))
 
@@ -146,7 +146,7 @@ def hbm_bytes(kernel, occ, batch, H=480, W=640):
         return 20.0 * px, "20 B/px: two depth maps read, flow (2 ch) + valid written"
     if kernel.startswith("resolve_kernel"):       # z-buffer read + re-armed (8 + 8), RGB (12) + depth (4) + mask (4) written
         return 36.0 * px, "36 B/px: 64-bit z-buffer read and re-armed, image (3 ch) + depth + mask_rendered written"
-    if kernel.startswith("upsample16_kernel"):    # Deconvolution k32 s16 + Crop of the 30x40 head output: occurrence 0 = mask (1 ch), 1 = flow (2 ch)
+    if kernel.startswith(("upsample16_kernel", "upsample16x4_kernel")):    # Deconvolution k32 s16 + Crop of the 30x40 head output: occurrence 0 = mask (1 ch), 1 = flow (2 ch)
         c = 1 if occ == 0 else 2
         return 4.0 * c * (px + batch * 30 * 40), "%d-channel full-resolution output written, 30x40 input read" % c
     if kernel.startswith("resample4_kernel"):     # ZoomMaskWithFactor (1 ch) / ZoomFlow (2 ch) back to the camera frame: read + write once
@@ -172,7 +172,7 @@ def cmd_perkernel(a):
             if not is_conv(n):
                 continue
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            if n.startswith(("splitk_reduce", "tail_reduce")):
+            if n.startswith(("splitk_reduce", "tail_reduce", "wino_reduce")):
                 acc[li][4] += d
             else:
                 li += 1
@@ -189,7 +189,7 @@ def cmd_perkernel(a):
         marks = [i for i, d in enumerate(seq) if d["name"].startswith(("rt_transform_kernel", "pose_tail_kernel"))]
         li = -1
         for d in seq[marks[-2] + 1:marks[-1] + 1]:            # the last iteration of the PMC run
-            if is_conv(d["name"]) and not d["name"].startswith(("splitk_reduce", "tail_reduce")):
+            if is_conv(d["name"]) and not d["name"].startswith(("splitk_reduce", "tail_reduce", "wino_reduce")):
                 li += 1
                 busy[ENC_GEOM[li][0]] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (max(1.0, d.get("GRBM_GUI_ACTIVE", 0.0)) * 128)
     per, tot_ms = [], 0.0
@@ -218,7 +218,7 @@ def cmd_perkernel(a):
             occ = defaultdict(int)
             for r, n in zip(hr[lo:hi], hn[lo:hi]):
                 base = re.sub(r"<.*$", "", n)
-                if base not in (("flow_kernel", "resolve_kernel", "upsample16_kernel", "resample4_kernel", "conv_fewout_kernel") if it
+                if base not in (("flow_kernel", "resolve_kernel", "upsample16_kernel", "upsample16x4_kernel", "resample4_kernel", "conv_fewout_kernel") if it
                                 else ("flow_kernel",)):     # the training-step trace: lib/flow_c's kernel only (its other launches mix shapes)
                     continue
                 o = occ[base] if it else 0
