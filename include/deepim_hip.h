@@ -70,7 +70,9 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * through LDS), 0 = the round-4 one-wave kernel. "wino_wide": block shape of that kernel — 1 (default) = per layer by the work per CU,
  * 0 = 64 channels x 64 tiles, 3 = 128 x 32 (Cout % 128 == 0), 2 = 64 x 32 on four waves, two blocks per CU. "wino_split": its split
  * over the input channels where the grid does not fill the chip — 0 (default) = the deterministic plan of the geometry, 1 = never
- * (one block walks all of Cin: the 3x3 layers are then bit-identical to the one-wave kernel), n = at most n slices. Unknown names fail. */
+ * (one block walks all of Cin: the 3x3 layers are then bit-identical to the one-wave kernel), n = at most n slices. "wino_persistent": 1
+ * (default) = its grid is one block per resident slot (256 of 8 waves, 512 of 4), each walking its share of the tile blocks, 0 = one
+ * block per tile block (same results). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */

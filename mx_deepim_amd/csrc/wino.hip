@@ -42,7 +42,7 @@ struct WinoParams {
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
   // conv_wino8_kernel, split over the input channels: slice = blockIdx.x / grid0 walks the 8-channel blocks [slice*kslice, +kslice) and
   // writes its raw sums (no bias, no activation) to out + slice*part_stride — `out` is then the partial buffer, wino_reduce_kernel finishes
-  int grid0, kslice, ksplit;
+  int grid0, kslice, ksplit, nvb;   // nvb = grid0 * ksplit virtual blocks (conv_wino8_kernel's blocks are persistent)
   long part_stride;
 };
 
@@ -566,6 +566,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //     so that one loop body of eight steps has a compile-time phase per step and the identically-zero positions are dropped with no
 //     branch at all (wave-uniform branches around MFMAs make the register allocator move accumulator tuples between the arms and
 //     spill them). The channel sum runs in that order, so these layers agree with the one-wave kernel to rounding, not bit for bit.
+// dev builds (-DW8_TRACE=1, tools/wino8_trace.py): every wave of ONE block (blockIdx.x == gridDim.x / 2) writes s_memtime stamps of its
+// first tile — entry, first MFMA, loop end, exchange done, exit — to a device buffer: where a block's fixed cost goes
+#ifndef W8_TRACE
+#define W8_TRACE 0
+#endif
+#if W8_TRACE
+__device__ unsigned long long* g_w8_trace = nullptr;
+#define W8_STAMP(k_) if (g_w8_trace && blockIdx.x == gridDim.x / 2 && vb == (int)blockIdx.x && (threadIdx.x & 63) == 0) g_w8_trace[wave * 8 + (k_)] = __builtin_amdgcn_s_memtime();
+#else
+#define W8_STAMP(k_)
+#endif
+#ifndef W8_PRO_AFIRST
+#define W8_PRO_AFIRST 0
+#endif
 #ifndef W8_ABL
 #define W8_ABL 0   // dev ablations (wrong results): 1 no step barriers, 4 no pixel loads + transform + V stores, 8 no operand reads in the loop, 16 no output transform / stores, 32 no MFMAs
 #endif
@@ -585,8 +599,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // block, the blocks run independently — one block's prologue / output transform / stores under the other's MFMAs, and a last partial
 // round of lone blocks runs faster instead of idling half the chip's issue slots.
 template <int OUT_NC8, int S2D, int PH, int SHAPE>
-__device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave) {
+__device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave, const int vb) {
   constexpr int WIDE = SHAPE == 1, HALF = SHAPE == 2;
+  W8_STAMP(0)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   constexpr int ph = PH;
@@ -599,7 +614,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int lrow = lane >> 5, lcol = lane & 31;
   int mb2, bx;
   {
-    const int bid = blockIdx.x % p.grid0, xcd = bid & 7, idx = bid >> 3;
+    const int bid = vb % p.grid0, xcd = bid & 7, idx = bid >> 3;   // vb: the virtual block this (persistent) block works on
     if ((p.gy & 7) == 0) {          // XCD x owns the channel blocks [x·gy/8, (x+1)·gy/8): its slice of U stays in its L2
       const int per = p.gy >> 3;
       mb2 = xcd * per + idx % per;
@@ -616,7 +631,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   if (bx >= p.gx) return;
   const int tpi = p.TY * p.TX;
   const int c8n = p.Cin >> 3;                               // 8-channel blocks of the input: strides
-  const int slice = blockIdx.x / p.grid0;                   // this block's share of them: stages [kb, ke)
+  const int slice = vb / p.grid0;                           // this block's share of them: stages [kb, ke)
   const int kb = slice * p.kslice, ke = min(c8n, kb + p.kslice);
   const int hw32 = p.H * p.W * 32;
 
@@ -706,11 +721,9 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
 // operands of position i for the stage whose weights sit at scalar offset rsa_: the weights straight from global memory (L1 / L2:
 // the two tile halves of a channel half read the same bytes), V from LDS slot slot_
-#define W8_RD(i, slot_)                                                                               \
-  {                                                                                                   \
-    A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0)); \
-    Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * VSLOT + (i) * QS));                                     \
-  }
+#define W8_RDA(i) A[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrw, ra_g + (i) * 1024, rsa_, 0));
+#define W8_RDB(i, slot_) Bv[i] = W8_LDS4(rb + (unsigned)((slot_) * VSLOT + (i) * QS));
+#define W8_RD(i, slot_) { W8_RDA(i) W8_RDB(i, slot_) }
 #define W8_MFMA(i, s_)                                                                                \
   acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((s_) == 0 ? A[i].x : (s_) == 1 ? A[i].y : (s_) == 2 ? A[i].z : A[i].w, \
                                                 (s_) == 0 ? Bv[i].x : (s_) == 1 ? Bv[i].y : (s_) == 2 ? Bv[i].z : Bv[i].w, acc[i], 0, 0, 0); \
@@ -751,6 +764,14 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 
   // ---- prologue: stage 0 into slot 0 and into the operand registers; the top wave also transforms stage 1 into slot 1 and loads the
   // pixels of stage 2 (the bottom wave does both in its first step). S2D: stages 0, 1 have phase 0, stages 2, 3 phase 1
+#if W8_PRO_AFIRST
+  {   // dev: the first stage's weight operands requested before anything else
+    const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(kb) * 16384);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W8_RDA(i)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   W8_PIX(kb, 0)
   W8_ROW(0)
   W8_PIX(kb + 1, 0)
@@ -760,7 +781,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   {
     const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(kb) * 16384);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) W8_RD(i, 0)
+    for (int i = 0; i < 8; ++i) { if (!W8_PRO_AFIRST) { W8_RDA(i) } W8_RDB(i, 0) }
   }
   if (!ph) {
     W8_ROW(0)
@@ -770,6 +791,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
   __builtin_amdgcn_sched_barrier(0);
 
+  W8_STAMP(1)
   // ---- one step per stage k (SL = k & 1), ONE barrier each: behind barrier k every wave reads stage k + 1 into its operand
   // registers (V from slot SL ^ 1); between barriers k and k + 1 it transforms its share of stage k + 2 (pixels loaded a step earlier)
   // into slot SL and loads its pixels of stage k + 3. The two waves of a SIMD run 16 MFMAs apart:
@@ -835,6 +857,8 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_M2X
 #undef W8_MFMA
 #undef W8_RD
+#undef W8_RDA
+#undef W8_RDB
 #undef W8_COL
 #undef W8_FMACD
 #undef W8_ROW
@@ -842,6 +866,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_ACT
 #undef W8_CB
 
+  W8_STAMP(2)
   // ---- output transform. acc[x*4 + nu][r] with xi = 2ph + x: channel (r&3) + 8(r>>2) + 4·lrow of the wave's 32, tile lcol.
   // s[xi][0] = (m0 + m1) + m2, s[xi][1] = (m1 - m2) - m3; Y[0][b] = ((s0 + s1) + s2) + bias, Y[1][b] = ((s1 - s2) - s3) + bias.
   // The top wave (s0, s1) finishes accumulator rows 0-7, the bottom wave (s2, s3) rows 8-15; each hands the other its s of the
@@ -930,21 +955,33 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
   if (ph == 0) W8_SEND(0) else W8_SEND(1)
   W8_SYNC()
+  W8_STAMP(3)
   if (!tvalid) return;
   if (ph == 0) W8_FINISH(0) else W8_FINISH(1)
+  W8_STAMP(4)
 #undef W8_SEND
 #undef W8_FINISH
 #undef W8_SYNC
 #undef W8_LDS4
 }
 
+// Persistent blocks: the grid is one block per resident slot (256 of 8 waves, 512 of 4) and block b works on the virtual blocks b,
+// b + gridDim.x, … (gridDim.x % 8 == 0 keeps a virtual block on the XCD its index names). What it buys is measured in
+// profiles/r05_winograd.md: a block's fixed cost is ~10 us, and part of it is the hardware's own turn-around between two workgroups.
+#define W8_PERSIST(BODY)                                                                              \
+  for (int vb = blockIdx.x; vb < p.nvb; vb += gridDim.x) {                                            \
+    BODY;                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the output exchange has been read: the slots are free for the next tile */ \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("" ::: "memory");                                                                    \
+  }
 template <int OUT_NC8, int S2D, int SHAPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // waves w and w + 4 share a SIMD: a top and a bottom half each
-  if (((wave >> 2) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, SHAPE>(p, smem, wave);
-  else wino8_body<OUT_NC8, S2D, 1, SHAPE>(p, smem, wave);
+  if (((wave >> 2) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, SHAPE>(p, smem, wave, vb))) }
+  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, SHAPE>(p, smem, wave, vb))) }
 }
 
 // SHAPE 2: four waves, two blocks per CU (the register file holds two waves of 256 registers per SIMD: one of each block)
@@ -952,9 +989,10 @@ template <int OUT_NC8, int S2D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_HALF_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (((wave >> 1) & 1) == 0) wino8_body<OUT_NC8, S2D, 0, 2>(p, smem, wave);
-  else wino8_body<OUT_NC8, S2D, 1, 2>(p, smem, wave);
+  if (((wave >> 1) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, 2>(p, smem, wave, vb))) }
+  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, 2>(p, smem, wave, vb))) }
 }
+#undef W8_PERSIST
 
 // Second pass of a split K loop of conv_wino8_kernel: sums the S raw copies (same layout as the output), adds the bias, applies the
 // LeakyReLU. nc8: channel-blocked output (float4 = 4 consecutive channels; space-to-depth order keeps the channel of a record:
@@ -1135,7 +1173,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
-  p.grid0 = 1; p.kslice = Cin / 8; p.ksplit = 1; p.part_stride = 0;
+  p.grid0 = 1; p.kslice = Cin / 8; p.ksplit = 1; p.part_stride = 0; p.nvb = 1;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   int grid = p.gx * p.gy;
   if (shared) {
@@ -1158,6 +1196,8 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
       if (!out_nc8) { p.out_ctotal = Cout; p.out_coff = 0; }   // dense NCHW partials
       grid *= S;
     }
+    p.nvb = grid;
+    if (ctx->wino_persistent) grid = (int)std::min<long>(grid, half ? 512 : 256);   // one block per resident slot, each walks its share
 #define W8_LAUNCH(O, S)                                                                               \
     if (half) conv_wino4_kernel<O, S><<<grid, 256, 0, ctx->stream>>>(p);                              \
     else if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                      \
@@ -1210,6 +1250,12 @@ extern "C" int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const
   return wino_forward_impl(ctx, out, in_s2d, packed_w, bias, B, 4 * Cin, H / 2, W / 2, Cout, slope, out_nc8, out_ctotal, out_coff, true);
 }
 
+#if W8_TRACE
+extern "C" int deepim_dev_w8_trace(void* buf) {
+  unsigned long long* b = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_w8_trace), &b, sizeof(b));
+}
+#endif
 #if WINO_TRACE
 extern "C" int deepim_dev_wino_trace(void* buf) {
   unsigned long long* b = (unsigned long long*)buf;
