@@ -602,7 +602,10 @@ template <int OUT_NC8, int S2D, int PH, int SHAPE>
 __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave, const int vb) {
   constexpr int WIDE = SHAPE == 1, HALF = SHAPE == 2;
   W8_STAMP(0)
-  const int tid = threadIdx.x;
+  // opaque per tile: what a lane derives from its index is recomputed for every tile of a persistent block instead of being carried
+  // (hoisted out of the tile loop it would live through the K loop and the output transform, i.e. in scratch)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   constexpr int ph = PH;
   constexpr int NSUB = WIDE ? 4 : 2;          // 32-channel sub-blocks of the block
@@ -629,9 +632,10 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     }
   }
   if (bx >= p.gx) return;
-  const int tpi = p.TY * p.TX;
+  int tpi = p.TY * p.TX, TXp = p.TX;
+  asm volatile("" : "+s"(tpi), "+s"(TXp));   // per tile: the divisions' reciprocals are not carried across the tile loop (in scratch)
   const int c8n = p.Cin >> 3;                               // 8-channel blocks of the input: strides
-  const int slice = vb / p.grid0;                           // this block's share of them: stages [kb, ke)
+  const int slice = __builtin_amdgcn_readfirstlane(vb / p.grid0);   // this block's share of them: stages [kb, ke) (uniform, but out of a VALU division)
   const int kb = slice * p.kslice, ke = min(c8n, kb + p.kslice);
   const int hw32 = p.H * p.W * 32;
 
@@ -643,7 +647,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
     const bool tv = tT < p.ntiles;
     const int n = tv ? tT / tpi : 0;
     const int tr = tv ? tT - n * tpi : 0;
-    const int ty = tr / p.TX, tx = tr - ty * p.TX;
+    const int ty = tr / TXp, tx = tr - ty * TXp;
     const int x = 2 * tx - 1 + j;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -664,11 +668,14 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, (int)p.wd_bytes, 0x00020000);
 
+  // zeroed by the matrix pipe itself (0 * 0 + the inline constant 0): a zero tuple built in vector registers is carried from tile to
+  // tile of a persistent block through scratch, and its reload sits in front of the first loads' wait
   f32x16 acc[8];
+  {
+    const float zf = 0.f;
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < 8; ++q) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(acc[q]) : "v"(zf));
+  }
   tvec raw[4], T[4];
   f32x4 A[8], Bv[8];
 
@@ -891,7 +898,8 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   // a slice of a split K loop writes raw sums to its own copy of the output; bias and activation wait for wino_reduce_kernel
   float* const outp = p.out + (long)slice * p.part_stride;
   const float* const biasp = p.ksplit > 1 ? nullptr : p.bias;
-  const float slope_e = p.ksplit > 1 ? 1.f : p.slope;
+  float slope_e = p.ksplit > 1 ? 1.f : p.slope;
+  asm volatile("" : "+v"(slope_e));
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
   const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ (HALF ? 2 : 4)) * 2048 + lanee;
   // whole-vector forms: reading single elements of an AGPR-resident f32x16 makes the compiler copy all 16 registers each time
