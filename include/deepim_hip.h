@@ -72,7 +72,10 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * over the input channels where the grid does not fill the chip — 0 (default) = the deterministic plan of the geometry, 1 = never
  * (one block walks all of Cin: the 3x3 layers are then bit-identical to the one-wave kernel), n = at most n slices. "wino_persistent": 1
  * (default) = its grid is one block per resident slot (256 of 8 waves, 512 of 4), each walking its share of the tile blocks, 0 = one
- * block per tile block (same results). Unknown names fail. */
+ * block per tile block (same results). "wino_streamk": 1 (default) = where that walk would end in a partly filled round the persistent
+ * blocks share that round granule by granule, a cut tile block is finished by whichever of its pieces arrives last (a fixed order of adds:
+ * deterministic; rounding as for a K split;
+ * off with wino_split = 1 or wino_persistent = 0; 2 = wherever it applies, whatever the cost model says; 0 = never). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */
@@ -314,6 +317,12 @@ size_t deepim_conv_wino_packed_size(int Cout, int Cin);
 int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
 /* the same for a 5x5 stride-2 pad-2 layer (B, Cin, H, W) run over its space-to-depth form (one-wave kernel: from 256 blocks on) */
 int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout);
+/* The launch plan the shared-transform kernel would use for a layer under the context's options (no launch; tests and docs read it):
+ * arguments as deepim_conv2d_wino_forward sees them (s2d = 1: Cin, H, W of the space-to-depth problem). plan[0] block shape (0 = 64
+ * channels x 64 tiles, 1 = 128 x 32, 2 = 64 x 32 on four waves), [1] grid, [2] K slices S, [3] K steps per slice, [4] stream-K granules
+ * per tile block (0 = off: whole tile blocks per block), [5] granules of the last round per persistent block, [6] whole tile blocks
+ * per persistent block before them. All -1 where another kernel runs the layer. */
+int deepim_conv_wino_plan(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int out_nc8, int s2d, int* plan /*7, host*/);
 int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
 /* The 5x5 stride-2 pad-2 layers (conv2 / conv3, deepIM_flownet.py:65-68) on the same kernel: a stride-2 convolution is a stride-1
  * convolution over the four input phases (x[2m + py][2l + px] as channel (py*2+px)*Cin + c of a (4 Cin, H/2, W/2) tensor) with the

@@ -44,6 +44,15 @@ struct WinoParams {
   // writes its raw sums (no bias, no activation) to out + slice*part_stride — `out` is then the partial buffer, wino_reduce_kernel finishes
   int grid0, kslice, ksplit, nvb;   // nvb = grid0 * ksplit virtual blocks (conv_wino8_kernel's blocks are persistent)
   long part_stride;
+  float* part;                // raw sums of the pieces that do not cover all of Cin: copy c at part + c * part_stride, laid out like the output
+  // stream-K of the last, partly filled round (sk_G > 0). XCD x (the blocks b with b % 8 == x) owns the tile blocks bid % 8 == x, as in the
+  // plain walk; its sk_nlb blocks first walk sk_F whole tile blocks each, side by side (local tile block r * sk_nlb + lb: the blocks of an
+  // XCD read the same weights at the same time), then deal the remaining tile blocks' granules — sk_G per tile block, sk_gran K steps
+  // each — in consecutive runs of sk_q (+ 1 for the first sk_rem blocks). A run cuts tile blocks into pieces: piece c (in K order)
+  // writes raw sums to copy c of `part`, bumps the tile block's counter in sk_count, and whichever piece arrives last adds the copies in
+  // order, the bias and the activation (a fixed order of fp32 adds: deterministic whatever the arrival order). Counters return to zero.
+  int sk_G, sk_gran, sk_F, sk_q, sk_rem, sk_nlb;
+  int* sk_count;
 };
 
 #ifndef WINO_ABL
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 #if W8_TRACE
 __device__ unsigned long long* g_w8_trace = nullptr;
-#define W8_STAMP(k_) if (g_w8_trace && blockIdx.x == gridDim.x / 2 && vb == (int)blockIdx.x && (threadIdx.x & 63) == 0) g_w8_trace[wave * 8 + (k_)] = __builtin_amdgcn_s_memtime();
+#define W8_STAMP(k_) if (g_w8_trace && blockIdx.x == gridDim.x / 2 && vb == W8_TRACE - 1 && (threadIdx.x & 63) == 0) g_w8_trace[wave * 8 + (k_)] = __builtin_amdgcn_s_memtime();   /* W8_TRACE - 1 = which tile of the persistent block */
 #else
 #define W8_STAMP(k_)
 #endif
@@ -598,8 +607,29 @@ __device__ unsigned long long* g_w8_trace = nullptr;
 // SHAPE 2: the block is 64 channels x 32 tiles on FOUR waves (one per SIMD), two blocks per CU: each SIMD then runs a wave of either
 // block, the blocks run independently — one block's prologue / output transform / stores under the other's MFMAs, and a last partial
 // round of lone blocks runs faster instead of idling half the chip's issue slots.
+// tile block bid -> (channel block mb2, tile block bx). bid % 8 names the XCD that works on it (persistent blocks: block b takes tile
+// blocks bid = b mod 8 only)
+__device__ __forceinline__ void w8_block_coords(const WinoParams& p, const int bid, int& mb2, int& bx) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  if ((p.gy & 7) == 0) {          // XCD x owns the channel blocks [x·gy/8, (x+1)·gy/8): its slice of U stays in its L2
+    const int per = p.gy >> 3;
+    mb2 = xcd * per + idx % per;
+    bx = idx / per;
+  } else if ((8 % p.gy) == 0) {   // 8 / gy XCDs per channel block
+    const int r = 8 / p.gy;
+    mb2 = xcd % p.gy;
+    bx = idx * r + xcd / p.gy;
+  } else {
+    mb2 = bid % p.gy;
+    bx = bid / p.gy;
+  }
+}
+
+// One piece of work: tile block `bid`, stages [kb, ke) of its K walk, results to the output (copy < 0: bias + activation applied) or as
+// raw sums to copy `copy` of p.part. vb: the piece's number within its block (dev trace only).
 template <int OUT_NC8, int S2D, int PH, int SHAPE>
-__device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave, const int vb) {
+__device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, const int wave, const int vb, const int bid, const int kb,
+                                           const int ke, const int copy) {
   constexpr int WIDE = SHAPE == 1, HALF = SHAPE == 2;
   W8_STAMP(0)
   // opaque per tile: what a lane derives from its index is recomputed for every tile of a persistent block instead of being carried
@@ -616,27 +646,11 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int msub = WIDE ? (wave & 3) : (wave & 1), tg = (WIDE || HALF) ? 0 : (wave >> 1) & 1;
   const int lrow = lane >> 5, lcol = lane & 31;
   int mb2, bx;
-  {
-    const int bid = vb % p.grid0, xcd = bid & 7, idx = bid >> 3;   // vb: the virtual block this (persistent) block works on
-    if ((p.gy & 7) == 0) {          // XCD x owns the channel blocks [x·gy/8, (x+1)·gy/8): its slice of U stays in its L2
-      const int per = p.gy >> 3;
-      mb2 = xcd * per + idx % per;
-      bx = idx / per;
-    } else if ((8 % p.gy) == 0) {   // 8 / gy XCDs per channel block
-      const int r = 8 / p.gy;
-      mb2 = xcd % p.gy;
-      bx = idx * r + xcd / p.gy;
-    } else {
-      mb2 = bid % p.gy;
-      bx = bid / p.gy;
-    }
-  }
+  w8_block_coords(p, bid, mb2, bx);
   if (bx >= p.gx) return;
   int tpi = p.TY * p.TX, TXp = p.TX;
   asm volatile("" : "+s"(tpi), "+s"(TXp));   // per tile: the divisions' reciprocals are not carried across the tile loop (in scratch)
   const int c8n = p.Cin >> 3;                               // 8-channel blocks of the input: strides
-  const int slice = __builtin_amdgcn_readfirstlane(vb / p.grid0);   // this block's share of them: stages [kb, ke) (uniform, but out of a VALU division)
-  const int kb = slice * p.kslice, ke = min(c8n, kb + p.kslice);
   const int hw32 = p.H * p.W * 32;
 
   // ---- transform role: lane = (tile Tl of the block's TB, channel group cg of the 8 — 2 groups of 4 / WIDE: 4 groups of 2 —, patch column j)
@@ -785,6 +799,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) W8_COL(xi, 0)
   W8_SYNC()
+  W8_STAMP(5)
   {
     const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + W8_CB(kb) * 16384);
 #pragma unroll
@@ -895,10 +910,12 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const int y0 = 2 * ty, x0 = 2 * tx;
   const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
   const int mb = mb2e * NSUB + msub;
-  // a slice of a split K loop writes raw sums to its own copy of the output; bias and activation wait for wino_reduce_kernel
-  float* const outp = p.out + (long)slice * p.part_stride;
-  const float* const biasp = p.ksplit > 1 ? nullptr : p.bias;
-  float slope_e = p.ksplit > 1 ? 1.f : p.slope;
+  // a piece of a split K walk writes raw sums to its own copy of the output; bias and activation wait for the second pass
+  float* const outp = copy >= 0 ? p.part + (long)copy * p.part_stride : p.out;
+  const float* const biasp = copy >= 0 ? nullptr : p.bias;
+  float slope_e = copy >= 0 ? 1.f : p.slope;
+  const bool through = copy >= 0 && p.sk_G > 0;
+  const __amdgpu_buffer_rsrc_t rsrp = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, through ? (int)(p.part_stride * 4) : 0, 0x00020000);
   asm volatile("" : "+v"(slope_e));
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
   const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ (HALF ? 2 : 4)) * 2048 + lanee;
@@ -952,6 +969,10 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
               rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * TXe) + ty * TXe + tx; \
             else                                                                                      \
               rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;                         \
+            if (through) {   /* a stream-K piece: straight to memory (sc0 sc1), whichever XCD's block reads it back */ \
+              f32x4 ov; ov.x = o[ab][0]; ov.y = o[ab][1]; ov.z = o[ab][2]; ov.w = o[ab][3];            \
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, ov), rsrp, (int)(rec * 32) + 16 * lrow_e, 0, 17); \
+            } else                                                                                    \
             *reinterpret_cast<float4*>(outp + rec * 8 + 4 * lrow_e) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]); \
           } else {                                                                                    \
             const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow_e;         \
@@ -962,6 +983,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
       }                                                                                               \
   }
   if (ph == 0) W8_SEND(0) else W8_SEND(1)
+  W8_STAMP(6)
   W8_SYNC()
   W8_STAMP(3)
   if (!tvalid) return;
@@ -973,23 +995,111 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_LDS4
 }
 
+// stream-K: which block's run holds granule u of the XCD's last-round granules (runs of sk_q + 1 for the first sk_rem blocks, sk_q after)
+__device__ __forceinline__ int w8_run_owner(const WinoParams& p, const int u) {
+  const int big = p.sk_rem * (p.sk_q + 1);
+  return u < big ? u / (p.sk_q + 1) : p.sk_rem + (u - big) / p.sk_q;
+}
+
+// stream-K: this block has just written one of the `npieces` raw copies of tile block `bid` (TB tiles x CB channels, channel-blocked
+// output). Count it; the block whose piece arrives last reads the copies back (same XCD, same L2: the runs of a cut tile block belong
+// to neighbouring blocks of one XCD) and writes out = act((copy 0 + copy 1 + ...) + bias) — the same sum whoever comes last.
+__device__ __forceinline__ void w8_finish_cut_tile_block(const WinoParams& p, char* smem, const int bid, const int npieces, const int TB,
+                                                         const int CB) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's raw sums have reached memory (written through: sc0 sc1) ...
+  __syncthreads();                                       // ... every thread's have
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(p.sk_count + bid, 1);
+    if (old == npieces - 1) atomicExch(p.sk_count + bid, 0);   // the last piece leaves the counter as it found it before the launch
+    *reinterpret_cast<volatile int*>(smem) = old;
+  }
+  __syncthreads();
+  const int old = *reinterpret_cast<volatile int*>(smem);
+  __syncthreads();                                       // (the word is free again for the next piece's V)
+  if (old != npieces - 1) return;
+  int mb2, bx;
+  w8_block_coords(p, bid, mb2, bx);
+  const int tpi = p.TY * p.TX, c4n = CB >> 2;
+  for (int i = threadIdx.x; i < TB * CB; i += blockDim.x) {     // (tile, pixel of its 2x2, 4 channels)
+    const int c4 = i % c4n, ab = (i / c4n) & 3, tl = i / CB;
+    const int t = bx * TB + tl;
+    if (t >= p.ntiles) continue;
+    const int n = t / tpi, tr = t - n * tpi;
+    const int ty = tr / p.TX, tx = tr - ty * p.TX;
+    const int y = 2 * ty + (ab >> 1), x = 2 * tx + (ab & 1);
+    if (y >= p.H || x >= p.W) continue;
+    const int c = mb2 * CB + c4 * 4;
+    long rec;
+    if (p.out_s2d) rec = (((long)n * 4 + ab) * (p.Cout >> 3) + (c >> 3)) * tpi + ty * p.TX + tx;
+    else rec = ((long)n * (p.Cout >> 3) + (c >> 3)) * p.H * p.W + (long)y * p.W + x;
+    const long o4 = rec * 2 + ((c >> 2) & 1);
+    // read from memory, past both cache levels (sc0 sc1): the pieces may have been written from another XCD
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, (int)(p.part_stride * 4), 0x00020000);
+    f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(o4 * 16), 0, 17));
+    for (int s_ = 1; s_ < npieces; ++s_) {
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (long)s_ * p.part_stride), 0, (int)(p.part_stride * 4), 0x00020000);
+      const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(o4 * 16), 0, 17));
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+    v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+    reinterpret_cast<float4*>(p.out)[o4] = make_float4(v.x, v.y, v.z, v.w);
+  }
+}
+
 // Persistent blocks: the grid is one block per resident slot (256 of 8 waves, 512 of 4) and block b works on the virtual blocks b,
-// b + gridDim.x, … (gridDim.x % 8 == 0 keeps a virtual block on the XCD its index names). What it buys is measured in
-// profiles/r05_winograd.md: a block's fixed cost is ~10 us, and part of it is the hardware's own turn-around between two workgroups.
-#define W8_PERSIST(BODY)                                                                              \
-  for (int vb = blockIdx.x; vb < p.nvb; vb += gridDim.x) {                                            \
-    BODY;                                                                                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the output exchange has been read: the slots are free for the next tile */ \
-    __builtin_amdgcn_s_barrier();                                                                     \
-    asm volatile("" ::: "memory");                                                                    \
+// b + gridDim.x, … (gridDim.x % 8 == 0 keeps a virtual block on the XCD its index names), or — stream-K — on its column of whole
+// tile blocks and then its run of the last round's granules. What it buys is measured in profiles/r05_winograd.md: a block's fixed
+// cost is ~10 us, and part of it is the hardware's own turn-around between two workgroups; stream-K shortens the last, partly filled
+// round to its share of the work (9.375 rounds of tile blocks cost 10 without it on conv3 / conv3_1 at B = 32).
+// Every value that names a piece is wave-uniform and lives in scalar registers (readfirstlane: the divisions run on the VALU).
+#define W8_PERSIST(BODY, TB_, CB_)                                                                    \
+  {                                                                                                   \
+    int u = 0, uend = 0, xcd = 0, lb = 0;                                                             \
+    if (p.sk_G > 0) {                                                                                 \
+      lb = blockIdx.x >> 3;                                                                           \
+      xcd = blockIdx.x & 7;                                                                           \
+      u = lb * p.sk_q + min(lb, p.sk_rem);                                                            \
+      uend = u + p.sk_q + (lb < p.sk_rem ? 1 : 0);                                                    \
+    }                                                                                                 \
+    for (int vb = 0;; ++vb) {                                                                         \
+      int bid, kb, ke, copy, npieces = 0;                                                             \
+      if (p.sk_G > 0) {                                                                               \
+        if (vb < p.sk_F) {            /* the whole rounds: tile block vb of this block's column */      \
+          bid = (vb * p.sk_nlb + lb) * 8 + xcd; kb = 0; ke = p.Cin >> 3; copy = -1;                   \
+        } else {                                                                                      \
+          if (u >= uend) break;                                                                       \
+          const int lt = __builtin_amdgcn_readfirstlane(u / p.sk_G), g0 = u - lt * p.sk_G, g1 = min(p.sk_G, g0 + uend - u); \
+          const int o0 = __builtin_amdgcn_readfirstlane(w8_run_owner(p, lt * p.sk_G)), o1 = __builtin_amdgcn_readfirstlane(w8_run_owner(p, lt * p.sk_G + p.sk_G - 1)); \
+          bid = (p.sk_F * p.sk_nlb + lt) * 8 + xcd; kb = g0 * p.sk_gran; ke = g1 * p.sk_gran;         \
+          npieces = o1 - o0 + 1;                                                                      \
+          copy = npieces == 1 ? -1 : lb - o0;                                                         \
+          if (npieces == 1) npieces = 0;                                                              \
+          u += g1 - g0;                                                                               \
+        }                                                                                             \
+      } else {                                                                                        \
+        const int v = blockIdx.x + vb * gridDim.x;                                                    \
+        if (v >= p.nvb) break;                                                                        \
+        const int slice = __builtin_amdgcn_readfirstlane(v / p.grid0);                                \
+        bid = v - slice * p.grid0; kb = slice * p.kslice; ke = min(p.Cin >> 3, kb + p.kslice);        \
+        copy = p.ksplit > 1 ? slice : -1;                                                             \
+      }                                                                                               \
+      BODY;                                                                                           \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the output exchange has been read: the slots are free for the next piece */ \
+      __builtin_amdgcn_s_barrier();                                                                   \
+      asm volatile("" ::: "memory");                                                                  \
+      if (npieces > 0) w8_finish_cut_tile_block(p, smem, bid, npieces, TB_, CB_);                     \
+    }                                                                                                 \
   }
 template <int OUT_NC8, int S2D, int SHAPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // waves w and w + 4 share a SIMD: a top and a bottom half each
-  if (((wave >> 2) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, SHAPE>(p, smem, wave, vb))) }
-  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, SHAPE>(p, smem, wave, vb))) }
+  if (((wave >> 2) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, SHAPE>(p, smem, wave, vb, bid, kb, ke, copy)), (SHAPE == 0 ? 64 : 32), (SHAPE == 1 ? 128 : 64)) }
+  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, SHAPE>(p, smem, wave, vb, bid, kb, ke, copy)), (SHAPE == 0 ? 64 : 32), (SHAPE == 1 ? 128 : 64)) }
 }
 
 // SHAPE 2: four waves, two blocks per CU (the register file holds two waves of 256 registers per SIMD: one of each block)
@@ -997,8 +1107,8 @@ template <int OUT_NC8, int S2D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(WinoParams p) {
   __shared__ __attribute__((aligned(16))) char smem[W8_LDS_HALF_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (((wave >> 1) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, 2>(p, smem, wave, vb))) }
-  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, 2>(p, smem, wave, vb))) }
+  if (((wave >> 1) & 1) == 0) { W8_PERSIST((wino8_body<OUT_NC8, S2D, 0, 2>(p, smem, wave, vb, bid, kb, ke, copy)), 32, 64) }
+  else { W8_PERSIST((wino8_body<OUT_NC8, S2D, 1, 2>(p, smem, wave, vb, bid, kb, ke, copy)), 32, 64) }
 }
 #undef W8_PERSIST
 
@@ -1036,7 +1146,8 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(float* __restrict__ ou
 // time): S slices of ks steps each so that blocks x S fills whole rounds; cost model = rounds x (steps + per-block prologue/epilogue,
 // ~6 steps' worth) + the second pass (S + 1 passes over the output at ~4 TB/s, in steps of ~1.7 us). Deterministic: a function of
 // the geometry only. step_granule: 2 (slot parity) or 8 (the stride-2 form's loop body).
-static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb, int max_split, int* kslice, int slots = 256) {
+static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb, int max_split, int* kslice, int slots = 256,
+                            double* cost_out = nullptr) {
   int best = 1;
   double best_cost = 1e30;
   for (int S = 1; S <= 16; ++S) {
@@ -1051,7 +1162,27 @@ static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb
     if (cost < best_cost - 1e-9) { best_cost = cost; best = S; *kslice = ks; }
   }
   if (best == 1) *kslice = nK;
+  if (cost_out) *cost_out = best_cost;
   return best;
+}
+
+// Stream-K of the last round of the same grid (WinoParams::sk_*): F whole tile blocks per persistent block, then every block an equal
+// run (+- 1) of the remaining tile blocks' granules — at the price of up to two more pieces per block and the read-back of the cut tile
+// blocks. Same cost unit as wino8_split_plan (steps). Returns the granules per tile block, 0 where it does not apply: the XCD deal
+// needs grid % 8 == 0, and no tile block is cut into more than W8_SK_MAX_COPIES pieces.
+#define W8_SK_MAX_COPIES 8
+#define W8_SK_MAX_TILE_BLOCKS 16384      /* counters per context (64 KB) */
+static int wino8_streamk_plan(long grid, int nK, int step_granule, int slots, double* cost, int* F, int* q, int* rem) {
+  if (grid % 8 != 0 || nK % step_granule != 0 || grid > W8_SK_MAX_TILE_BLOCKS) return 0;
+  const int G = nK / step_granule, nlb = slots / 8;
+  const long ltiles = grid / 8;
+  *F = (int)(ltiles / nlb);
+  const long units = (ltiles - (long)*F * nlb) * G;
+  if (units == 0) return 0;
+  *q = (int)(units / nlb); *rem = (int)(units % nlb);
+  if (*q < 1 || di_div_up(G, *q) + 1 > W8_SK_MAX_COPIES) return 0;
+  *cost = (double)*F * (nK + 6.0) + ((double)*q + (*rem ? 1 : 0)) * step_granule + 2 * 6.0 + 2.0;
+  return G;
 }
 
 // U = G g G^T in double, rounded once; packed [Cout/32][Cin/8][position][lane = h*32 + row][4] with channel 8(c/8) + 4h + s (s = 0, 1: body 0; 2, 3: body 1)
@@ -1151,7 +1282,8 @@ extern "C" int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_
 // `out` (out_nc8 = 1; 3 = channel-blocked in space-to-depth order, what a stride-2 layer on this kernel reads) or into channels
 // [out_coff, out_coff + Cout) of an NCHW tensor of out_ctotal channels (out_nc8 = 0).
 static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B, int Cin,
-                             int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff, bool s2d) {
+                             int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff, bool s2d,
+                             int* plan_only = nullptr) {
   DI_DEVICE(ctx);
   DI_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d_wino_forward: bad shape");
   DI_REQUIRE((Cout & 31) == 0 && (Cin & 7) == 0, "conv2d_wino_forward: Cout % 32 == 0 and Cin % 8 == 0 required");
@@ -1181,7 +1313,8 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
-  p.grid0 = 1; p.kslice = Cin / 8; p.ksplit = 1; p.part_stride = 0; p.nvb = 1;
+  p.grid0 = 1; p.kslice = Cin / 8; p.ksplit = 1; p.part_stride = 0; p.nvb = 1; p.part = nullptr;
+  p.sk_G = 0; p.sk_gran = 0; p.sk_F = 0; p.sk_q = 0; p.sk_rem = 0; p.sk_nlb = 0; p.sk_count = nullptr;
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   int grid = p.gx * p.gy;
   if (shared) {
@@ -1193,19 +1326,42 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     const int nK = Cin / 8;
     const size_t out_elems = (size_t)B * Cout * H * W;
     int ks = nK;
-    const int S = ctx->wino_split == 1 ? 1 : wino8_split_plan(grid, nK, ph8 ? 8 : 2, out_elems * 4 / 1e6, ctx->wino_split, &ks, half ? 512 : 256);
-    p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0;
-    float* final_out = out;
-    if (S > 1) {
+    const int slots = half ? 512 : 256, gran = ph8 ? 8 : 2;
+    double cost_split = 0, cost_sk = 0;
+    int S = ctx->wino_split == 1 ? 1 : wino8_split_plan(grid, nK, gran, out_elems * 4 / 1e6, ctx->wino_split, &ks, slots, &cost_split);
+    int skF = 0, skq = 0, skrem = 0;
+    const int skG = (ctx->wino_split != 1 && ctx->wino_persistent && ctx->wino_streamk && out_nc8 && out_elems * 4 < (1ull << 31)) ? wino8_streamk_plan(grid, nK, gran, slots, &cost_sk, &skF, &skq, &skrem) : 0;
+    // measured (bench.py A/B in one box): +1 % at B = 32 (4-18 whole rounds before the cut one), -1 % at B = 4 (one): from two whole rounds on
+    const bool streamk = skG > 0 && (ctx->wino_streamk == 2 || (skF >= 2 && cost_sk < cost_split * 0.98));   // 2: wherever it applies (tests)
+    if (streamk) { S = 1; ks = nK; }
+    p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0; p.part = nullptr;
+    if ((S > 1 || streamk) && !plan_only) {
       void* scr = nullptr;
-      if (deepim_scratch(ctx, (size_t)S * out_elems * 4, &scr) != 0) return -1;
-      p.out = (float*)scr;
+      const int copies = streamk ? di_div_up(skG, skq) + 1 : S;   // a tile block of G granules cut by runs of >= q: at most that many pieces
+      if (deepim_scratch(ctx, (size_t)copies * out_elems * 4, &scr) != 0) return -1;
+      p.part = (float*)scr;
       p.part_stride = (long)out_elems;
+    }
+    if (S > 1) {
       if (!out_nc8) { p.out_ctotal = Cout; p.out_coff = 0; }   // dense NCHW partials
       grid *= S;
     }
     p.nvb = grid;
-    if (ctx->wino_persistent) grid = (int)std::min<long>(grid, half ? 512 : 256);   // one block per resident slot, each walks its share
+    if (ctx->wino_persistent) grid = (int)std::min<long>(grid, slots);   // one block per resident slot, each walks its share
+    if (streamk) {
+      p.sk_G = skG; p.sk_gran = gran; p.sk_F = skF; p.sk_q = skq; p.sk_rem = skrem; p.sk_nlb = slots / 8; grid = slots;
+      if (!plan_only) {
+        if (!ctx->wino_counters) {   // one word per tile block, zero between launches (the kernel leaves them so)
+          DI_CHECK(hipMalloc(&ctx->wino_counters, W8_SK_MAX_TILE_BLOCKS * sizeof(int)));
+          DI_CHECK(hipMemsetAsync(ctx->wino_counters, 0, W8_SK_MAX_TILE_BLOCKS * sizeof(int), ctx->stream));
+        }
+        p.sk_count = (int*)ctx->wino_counters;
+      }
+    }
+    if (plan_only) {   // {block shape 0 / 1 wide / 2 four-wave, grid, K slices, K steps per slice, stream-K granules per tile block (0: off), granules per run, whole tile blocks per block before the run}
+      plan_only[0] = half ? 2 : wide ? 1 : 0; plan_only[1] = grid; plan_only[2] = S; plan_only[3] = ks; plan_only[4] = p.sk_G; plan_only[5] = p.sk_q; plan_only[6] = p.sk_F;
+      return 0;
+    }
 #define W8_LAUNCH(O, S)                                                                               \
     if (half) conv_wino4_kernel<O, S><<<grid, 256, 0, ctx->stream>>>(p);                              \
     else if (wide) conv_wino8_kernel<O, S, 1><<<grid, 512, 0, ctx->stream>>>(p);                      \
@@ -1219,13 +1375,14 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     if (S > 1) {
       const long total = out_nc8 ? (long)(out_elems / 4) : (long)out_elems;
       const int hw = p.out_s2d ? H * W / 4 : H * W;
-      wino_reduce_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(final_out, p.out, bias, total, p.part_stride, S, slope, out_nc8 ? 1 : 0,
+      wino_reduce_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(out, p.part, bias, total, p.part_stride, S, slope, out_nc8 ? 1 : 0,
                                                                            (Cout >> 3) * (p.out_s2d ? 4 : 1), hw, Cout >> 3, Cout,
                                                                            out_ctotal > 0 ? out_ctotal : Cout, out_coff);
     }
     DI_LAUNCH_CHECK();
     return 0;
   }
+  if (plan_only) return 0;
   // phase-by-phase K loop with the zero positions skipped: needs an even number of 8-channel blocks per input phase
   const bool phases = s2d && (Cin % 64) == 0 && ctx->wino_s2d_skip;
   if (two_wave) {
@@ -1256,6 +1413,14 @@ extern "C" int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const
                                               int out_coff) {
   DI_REQUIRE(H > 0 && W > 0 && ((H | W) & 1) == 0, "conv2d_wino_forward_s2d: even H and W required");
   return wino_forward_impl(ctx, out, in_s2d, packed_w, bias, B, 4 * Cin, H / 2, W / 2, Cout, slope, out_nc8, out_ctotal, out_coff, true);
+}
+
+// The launch plan of the shared-transform kernel for a layer geometry (s2d: the arguments are the space-to-depth problem's, as
+// wino_forward_impl sees them) under the context's options; plan[6] as documented at the fill site. -1 where that kernel is not used.
+extern "C" int deepim_conv_wino_plan(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int out_nc8, int s2d, int* plan) {
+  DI_REQUIRE(plan != nullptr, "conv_wino_plan: null plan");
+  for (int i = 0; i < 7; ++i) plan[i] = -1;
+  return wino_forward_impl(ctx, nullptr, nullptr, nullptr, nullptr, B, Cin, H, W, Cout, 0.f, out_nc8, 0, 0, s2d != 0, plan);
 }
 
 #if W8_TRACE

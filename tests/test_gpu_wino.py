@@ -26,6 +26,8 @@ def wino_kernel(ctx, request):
     lib.deepim_set_option(ctx.handle, b"wino_two_wave", 0)
     lib.deepim_set_option(ctx.handle, b"wino_wide", 1)
     lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
+    lib.deepim_set_option(ctx.handle, b"wino_streamk", 1)
+    lib.deepim_set_option(ctx.handle, b"wino_split", 0)
 
 
 def _to_nc8(x):
@@ -157,6 +159,93 @@ def test_wino_argument_checks(ctx):
     with pytest.raises(RuntimeError):
         lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 1, 8, 2, 2, 40, cf(0.1), 1, 0, 0)
     lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 0, 8, 2, 2, 32, cf(0.1), 1, 0, 0)      # empty batch: no launch
+
+def _plan(ctx, B, cin, H, W, cout, out_nc8, s2d):
+    plan = (ctypes.c_int * 7)()
+    assert lib.load().deepim_conv_wino_plan(ctx.handle, B, cin, H, W, cout, out_nc8, s2d, plan) == 0
+    return list(plan)
+
+
+# (B, Cin, H, W, Cout, forced): grids beyond one round of resident blocks on every block shape; forced = 2: stream-K wherever it applies
+# (few K steps: the cost model itself would not cut these), 1: the cost model's own choice (conv3_1 at the per-GPU share of an 8-GPU node)
+STREAMK_CASES = [
+    (4, 32, 96, 128, 128, 2),      # two granules per tile block, one channel block (wide) / two
+    (9, 64, 40, 56, 256, 2),       # ragged last tile block, padded grid (invalid tile blocks inside the runs)
+    (4, 256, 60, 80, 256, 1),      # conv3_1, B = 4
+]
+
+
+@pytest.mark.parametrize("case", STREAMK_CASES)
+def test_shared_transform_kernel_stream_k(ctx, case, wino_kernel):
+    """Grids that end in a partly filled round: the persistent blocks share that round granule by granule, a cut tile block's raw copies
+    are summed by whichever piece arrives last. Against the whole-tile-block walk (same kernel, wino_streamk = 0): rounding of the K cuts;
+    twice the same bits (the order of the adds is fixed, not the order of arrival)."""
+    if wino_kernel != "shared":
+        pytest.skip("the shared-transform kernel's own path")
+    B, cin, H, W, cout, forced = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    xin, pk, bias = ctx.array(_to_nc8(x)), _pack(ctx, w), ctx.array(b)
+    for out_nc8 in (1, 3):
+        outs = []
+        for sk in (0, forced):
+            lib.deepim_set_option(ctx.handle, b"wino_streamk", sk)
+            plan = _plan(ctx, B, cin, H, W, cout, out_nc8, 0)
+            if sk and plan[4] == 0 and case != STREAMK_CASES[0]:
+                pytest.skip("the last round of this grid on this block shape has too few granules per block: no stream-K")
+            assert (plan[4] > 0) == (sk > 0), plan
+            if sk:
+                assert plan[2] == 1 and plan[5] >= 1 and plan[6] >= 1 and plan[1] in (256, 512), plan
+            o = ctx.array(np.full((B, cout, H, W), 3.0, np.float32))
+            lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, 0, 0)
+            outs.append(o.asnumpy())
+        scale = max(1.0, float(np.abs(outs[0]).max()))
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * scale
+        assert not (outs[1] == 3.0).any()
+        o = ctx.array(np.full((B, cout, H, W), 5.0, np.float32))
+        lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, 0, 0)
+        np.testing.assert_array_equal(o.asnumpy(), outs[1])
+    # NCHW output: stream-K does not apply (the plan says so), the layer still runs
+    lib.deepim_set_option(ctx.handle, b"wino_streamk", 2)
+    assert _plan(ctx, B, cin, H, W, cout, 0, 0)[4] == 0
+    if case == STREAMK_CASES[0]:
+        ref = onet.conv2d(x, w, b, 1, 1, 0.1)
+        o = ctx.zeros((B, cout, H, W))
+        lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), 1, 0, 0)
+        got = _from_nc8(o.asnumpy(), (B, cout, H, W))
+        assert np.abs(got - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def test_stride2_layer_stream_k(ctx, wino_kernel):
+    """The 5x5 stride-2 form cuts between its eight-step loop bodies (granule = 8 steps = two 8-channel blocks of each input phase)."""
+    if wino_kernel != "shared":
+        pytest.skip("the shared-transform kernel's own path")
+    B, cin, H, W, cout = 6, 32, 128, 128, 256
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    Ho, Wo = H // 2, W // 2
+    xs = ctx.empty((B, 4 * cin, Ho, Wo))
+    lib.deepim_relayout_nc8_s2d(ctx.handle, xs, ctx.array(x), B, cin, H, W, 1)
+    pk = DeviceArray(ctx, (lib.load().deepim_conv_wino_packed_size(cout, 4 * cin) // 4,))
+    lib.deepim_conv_wino_pack_weights_s2d(ctx.handle, pk, ctx.array(w), cout, cin)
+    outs = []
+    for sk in (0, 2):
+        lib.deepim_set_option(ctx.handle, b"wino_streamk", sk)
+        plan = _plan(ctx, B, 4 * cin, Ho, Wo, cout, 3, 1)
+        assert (plan[4] == 2) == (sk > 0), plan            # 16 steps = 2 granules of 8
+        o = ctx.zeros((B, cout, Ho, Wo))
+        lib.deepim_conv2d_wino_forward_s2d(ctx.handle, o, xs, pk, ctx.array(b), B, cin, H, W, cout, cf(0.1), 3, 0, 0)
+        nchw = ctx.empty((B, cout, Ho, Wo))
+        lib.deepim_relayout_nc8_s2d(ctx.handle, nchw, o, B, cout, Ho, Wo, 0)
+        outs.append(nchw.asnumpy())
+    ref = onet.conv2d(x, w, b, 2, 2, 0.1)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(outs[1] - ref).max() <= TOL * scale
+    assert np.abs(outs[1] - outs[0]).max() <= 2e-6 * scale
 
 
 S2D_CASES = [

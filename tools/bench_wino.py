@@ -15,6 +15,7 @@ ROUNDS, REPS = 3, 5
 WIDE0, WIDE1 = (int(v) for v in os.environ.get('WINO_SHAPES', '1,3').split(','))   # block shapes: the timed one, the other one (1 auto, 0 64x64, 3 128x32, 2 64x32 x2)
 lib.deepim_set_option(ctx.handle, b'wino_wide', WIDE0)
 lib.deepim_set_option(ctx.handle, b'wino_persistent', int(os.environ.get('WINO_PERSIST', '1')))
+lib.deepim_set_option(ctx.handle, b'wino_streamk', int(os.environ.get('WINO_STREAMK', '1')))
 ONLY = os.environ.get("WINO_LAYERS", "").split(",") if os.environ.get("WINO_LAYERS") else None
 for name, cin, H, W, cout in LAYERS:
     if ONLY and name not in ONLY:

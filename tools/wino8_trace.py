@@ -25,9 +25,11 @@ for shape in (3, 2):
             lib.deepim_conv2d_wino_forward(ctx.handle, out, x, pw, None, B, cin, H, W, cout, ctypes.c_float(0.1), 1, 0, 0)
         ctx.sync()
         t = tr.asnumpy().reshape(8, 8).astype(np.int64)
-        print("%s B %d shape %d: per wave ticks [prologue | K loop (%d steps) | output transform + exchange | finish + stores | total]" % (name, B, shape, cin // 8))
+        print("%s B %d shape %d: per wave ticks [prologue: to stage 0 visible + rest | K loop (%d steps) | output transform, sums sent | + barrier | finish + stores | total]" % (name, B, shape, cin // 8))
         for w in range(8):
             if t[w, 0] == 0:
                 continue
-            print("  wave %d: %6d | %7d (%.0f / step) | %6d | %6d | %7d" % (w, t[w, 1] - t[w, 0], t[w, 2] - t[w, 1], (t[w, 2] - t[w, 1]) / (cin // 8),
-                                                                              t[w, 3] - t[w, 2], t[w, 4] - t[w, 3], t[w, 4] - t[w, 0]))
+            print("  wave %d: %6d + %5d | %7d (%.0f / step) | %6d | %5d | %6d | %7d" % (w, t[w, 5] - t[w, 0], t[w, 1] - t[w, 5], t[w, 2] - t[w, 1], (t[w, 2] - t[w, 1]) / (cin // 8),
+                                                                                    t[w, 6] - t[w, 2], t[w, 3] - t[w, 6], t[w, 4] - t[w, 3], t[w, 4] - t[w, 0]))
+        t0 = t[t[:, 0] > 0]
+        print("  block: first entry -> last exit %d ticks; entry spread %d, exit spread %d" % (t0[:, 4].max() - t0[:, 0].min(), t0[:, 0].max() - t0[:, 0].min(), t0[:, 4].max() - t0[:, 4].min()))
