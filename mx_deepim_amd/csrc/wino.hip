@@ -1332,7 +1332,9 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     int skF = 0, skq = 0, skrem = 0;
     const int skG = (ctx->wino_split != 1 && ctx->wino_persistent && ctx->wino_streamk && out_nc8 && out_elems * 4 < (1ull << 31)) ? wino8_streamk_plan(grid, nK, gran, slots, &cost_sk, &skF, &skq, &skrem) : 0;
     // measured (bench.py A/B in one box): +1 % at B = 32 (4-18 whole rounds before the cut one), -1 % at B = 4 (one): from two whole rounds on
-    const bool streamk = skG > 0 && (ctx->wino_streamk == 2 || (skF >= 2 && cost_sk < cost_split * 0.98));   // 2: wherever it applies (tests)
+    // (the arrival counters are allocated on the first such launch: not inside a graph capture — run the sequence once eagerly first)
+    const bool streamk = skG > 0 && (ctx->wino_counters || !ctx->capturing) &&
+                         (ctx->wino_streamk == 2 || (skF >= 2 && cost_sk < cost_split * 0.98));   // 2: wherever it applies (tests)
     if (streamk) { S = 1; ks = nK; }
     p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0; p.part = nullptr;
     if ((S > 1 || streamk) && !plan_only) {
