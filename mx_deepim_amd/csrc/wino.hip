@@ -37,7 +37,7 @@ struct WinoParams {
   const float* bias;
   float slope;
   int Cin, Cout, H, W, TY, TX, ntiles, gx, gy;
-  unsigned in_bytes, wd_bytes;
+  unsigned in_bytes, wd_bytes, out_bytes;   // out_bytes: one channel-blocked copy of the output (conv_wino8_kernel's buffer stores; < 2 GB)
   int out_ctotal, out_coff;   // NCHW output: channel slice of a wider tensor
   int out_s2d;                // NC8 output in space-to-depth order (the input format of the next stride-2 layer on this kernel)
   // conv_wino8_kernel, split over the input channels: slice = blockIdx.x / grid0 walks the 8-channel blocks [slice*kslice, +kslice) and
@@ -915,7 +915,13 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   const float* const biasp = copy >= 0 ? nullptr : p.bias;
   float slope_e = copy >= 0 ? 1.f : p.slope;
   const bool through = copy >= 0 && p.sk_G > 0;
-  const __amdgpu_buffer_rsrc_t rsrp = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, through ? (int)(p.part_stride * 4) : 0, 0x00020000);
+  // channel-blocked output: 32-byte records addressed as the lane's base (its tile's first pixel in channel block mb*4) + a wave-uniform
+  // scalar offset per (channel block, pixel) — no 64-bit address arithmetic per store (it was a third of this epilogue's vector work)
+  const __amdgpu_buffer_rsrc_t rsrp = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, OUT_NC8 ? (int)p.out_bytes : 0, 0x00020000);
+  const int C8o = p.Cout >> 3, tpo = p.TY * TXe;
+  const int gstep = p.out_s2d ? tpo : p.H * p.W;                    // records from one channel block to the next
+  const int ab1 = p.out_s2d ? C8o * tpo : 1, ab2 = p.out_s2d ? 2 * C8o * tpo : p.W;   // ... to the pixel to the right / below
+  const int vo0 = ((p.out_s2d ? (n * 4 * C8o + mb * 4) * tpo + ty * TXe + tx : (n * C8o + mb * 4) * (p.H * p.W) + y0 * p.W + x0) * 32) + 16 * lrow_e;
   asm volatile("" : "+v"(slope_e));
   float* xw = reinterpret_cast<float*>(smem) + wave * 2048 + lanee;
   const float* xr = reinterpret_cast<const float*>(smem) + (wave ^ (HALF ? 2 : 4)) * 2048 + lanee;
@@ -962,19 +968,14 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
         _Pragma("unroll") for (int ab = 0; ab < 4; ++ab) {                                            \
           const int a = ab >> 1, b = ab & 1;                                                          \
           if ((a && !y1ok) || (b && !x1ok)) continue;                                                 \
-          const long pix = (long)(y0 + a) * p.W + x0 + b;                                             \
-          if (OUT_NC8) {                                                                              \
-            long rec;                                                                                 \
-            if (p.out_s2d)                                                                            \
-              rec = (((long)n * 4 + ab) * (p.Cout >> 3) + mb * 4 + g) * (p.TY * TXe) + ty * TXe + tx; \
-            else                                                                                      \
-              rec = ((long)n * (p.Cout >> 3) + mb * 4 + g) * p.H * p.W + pix;                         \
-            if (through) {   /* a stream-K piece: straight to memory (sc0 sc1), whichever XCD's block reads it back */ \
-              f32x4 ov; ov.x = o[ab][0]; ov.y = o[ab][1]; ov.z = o[ab][2]; ov.w = o[ab][3];            \
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, ov), rsrp, (int)(rec * 32) + 16 * lrow_e, 0, 17); \
-            } else                                                                                    \
-            *reinterpret_cast<float4*>(outp + rec * 8 + 4 * lrow_e) = make_float4(o[ab][0], o[ab][1], o[ab][2], o[ab][3]); \
+          if (OUT_NC8) {   /* record (channel block g, pixel ab) of this lane's tile: the lane's base + a wave-uniform offset */ \
+            const int so_ = (g * gstep + (ab == 0 ? 0 : ab == 1 ? ab1 : ab == 2 ? ab2 : ab1 + ab2)) * 32; \
+            f32x4 ov; ov.x = o[ab][0]; ov.y = o[ab][1]; ov.z = o[ab][2]; ov.w = o[ab][3];              \
+            const auto od = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, ov); \
+            if (through) __builtin_amdgcn_raw_buffer_store_b128(od, rsrp, vo0, so_, 17);   /* a stream-K piece: straight to memory (sc0 sc1), whichever XCD's block reads it back */ \
+            else __builtin_amdgcn_raw_buffer_store_b128(od, rsrp, vo0, so_, 0);                       \
           } else {                                                                                    \
+            const long pix = (long)(y0 + a) * p.W + x0 + b;                                           \
             const long c0 = (long)n * p.out_ctotal + p.out_coff + mb * 32 + 8 * g + 4 * lrow_e;         \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) outp[(c0 + e) * p.H * p.W + pix] = o[ab][e]; \
           }                                                                                           \
@@ -1247,12 +1248,13 @@ static int wino_pays(deepim_ctx* ctx, int B, int H, int W, int Cout, long min_bl
 extern "C" int deepim_conv_wino_preferred(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7)) return 0;
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;   // one buffer descriptor per launch: larger inputs stay on the direct kernels (sub-batched there)
+  if ((size_t)B * Cout * H * W * 4 >= (1ull << 31)) return 0;  // ... and one for the output
   return wino_pays(ctx, B, H, W, Cout, WINO_MIN_BLOCKS);
 }
 // the same question for a 5x5 stride-2 pad-2 layer with input (B, Cin, H, W) run over its space-to-depth form
 extern "C" int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cout & 31) || (Cin & 7) || ((H | W) & 1)) return 0;
-  if ((size_t)B * Cin * H * W * 4 >= (1ull << 31)) return 0;
+  if ((size_t)B * Cin * H * W * 4 >= (1ull << 31) || (size_t)B * Cout * (H / 2) * (W / 2) * 4 >= (1ull << 31)) return 0;
   return wino_pays(ctx, B, H / 2, W / 2, Cout, WINO_MIN_BLOCKS_S2D);
 }
 
@@ -1310,6 +1312,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   p.gx = di_div_up(p.ntiles, (wide || half) ? 32 : (two_wave || shared) ? 64 : 128);
   p.gy = wide ? Cout / 128 : shared ? Cout / 64 : Cout / 32;
   p.in_bytes = (unsigned)in_bytes; p.wd_bytes = (unsigned)wd_bytes;
+  p.out_bytes = (unsigned)std::min<size_t>((size_t)B * Cout * H * W * 4, 0x7fffffffu);
   p.out_ctotal = out_ctotal > 0 ? out_ctotal : Cout;
   p.out_coff = out_coff;
   p.out_s2d = out_nc8 == 3 ? 1 : 0;
@@ -1318,6 +1321,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
   if (p.out_s2d) DI_REQUIRE(((H | W) & 1) == 0, "conv2d_wino_forward: space-to-depth output needs even H and W");
   int grid = p.gx * p.gy;
   if (shared) {
+    DI_REQUIRE(!out_nc8 || (size_t)B * Cout * H * W * 4 < (1ull << 31), "conv2d_wino_forward: channel-blocked output beyond the 2 GB buffer range");
     // block -> (channel block, tile block) as conv_wino8_kernel maps it: gy < 8 dividing 8 deals 8 / gy XCDs to each channel block
     if ((p.gy & 7) != 0 && (8 % p.gy) == 0) grid = 8 * di_div_up(p.gx, 8 / p.gy);
     // the zero positions are dropped along an interleaved walk of the four input phases: two 8-channel blocks of each per loop body
