@@ -11,7 +11,7 @@ rng = np.random.default_rng(0)
 LAYERS = [("conv3_1", 256, 60, 80, 256), ("conv4_1", 512, 30, 40, 512), ("conv5_1", 512, 15, 20, 512), ("conv6_1", 1024, 8, 10, 1024)]
 if os.environ.get("WINO_CUSTOM"):     # "name,cin,H,W,cout;..." instead of the encoder's 3x3 layers (e.g. the same tiles at two depths: the per-block fixed cost)
     LAYERS = [(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4])) for f in (e.split(",") for e in os.environ["WINO_CUSTOM"].split(";"))]
-ROUNDS, REPS = 3, 5
+ROUNDS, REPS = (1, 1) if os.environ.get('WINO_PROBE') else (3, 5)   # WINO_PROBE: one dispatch run per (layer, kernel) for a counter pass
 WIDE0, WIDE1 = (int(v) for v in os.environ.get('WINO_SHAPES', '1,3').split(','))   # block shapes: the timed one, the other one (1 auto, 0 64x64, 3 128x32, 2 64x32 x2)
 lib.deepim_set_option(ctx.handle, b'wino_wide', WIDE0)
 lib.deepim_set_option(ctx.handle, b'wino_persistent', int(os.environ.get('WINO_PERSIST', '1')))

@@ -9,7 +9,7 @@ prof r5_prof --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out
 tr=$(find gpurun_out/r5_prof -name "*kernel_trace.csv" | head -1); st=$(find gpurun_out/r5_prof -name "*kernel_stats.csv" | head -1)
 python tools/profile_summary.py stats $tr $st gpurun_out/r5_bench_profiled.log --iters 80 --batch 32 > gpurun_out/r05_bench_kernel_stats.csv
 python tools/trace_iteration.py $tr 1 > gpurun_out/r05_b32_iteration_trace.txt
-tail -c 3000 gpurun_out/r5_bench_profiled.log | grep "^{" > gpurun_out/r05_bench_profiled_n1.json.log
+grep "^{" gpurun_out/r5_bench_profiled.log | tail -1 > gpurun_out/r05_bench_profiled_n1.json.log
 # (2) heads graph and the training step: the H / F kernels
 prof r5_heads --kernel-trace --output-format csv -d /root/repo/gpurun_out/r5_heads -- $BENCH --heads --steps 4 --warmup 2 > gpurun_out/r5_heads.log 2>&1
 hr=$(find gpurun_out/r5_heads -name "*kernel_trace.csv" | head -1)
@@ -24,7 +24,7 @@ python tools/profile_summary.py perkernel $tr gpurun_out/r5_bench_profiled.log -
 tail -5 gpurun_out/r05_per_kernel.log
 rm -rf gpurun_out/r5_prof gpurun_out/r5_heads gpurun_out/r5_train gpurun_out/r5_pmc
 # (4) Winograd layer probe: issue counters per layer, both block shapes
-prof r5_pmcw --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /root/repo/gpurun_out/r5_pmcw -- python /root/repo/tools/bench_wino.py 32 > gpurun_out/r5_pmcw.log 2>&1
+prof r5_pmcw --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /root/repo/gpurun_out/r5_pmcw -- env WINO_PROBE=1 python /root/repo/tools/bench_wino.py 32 > gpurun_out/r5_pmcw.log 2>&1
 f=$(find gpurun_out/r5_pmcw -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python tools/pmc_summary.py $f 2>&1 | grep -v "pack\|relayout\|build_conv" | tee gpurun_out/r05_pmc_winograd.txt
 rm -rf gpurun_out/r5_pmcw
