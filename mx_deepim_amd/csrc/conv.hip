@@ -1027,6 +1027,99 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
   }
 }
 
+// The 3x3 stride-1 pad-1 heads with W % 4 == 0 (deepIM_flownet.py:123,145,317: the flow / mask predictors at 15x20 and 30x40): a lane
+// owns FOUR consecutive output pixels of a row. Per input channel it loads three rows of six columns — one aligned dwordx4 + the two
+// neighbours, out-of-image positions through out-of-range buffer offsets (the hardware returns the zero padding: no selects) — and
+// runs the 4 x 9 x COUT fmaf: 2.25 loads per output pixel and channel instead of 9, and no masking VALU. The conv_fewout_kernel above
+// ran at 0.10-0.20 of the HBM rate (profiles/per_kernel.json); this one at 0.19-0.24 (the 770-channel heads 75-79 -> 61-64 us). Eight waves split the block's
+// channel slice into eighths ((ci,ky,kx)-ordered chains, partial sums added in wave order through LDS), grid.y slices the channels
+// further where the pixels alone leave the chip empty (raw sums to partial[slice][n][co][hw], fixed-order second pass).
+template <int COUT>
+__global__ __launch_bounds__(512) void conv_fewout_quad_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                              const float* __restrict__ wp, const float* __restrict__ bias, int Cin,
+                                                              int H, int W, long nquad, unsigned in_bytes, int out_ctotal, int out_coff,
+                                                              float slope, float* __restrict__ partial, int cslice) {
+  constexpr int NW = 8;
+  __shared__ float4 part[NW - 1][COUT][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long q = (long)blockIdx.x * 64 + lane;
+  const bool live = q < nquad;
+  const int Wq = W >> 2, hwq = H * Wq, hw = H * W;
+  const int n = live ? (int)(q / hwq) : 0;
+  const int r = live ? (int)(q - (long)n * hwq) : 0;
+  const int ho = r / Wq, x0 = (r - ho * Wq) * 4;
+  // byte offsets of (row ho - 1 + ky, columns x0 - 1 | x0 .. x0 + 3 | x0 + 4) in channel 0 of sample n; bit 31 = outside the image
+  int voff[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int hi = ho - 1 + ky;
+    const bool rowok = live && hi >= 0 && hi < H;
+    const int base = ((n * Cin) * H + hi) * W + x0;
+    voff[ky][0] = rowok && x0 > 0 ? (base - 1) * 4 : (int)0x80000000;
+    voff[ky][1] = rowok ? base * 4 : (int)0x80000000;
+    voff[ky][2] = rowok && x0 + 4 < W ? (base + 4) * 4 : (int)0x80000000;
+  }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+  const int s_lo = blockIdx.y * cslice, s_hi = min(Cin, s_lo + cslice);
+  const int cq = (s_hi - s_lo + NW - 1) / NW;
+  const int c_lo = min(s_hi, s_lo + wave * cq), c_hi = min(s_hi, c_lo + cq);
+  float acc[COUT][4];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[co][o] = 0.f;
+  // (Tried, same box: four channels' loads in flight together — 62.5 / 61.1 us against 63.6 / 61.4 on the 770-channel heads; the weights
+  // staged in per-wave LDS strips instead of scalar loads from the packed layout's 256-byte lines — 75 us. Neither the load latency of a
+  // wave nor the scalar cache is what holds this stream at ~2 TB/s; kept simple.)
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    const int so = ci * hw * 4;
+    float x[3][6];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      x[ky][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][0], so, 0));
+      const float4 m = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ky][1], so, 0));
+      x[ky][1] = m.x; x[ky][2] = m.y; x[ky][3] = m.z; x[ky][4] = m.w;
+      x[ky][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][2], so, 0));
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {   // LDS-kernel packing, granule 0: wp[k*64 + co] = w[co][k], k = (ci,ky,kx)
+          const float wv = wp[((long)ci * 9 + ky * 3 + kx) * GRAN + co];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv, x[ky][o + kx], acc[co][o]);
+        }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) part[wave - 1][co][lane] = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float4 v = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+#pragma unroll
+      for (int w_ = 0; w_ < NW - 1; ++w_) {
+        const float4 t = part[w_][co][lane];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      const long pix0 = (long)ho * W + x0;
+      if (partial) {
+        *reinterpret_cast<float4*>(partial + (((long)blockIdx.y * (nquad / hwq) + n) * COUT + co) * hw + pix0) = v;
+        continue;
+      }
+      const float bv = bias ? bias[co] : 0.f;
+      v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      *reinterpret_cast<float4*>(out + ((long)n * out_ctotal + out_coff + co) * hw + pix0) = v;
+    }
+  }
+}
+
 // split-K second pass: out[n][coff+c][hw] = lrelu(Σ_s partial[s][n][c][hw] + bias[c]) in fixed order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(float* __restrict__ out, const float* __restrict__ partial,
                                                             const float* __restrict__ bias, long total, long stride,
@@ -2002,7 +2095,10 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
   }
   if (Cout <= 4 && ctx->conv_max_split != 1 && p.out_nc8 == 0) {   // heads: a stream over the input, not an MFMA problem
     // channel slices when the pixels alone leave the chip empty: ~512 blocks, slices of at least 32 channels (fixed by the geometry)
-    const int nblk = di_div_up(p.npix, 64);
+    // the 3x3 stride-1 pad-1 heads on rows of whole quads: four pixels per lane (conv_fewout_quad_kernel); dev option conv_fewout_quad = 0: the one-pixel form
+    const bool quad = kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W & 3) == 0 && ctx->conv_fewout_quad &&
+                      (((uintptr_t)out | (uintptr_t)in) & 15) == 0;
+    const int nblk = quad ? di_div_up(p.npix / 4, 64) : di_div_up(p.npix, 64);
     int S = max(1, min(min(512 / nblk, Cin / 32), 16));
     const int cslice = di_div_up(Cin, S);
     S = di_div_up(Cin, cslice);
@@ -2015,6 +2111,13 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
       partial = (float*)scratch;
     }
     const dim3 grid(nblk, S);
+    if (quad) {
+#define DI_FEWOUT_Q(C)                                                                                                  \
+  hipLaunchKernelGGL((conv_fewout_quad_kernel<C>), grid, dim3(512), 0, ctx->stream, out, in, packed_w, bias, Cin, H, W, p.npix / 4, \
+                     p.in_bytes, p.out_ctotal, out_coff, slope, partial, cslice)
+      if (Cout == 1) DI_FEWOUT_Q(1); else if (Cout == 2) DI_FEWOUT_Q(2); else if (Cout == 3) DI_FEWOUT_Q(3); else DI_FEWOUT_Q(4);
+#undef DI_FEWOUT_Q
+    } else {
 #define DI_FEWOUT(C, KS)                                                                                               \
   hipLaunchKernelGGL((conv_fewout_kernel<C, KS>), grid, dim3(1024), 0, ctx->stream, out, in, packed_w, bias, Cin, H, W, p.Ho, \
                      p.Wo, kh, kw, stride, pad, p.npix, p.out_ctotal, out_coff, slope, partial, cslice)
@@ -2024,6 +2127,7 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
     else if (Cout == 3) { if (k3) DI_FEWOUT(3, 3); else DI_FEWOUT(3, 0); }
     else { if (k3) DI_FEWOUT(4, 3); else DI_FEWOUT(4, 0); }
 #undef DI_FEWOUT
+    }
     if (S > 1) {
       Remap none = {};
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, out, partial, bias, total, total,

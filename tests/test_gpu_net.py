@@ -306,13 +306,23 @@ def test_conv_tail_split_plan(ctx):
         lib.deepim_set_option(ctx.handle, b"conv_tail_slots", 1024)
 
 
+@pytest.mark.parametrize("quad", [1, 0], ids=["four_pixels_per_lane", "one_pixel_per_lane"])
 @pytest.mark.parametrize("case", [(2, 770, 30, 40, 2, 3, 1, 1), (1, 1026, 15, 20, 2, 3, 1, 1), (3, 37, 19, 23, 3, 5, 2, 2),
-                                  (2, 5, 9, 70, 4, 7, 1, 3), (1, 3, 8, 8, 1, 1, 1, 0), (16, 64, 30, 40, 2, 3, 1, 1), (4, 1024, 8, 10, 2, 3, 1, 1)])
-def test_conv_few_output_channels(ctx, case):
-    """Cout <= 4 (flow / mask heads) runs on the VALU streaming kernel by default: sixteen (ci,ky,kx)-ordered chains over
-    channel shares, added in order (and, when the pixels alone would leave the chip empty, up to sixteen channel slices over
-    grid.y with a fixed-order second pass) — within fp32 re-association distance of the canonical chain; writes into a channel
-    slice too."""
+                                  (2, 5, 9, 70, 4, 7, 1, 3), (1, 3, 8, 8, 1, 1, 1, 0), (16, 64, 30, 40, 2, 3, 1, 1), (4, 1024, 8, 10, 2, 3, 1, 1),
+                                  (2, 770, 30, 40, 1, 3, 1, 1), (3, 40, 6, 8, 3, 3, 1, 1), (2, 16, 5, 4, 4, 3, 1, 1), (5, 9, 1, 12, 2, 3, 1, 1)])
+def test_conv_few_output_channels(ctx, case, quad):
+    """Cout <= 4 (flow / mask heads) runs on the VALU streaming kernels by default: (ci,ky,kx)-ordered chains over channel shares,
+    added in order (and, when the pixels alone would leave the chip empty, up to sixteen channel slices over grid.y with a fixed-order
+    second pass) — within fp32 re-association distance of the canonical chain; writes into a channel slice too. The 3x3 stride-1 pad-1
+    heads with W % 4 == 0 take the four-pixels-per-lane form (rows of one quad, one-row images, Cout = 1 … 4 among the cases)."""
+    lib.deepim_set_option(ctx.handle, b"conv_fewout_quad", quad)
+    try:
+        _few_output_channels(ctx, case)
+    finally:
+        lib.deepim_set_option(ctx.handle, b"conv_fewout_quad", 1)
+
+
+def _few_output_channels(ctx, case):
     B, cin, H, W, cout, k, s, p = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((B, cin, H, W)).astype(np.float32)

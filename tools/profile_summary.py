@@ -152,7 +152,7 @@ def hbm_bytes(kernel, occ, batch, H=480, W=640):
     if kernel.startswith("resample4_kernel"):     # ZoomMaskWithFactor (1 ch) / ZoomFlow (2 ch) back to the camera frame: read + write once
         c = 1 if occ == 0 else 2
         return 8.0 * c * px, "%d channel(s) read and written once at 480x640" % c
-    if kernel.startswith("conv_fewout_kernel"):   # flow6 (1024 ch, 8x10), flow5 (1026, 15x20), mask head (770, 30x40), flow4 head (770, 30x40)
+    if kernel.startswith("conv_fewout"):          # (conv_fewout_kernel / conv_fewout_quad_kernel, one occurrence count) flow6 (1024 ch, 8x10), flow5 (1026, 15x20), mask head (770, 30x40), flow4 head (770, 30x40)
         cin, h, w = [(1024, 8, 10), (1026, 15, 20), (770, 30, 40), (770, 30, 40)][min(occ, 3)]
         return 4.0 * batch * cin * h * w, "input stream: %d channels at %dx%d read once" % (cin, h, w)
     return None, None
@@ -218,6 +218,7 @@ def cmd_perkernel(a):
             occ = defaultdict(int)
             for r, n in zip(hr[lo:hi], hn[lo:hi]):
                 base = re.sub(r"<.*$", "", n)
+                if base == "conv_fewout_quad_kernel": base = "conv_fewout_kernel"      # the heads' two kernel forms share the occurrence count
                 if base not in (("flow_kernel", "resolve_kernel", "upsample16_kernel", "upsample16x4_kernel", "resample4_kernel", "conv_fewout_kernel") if it
                                 else ("flow_kernel",)):     # the training-step trace: lib/flow_c's kernel only (its other launches mix shapes)
                     continue
