@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <map>
 #include <type_traits>
 #include <algorithm>
 #include "../../include/deepim_hip.h"
@@ -75,6 +76,7 @@ struct deepim_ctx {
   int wino_split;        // K-split of the shared-transform kernel: 0 (default) = the plan of wino8_split_plan, 1 = never, n = at most n slices
   int conv_fewout_quad;  // 1 (default): the 3x3 stride-1 heads with W % 4 == 0 on the four-pixels-per-lane kernel; 0: one pixel per lane
   int wino_streamk;      // 1 (default): where a grid leaves a partly filled last round, the persistent blocks share the work granule by granule (stream-K; needs wino_persistent, off with wino_split = 1); 2: wherever it applies, whatever the cost model says; 0: never
+  std::map<uintptr_t, size_t> allocs;   // deepim_malloc's live allocations (base -> bytes): deepim_d2d's residency test without a driver query
   void* wino_counters;   // stream-K arrival counters, one per tile block (allocated on first use, zero between launches)
   int wino_persistent;   // 1 (default): the shared-transform kernel's grid is one block per resident slot, each walking its share of the tiles; 0: one block per tile block
   int wino_two_wave;     // 0 (default): Winograd layers on the one-wave 16-position kernel; 1: the two-waves-per-SIMD kernel (measured slower on the big layers)

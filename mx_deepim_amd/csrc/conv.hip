@@ -1816,8 +1816,8 @@ int actgrad_pass(deepim_ctx* ctx, float* dx, const ActGrad& ag, size_t n) {
 
 // forward use of the same machinery (a transposed convolution IS the data gradient of a stride-2 convolution): explicit size of the
 // input map (the Crop may keep fewer rows than the adjoint's full frame), bias + LeakyReLU + channel slice in the final stores,
-// weights packed once (pack_only fills packed_ws and returns; prepacked skips the pack launch)
-struct S2Forward { int Ho, Wo; const float* bias; float slope; int out_ctotal, out_coff; bool prepacked, pack_only; };
+// weights packed once (s2_pack_direct_group; prepacked skips the pack launch)
+struct S2Forward { int Ho, Wo; const float* bias; float slope; int out_ctotal, out_coff; bool prepacked; };
 static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
                                 int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag, const S2Forward* fw = nullptr);
 
@@ -1856,19 +1856,68 @@ extern "C" int deepim_conv2d_dgrad(deepim_ctx* ctx, float* dx, const float* dz, 
   return 0;
 }
 
+// The four parity classes of a stride-2 layer's operand buffer, a function of (Ci_l, Co_l, k, pad) only: class z at slot[z] (three
+// halves each: LDS-kernel packing, then the register-fed kernel's operand order), members of a grouped launch in descending K
+// (ord: the long blocks are dispatched first). Shared by the pack entry and the launches so the two cannot drift apart.
+struct S2Layout {
+  S2Class cls[4];
+  size_t slot[4];
+  int ord[4];
+};
+static S2Layout s2_layout(int Ci_l, int Co_l, int k, int pad) {
+  S2Layout L;
+  size_t off = 0;
+  for (int z = 0; z < 4; ++z) {
+    L.cls[z] = s2_class(z, k, pad);
+    L.slot[z] = off;
+    off += 3 * packed_half(Ci_l, Co_l * L.cls[z].nky * L.cls[z].nkx);
+    L.ord[z] = z;
+  }
+  for (int a = 0; a < 4; ++a)
+    for (int b = a + 1; b < 4; ++b)
+      if (L.cls[L.ord[b]].nky * L.cls[L.ord[b]].nkx > L.cls[L.ord[a]].nky * L.cls[L.ord[a]].nkx) { const int t = L.ord[a]; L.ord[a] = L.ord[b]; L.ord[b] = t; }
+  return L;
+}
+// The register-fed kernel's operands of all four classes from the layer's own (Co_l, Ci_l, k, k) weights, one launch. No geometry: the
+// operand order does not depend on the image (deepim_deconv_pack_weights packs once per update, the data gradient per call).
+static int s2_fill_pack_group(PackGroup& pg, const S2Layout& L, float* packed_ws, int Ci_l, int Co_l, int k) {
+  pg.n = 4;
+  pg.Cout = Ci_l; pg.Cin = Co_l;
+  int pstart = 0;
+  for (int m = 0; m < 4; ++m) {
+    const S2Class& c = L.cls[L.ord[m]];
+    const size_t half = packed_half(Ci_l, Co_l * c.nky * c.nkx);
+    pg.dst[m] = packed_ws + L.slot[L.ord[m]] + half;
+    pg.total[m] = (long)half;
+    pg.khw[m] = c.nky * c.nkx;
+    pg.npair[m] = chunk_count(Co_l * c.nky * c.nkx) * (KT / 2);
+    pg.v[m] = WView{1, Ci_l, k, k, c.ky0, c.kx0, 2, c.nky, c.nkx};
+    pg.start[m] = pstart;
+    pstart += (int)di_div_up((long)half, 256);
+  }
+  pg.start[4] = pstart;
+  return pstart;
+}
+static int s2_pack_direct_group(deepim_ctx* ctx, const float* w_layer, float* packed_ws, int Ci_l, int Co_l, int k, int pad) {
+  DI_REQUIRE(k >= 2 && k <= 7 && pad >= 0 && pad < k, "conv2d_dgrad_s2: kernel 2 … 7, pad < k");
+  const S2Layout L = s2_layout(Ci_l, Co_l, k, pad);
+  PackGroup pg;
+  const int pstart = s2_fill_pack_group(pg, L, packed_ws, Ci_l, Co_l, k);
+  hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
+  DI_LAUNCH_CHECK();
+  return 0;
+}
+
 static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, const float* w_layer, float* packed_ws, int B,
                                 int Ci_l, int Hd, int Wd, int Co_l, int k, int pad, const ActGrad* ag, const S2Forward* fw) {
   DI_DEVICE(ctx);
   if (B == 0) return 0;
   DI_REQUIRE(k >= 2 && k <= 7 && pad >= 0 && pad < k, "conv2d_dgrad_s2: kernel 2 … 7, pad < k");
   const int Ho = fw ? fw->Ho : (Hd + 2 * pad - k) / 2 + 1, Wo = fw ? fw->Wo : (Wd + 2 * pad - k) / 2 + 1;
-  S2Class cls[4];
-  size_t slot[4], off = 0;
-  for (int z = 0; z < 4; ++z) {
-    cls[z] = s2_class(z, k, pad);
-    slot[z] = off;
-    off += 3 * packed_half(Ci_l, Co_l * cls[z].nky * cls[z].nkx);
-  }
+  const S2Layout L = s2_layout(Ci_l, Co_l, k, pad);
+  const S2Class* cls = L.cls;
+  const size_t* slot = L.slot;
+  const int* ord = L.ord;
   const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
   const size_t in_bytes = (size_t)B * Co_l * Ho * Wo * 4;
   const bool grouped = fw != nullptr || (ctx->dgrad_group && direct && (Co_l & 1) == 0 && !(ctx->conv_tile256 && Ci_l % 256 == 0) &&
@@ -1887,17 +1936,12 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     }
     return ag ? actgrad_pass(ctx, dx, *ag, (size_t)B * Ci_l * Hd * Wd) : 0;
   }
-  // members in descending K (the long blocks are dispatched first)
-  int ord[4] = {0, 1, 2, 3};
-  for (int a = 0; a < 4; ++a)
-    for (int b = a + 1; b < 4; ++b)
-      if (cls[ord[b]].nky * cls[ord[b]].nkx > cls[ord[a]].nky * cls[ord[a]].nkx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+  // members in descending K (S2Layout::ord)
   ConvGroup g;
   PackGroup pg;
-  g.n = pg.n = 4;
-  pg.Cout = Ci_l; pg.Cin = Co_l;
+  g.n = 4;
+  const int pstart = s2_fill_pack_group(pg, L, packed_ws, Ci_l, Co_l, k);
   long tiles[4];
-  int pstart = 0;
   for (int m = 0; m < 4; ++m) {
     const S2Class& c = cls[ord[m]];
     ConvParams& p = g.p[m];
@@ -1929,20 +1973,6 @@ static int conv2d_dgrad_s2_impl(deepim_ctx* ctx, float* dx, const float* dz, con
     p.gx = di_div_up(p.npix, bn); p.gy = di_div_up(Ci_l, bm);
     p.n_full = 0; p.tail_s = 0; p.tail_cps = 0; p.n_tail_pad = 0; p.tail_partial = nullptr;
     tiles[m] = (long)p.gx * p.gy;
-    // pack member
-    pg.dst[m] = packed_ws + slot[ord[m]] + half;
-    pg.total[m] = (long)half;
-    pg.khw[m] = c.nky * c.nkx;
-    pg.npair[m] = p.nchunk * (KT / 2);
-    pg.v[m] = WView{1, Ci_l, k, k, c.ky0, c.kx0, 2, c.nky, c.nkx};
-    pg.start[m] = pstart;
-    pstart += (int)di_div_up((long)half, 256);
-  }
-  pg.start[4] = pstart;
-  if (fw && fw->pack_only) {
-    hipLaunchKernelGGL(pack_direct_group_kernel, dim3(pstart), dim3(256), 0, ctx->stream, w_layer, pg);
-    DI_LAUNCH_CHECK();
-    return 0;
   }
   // joint plan: T = K chunks per block; member m runs ceil(nchunk_m / T) slices. cost as plan_ksplit: rounds of 256 blocks x the
   // longest block, + the second pass
@@ -2169,10 +2199,8 @@ extern "C" int deepim_deconv_pack_weights(deepim_ctx* ctx, float* packed_w, cons
   hipLaunchKernelGGL(pack_deconv_kernel, dim3(di_div_up(total, 256)), dim3(256), 0, ctx->stream, packed_w, w, Cin, Cout,
                      ngran, nchunk, total);
   DI_LAUNCH_CHECK();
-  if (deconv_direct_ok(Cin, Cout)) {
-    const S2Forward fw = {1, 1, nullptr, 1.f, 0, 0, false, true};
-    return conv2d_dgrad_s2_impl(ctx, nullptr, nullptr, w, packed_w + deconv_lds_pack_floats(Cin, Cout), 1, Cout, 2, 2, Cin, 4, 1, nullptr, &fw);
-  }
+  if (deconv_direct_ok(Cin, Cout))   // the register-fed kernel's operands of the four parity classes (k = 4, pad = 1): no geometry involved
+    return s2_pack_direct_group(ctx, w, packed_w + deconv_lds_pack_floats(Cin, Cout), Cout, Cin, 4, 1);
   return 0;
 }
 
@@ -2192,7 +2220,7 @@ extern "C" int deepim_deconv4x4s2_crop_forward(deepim_ctx* ctx, float* out, cons
   const bool direct = ctx->conv_direct == 2 || (ctx->conv_direct == 1 && ctx->conv_max_split != 1);
   if (direct && crop_y == 1 && crop_x == 1 && deconv_direct_ok(Cin, Cout) && !ctx->conv_tile256 &&
       (size_t)B * Cin * H * W * 4 + (size_t)(4 * W + 4) * 4 < 0x7fffffffUL) {
-    const S2Forward fw = {H, W, bias, slope, out_ctotal > 0 ? out_ctotal : Cout, out_coff, true, false};
+    const S2Forward fw = {H, W, bias, slope, out_ctotal > 0 ? out_ctotal : Cout, out_coff, true};
     return conv2d_dgrad_s2_impl(ctx, out, in, nullptr, const_cast<float*>(packed_w) + deconv_lds_pack_floats(Cin, Cout), B, Cout, Ho, Wo,
                                 Cin, 4, 1, nullptr, &fw);
   }

@@ -124,12 +124,14 @@ int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
 extern "C" int deepim_malloc(deepim_ctx* ctx, size_t bytes, void** dptr) {
   DI_DEVICE(ctx);
   DI_CHECK(hipMalloc(dptr, bytes ? bytes : 4));
+  ctx->allocs[(uintptr_t)*dptr] = bytes ? bytes : 4;
   return 0;
 }
 extern "C" int deepim_free(deepim_ctx* ctx, void* dptr) {
   DI_DEVICE(ctx);
   if (!dptr) return 0;
   DI_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->allocs.erase((uintptr_t)dptr);
   DI_CHECK(hipFree(dptr));
   return 0;
 }
@@ -163,13 +165,23 @@ extern "C" int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t by
   // small word-aligned copies (poses, head weights, 7-row gradient blocks) as a kernel in stream order: the blit path of
   // hipMemcpyAsync left 8-18 µs gaps around each of them in the training trace
   // (the kernel dereferences both pointers on ctx's device: only when both allocations live there — a source on another
-  // device, e.g. DeviceArray.copyfrom across contexts, keeps the runtime's peer copy)
-  auto on_device = [&](const void* q) {
+  // device, e.g. DeviceArray.copyfrom across contexts, keeps the runtime's peer copy). Residency: the context's own allocation table
+  // first (deepim_malloc / deepim_free keep it: no driver call on the path this kernel exists to shorten); a pointer it does not
+  // know is asked of the driver — never inside a stream capture, where an unknown pointer takes the memcpy node instead.
+  auto mine = [&](const void* q, size_t n) {
+    auto it = ctx->allocs.upper_bound((uintptr_t)q);
+    if (it == ctx->allocs.begin()) return false;
+    --it;
+    return (uintptr_t)q + n <= it->first + it->second;
+  };
+  auto on_device = [&](const void* q, size_t n) {
+    if (mine(q, n)) return true;
+    if (ctx->capturing) return false;
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeDevice && a.device == ctx->device;
   };
-  if (bytes <= (1u << 20) && ((bytes | (size_t)dst | (size_t)src) & 3) == 0 && (ctx->capturing || (on_device(dst) && on_device(src)))) {   // no pointer queries inside a stream capture
+  if (bytes <= (1u << 20) && ((bytes | (size_t)dst | (size_t)src) & 3) == 0 && on_device(dst, bytes) && on_device(src, bytes)) {
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)dst,
                        (const uint32_t*)src, n);
