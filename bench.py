@@ -877,8 +877,9 @@ def other_configs(left=lambda: 1e9):
     import subprocess
     runs = [("configs[1]_ape_batch16", ["--batch", "16", "--verify", "1"]),
             ("configs[2]_per_gpu_share_batch4", ["--batch", "4", "--verify", "1"]),
+            ("configs[2]_per_gpu_share_of_4_gpus_batch8", ["--batch", "8", "--verify", "1"]),
             ("configs[3]_decoder_mask_flow_heads_batch32", ["--heads", "--verify", "1"]),
-            ("configs[3]_decoder_mask_flow_heads_per_gpu_share_batch4", ["--heads", "--batch", "4", "--verify", "0"]),
+            ("configs[3]_decoder_mask_flow_heads_per_gpu_share_batch4", ["--heads", "--batch", "4", "--verify", "1"]),
             ("configs[4]_rgbd_fp16_conv_per_gpu_share_batch8", ["--fp16", "--depth", "--batch", "8", "--verify", "1"]),
             ("configs[4]_rgbd_fp16_conv_batch32", ["--fp16", "--depth", "--verify", "0"]),
             ("fp16_conv_8ch_batch32", ["--fp16", "--verify", "0"]),

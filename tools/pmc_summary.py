@@ -14,17 +14,20 @@ for r in rows:
 # one row per RUN of consecutive dispatches of the same (name, grid) — the persistent Winograd kernels launch the same grid for every layer, so
 # the name + grid alone no longer tell the layers apart; the dispatch order does (rows appear in it). Repeated runs with the same key and a
 # duration within 1.5 % of an earlier row's are folded into that row (a bench loop's rounds).
+import os
+FOLD = float(os.environ.get("PMC_FOLD", os.environ.get("PMC_TOL", "0.015")))   # PMC_FOLD=0: every run its own row (the probe runs each layer once)
+TOL = float(os.environ.get("PMC_TOL", "0.015"))   # PMC_TOL=0.25 for the layer probe: its runs are separated by other kernels already, and a counter pass is noisy
 last = OrderedDict()
 prev_key, run, run_ns = None, 0, 0.0
 for d in disp.values():
     key = (d["name"], d["grid"])
-    if key != prev_key or abs(d["ns"] - run_ns) > 0.015 * run_ns:    # (conv2 and conv3 follow each other on one kernel and one grid)
+    if key != prev_key or abs(d["ns"] - run_ns) > TOL * run_ns:    # (conv2 and conv3 follow each other on one kernel and one grid)
         run += 1
         prev_key, run_ns = key, d["ns"]
     last[(d["name"], d["grid"], run)] = d
 seen, folded = [], OrderedDict()
 for (n, g, r), d in last.items():
-    if any(n == n0 and g == g0 and abs(d["ns"] - ns0) <= 0.015 * ns0 for n0, g0, ns0 in seen):
+    if any(n == n0 and g == g0 and abs(d["ns"] - ns0) <= FOLD * ns0 for n0, g0, ns0 in seen):
         continue
     seen.append((n, g, d["ns"]))
     folded[(n, "%s#%d" % (g, r))] = d
