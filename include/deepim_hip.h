@@ -74,8 +74,11 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * (default) = its grid is one block per resident slot (256 of 8 waves, 512 of 4), each walking its share of the tile blocks, 0 = one
  * block per tile block (same results). "wino_streamk": 1 (default) = where that walk would end in a partly filled round the persistent
  * blocks share that round granule by granule, a cut tile block is finished by whichever of its pieces arrives last (a fixed order of adds:
- * deterministic; rounding as for a K split;
- * off with wino_split = 1 or wino_persistent = 0; 2 = wherever it applies, whatever the cost model says; 0 = never). Unknown names fail. */
+ * deterministic; rounding as for a K split; like "conv_tail_split" it makes the last bits of a pair's result depend on the pair's place in
+ * the batch — which tile blocks are cut does —, never its 1e-5-of-range bound; on by default since it is worth +1 % of the loop where the
+ * direct kernels' tail split was not; off with wino_split = 1 or wino_persistent = 0; 2 = wherever it applies, whatever the cost model
+ * says; 0 = never: permuting the pairs of a batch then permutes the results bit for bit). "conv_fewout_quad": 1 (default) = the 3x3
+ * stride-1 pad-1 convolutions with Cout <= 4 and W % 4 == 0 (flow / mask predictors) compute four pixels per lane, 0 = one. Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */
