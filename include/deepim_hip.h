@@ -324,8 +324,10 @@ int deepim_conv_wino_preferred_s2d(deepim_ctx* ctx, int B, int Cin, int H, int W
  * arguments as deepim_conv2d_wino_forward sees them (s2d = 1: Cin, H, W of the space-to-depth problem). plan[0] block shape (0 = 64
  * channels x 64 tiles, 1 = 128 x 32, 2 = 64 x 32 on four waves), [1] grid, [2] K slices S, [3] K steps per slice, [4] stream-K granules
  * per tile block (0 = off: whole tile blocks per block), [5] granules of the last round per persistent block, [6] whole tile blocks
- * per persistent block before them. All -1 where another kernel runs the layer. */
-int deepim_conv_wino_plan(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int out_nc8, int s2d, int* plan /*7, host*/);
+ * per persistent block before them, [7] tile blocks of the layer (incl. the padding of the XCD deal), [8] the first so many blocks of an
+ * XCD take one granule more. All -1 where another kernel runs the layer. Host arithmetic only: ctx = NULL asks for the plan under
+ * the default options (no device needed). */
+int deepim_conv_wino_plan(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int out_nc8, int s2d, int* plan /*9, host*/);
 int deepim_conv_wino_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w /*Cout,Cin,3,3 dev*/, int Cout, int Cin);
 /* The 5x5 stride-2 pad-2 layers (conv2 / conv3, deepIM_flownet.py:65-68) on the same kernel: a stride-2 convolution is a stride-1
  * convolution over the four input phases (x[2m + py][2l + px] as channel (py*2+px)*Cin + c of a (4 Cin, H/2, W/2) tensor) with the

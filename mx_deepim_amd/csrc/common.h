@@ -135,6 +135,7 @@ void deepim_set_error_msg(const char* msg);
 // fill pass of the box_rendered rectangle from accumulated bbox words (csrc/flow.hip)
 int deepim_mask_box_fill(deepim_ctx* ctx, float* box, const int* words, int B, int H, int W);
 
+void deepim_ctx_default_options(deepim_ctx* c);
 // Grow-only scratch; never reallocated while a graph capture is open.
 int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out);
 

@@ -18,21 +18,9 @@ extern "C" int deepim_device_count(int* n) {
   return 0;
 }
 
-extern "C" int deepim_create(int device_id, deepim_ctx** out) {
-  DI_REQUIRE(out != nullptr, "deepim_create: out is NULL");
-  int n = 0;
-  DI_CHECK(hipGetDeviceCount(&n));
-  DI_REQUIRE(device_id >= 0 && device_id < n, "deepim_create: no such device");
-  DI_CHECK(hipSetDevice(device_id));
-  deepim_ctx* c = new deepim_ctx();
-  c->device = device_id;
-  c->scratch = nullptr;
-  c->scratch_bytes = 0;
+// The option defaults of a fresh context (also what the host-arithmetic queries — deepim_conv_wino_plan — assume without a context)
+void deepim_ctx_default_options(deepim_ctx* c) {
   c->capturing = false;
-  c->sync_event = nullptr;
-  c->comm = nullptr;
-  c->comm_rank = 0;
-  c->comm_world = 1;
   c->conv_max_split = 0;
   c->conv_xcd_swizzle = 1;
   c->f16_dev_flags = 0;
@@ -54,6 +42,24 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
   c->fc_slices = 0;
   c->conv_tail_split = 0;
   c->conv_tile256 = 0;   // measured: 113.1 vs 113.7 TF for 128x128 — kept as an option, off by default
+}
+
+extern "C" int deepim_create(int device_id, deepim_ctx** out) {
+  DI_REQUIRE(out != nullptr, "deepim_create: out is NULL");
+  int n = 0;
+  DI_CHECK(hipGetDeviceCount(&n));
+  DI_REQUIRE(device_id >= 0 && device_id < n, "deepim_create: no such device");
+  DI_CHECK(hipSetDevice(device_id));
+  deepim_ctx* c = new deepim_ctx();
+  c->device = device_id;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  c->capturing = false;
+  c->sync_event = nullptr;
+  c->comm = nullptr;
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  deepim_ctx_default_options(c);
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     deepim_set_error("hipStreamCreate", e);

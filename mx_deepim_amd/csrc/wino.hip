@@ -1286,7 +1286,7 @@ extern "C" int deepim_conv_wino_pack_weights_s2d(deepim_ctx* ctx, float* packed_
 static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias, int B, int Cin,
                              int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff, bool s2d,
                              int* plan_only = nullptr) {
-  DI_DEVICE(ctx);
+  if (!plan_only) DI_DEVICE(ctx);      // (the plan is host arithmetic)
   DI_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d_wino_forward: bad shape");
   DI_REQUIRE((Cout & 31) == 0 && (Cin & 7) == 0, "conv2d_wino_forward: Cout % 32 == 0 and Cin % 8 == 0 required");
   if (B == 0) return 0;
@@ -1364,8 +1364,8 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
         p.sk_count = (int*)ctx->wino_counters;
       }
     }
-    if (plan_only) {   // {block shape 0 / 1 wide / 2 four-wave, grid, K slices, K steps per slice, stream-K granules per tile block (0: off), granules per run, whole tile blocks per block before the run}
-      plan_only[0] = half ? 2 : wide ? 1 : 0; plan_only[1] = grid; plan_only[2] = S; plan_only[3] = ks; plan_only[4] = p.sk_G; plan_only[5] = p.sk_q; plan_only[6] = p.sk_F;
+    if (plan_only) {   // {block shape 0 / 1 wide / 2 four-wave, grid, K slices, K steps per slice, stream-K granules per tile block (0: off), granules per run, whole tile blocks per block before the run, tile blocks of the layer (incl. the padding of the XCD deal), runs that are one granule longer}
+      plan_only[0] = half ? 2 : wide ? 1 : 0; plan_only[1] = grid; plan_only[2] = S; plan_only[3] = ks; plan_only[4] = p.sk_G; plan_only[5] = p.sk_q; plan_only[6] = p.sk_F; plan_only[7] = p.grid0; plan_only[8] = p.sk_rem;
       return 0;
     }
 #define W8_LAUNCH(O, S)                                                                               \
@@ -1425,7 +1425,9 @@ extern "C" int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const
 // wino_forward_impl sees them) under the context's options; plan[6] as documented at the fill site. -1 where that kernel is not used.
 extern "C" int deepim_conv_wino_plan(deepim_ctx* ctx, int B, int Cin, int H, int W, int Cout, int out_nc8, int s2d, int* plan) {
   DI_REQUIRE(plan != nullptr, "conv_wino_plan: null plan");
-  for (int i = 0; i < 7; ++i) plan[i] = -1;
+  for (int i = 0; i < 9; ++i) plan[i] = -1;
+  deepim_ctx defaults;                 // ctx == NULL: the plan under the default options (no device involved)
+  if (!ctx) { deepim_ctx_default_options(&defaults); ctx = &defaults; }
   return wino_forward_impl(ctx, nullptr, nullptr, nullptr, nullptr, B, Cin, H, W, Cout, 0.f, out_nc8, 0, 0, s2d != 0, plan);
 }
 

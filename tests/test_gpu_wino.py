@@ -161,7 +161,7 @@ def test_wino_argument_checks(ctx):
     lib.deepim_conv2d_wino_forward(ctx.handle, d, d, d, None, 0, 8, 2, 2, 32, cf(0.1), 1, 0, 0)      # empty batch: no launch
 
 def _plan(ctx, B, cin, H, W, cout, out_nc8, s2d):
-    plan = (ctypes.c_int * 7)()
+    plan = (ctypes.c_int * 9)()
     assert lib.load().deepim_conv_wino_plan(ctx.handle, B, cin, H, W, cout, out_nc8, s2d, plan) == 0
     return list(plan)
 

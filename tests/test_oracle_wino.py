@@ -97,3 +97,91 @@ def test_f4x4_3x3_in_float32_misses_the_layer_bar():
     assert errs[256][0] < 2e-6 and errs[512][0] < 2e-6            # F(2x2): a comfortable factor inside the bar
     assert errs[256][1] > 5e-6 and errs[512][1] > 1e-5            # F(4x4): at the bar / over it
     assert errs[512][1] > 10 * errs[512][0]
+
+
+def _wino_plan(B, cin, H, W, cout, out_nc8=1, s2d=0):
+    from mx_deepim_amd.runtime import lib
+    plan = (ctypes.c_int * 9)()
+    assert lib.load().deepim_conv_wino_plan(None, B, cin, H, W, cout, out_nc8, s2d, plan) == 0      # host arithmetic: no context, no device
+    return list(plan)
+
+
+# the encoder's Winograd layers as the kernel sees them (the 5x5 stride-2 ones over their space-to-depth input): name -> (Cin, H, W, Cout, out_nc8, s2d)
+_WINO_LAYERS = {"conv2": (256, 120, 160, 128, 3, 1), "conv3": (512, 60, 80, 256, 1, 1), "conv3_1": (256, 60, 80, 256, 3, 0),
+                "conv4_1": (512, 30, 40, 512, 1, 0), "conv5_1": (512, 15, 20, 512, 1, 0), "conv6_1": (1024, 8, 10, 1024, 0, 0)}
+
+
+def test_launch_plans_of_the_encoder_layers():
+    """deepim_conv_wino_plan under the default options: block shape, K split and stream-K per layer and batch size — what
+    profiles/r05_winograd.md and DESIGN section 3 describe (wide persistent blocks and stream-K of the last round on the long grids,
+    four-wave blocks + K split on the short ones, no stream-K into an NCHW output or with fewer than two whole rounds)."""
+    p32 = {n: _wino_plan(32, *g) for n, g in _WINO_LAYERS.items()}
+    assert [p32[n][0] for n in ("conv2", "conv3", "conv3_1", "conv4_1", "conv5_1", "conv6_1")] == [1, 1, 1, 1, 2, 2]
+    assert all(p32[n][1] == 256 for n in ("conv2", "conv3", "conv3_1", "conv4_1")) and p32["conv5_1"][1] == 512      # persistent grids
+    assert p32["conv3"][4:7] == [8, 3, 9] and p32["conv3_1"][4:7] == [16, 6, 9] and p32["conv4_1"][4:7] == [32, 22, 4]   # 9.375 / 4.69 rounds
+    assert p32["conv2"][4] == 0                                   # 18.75 rounds: the cut would save less than its pieces cost
+    assert p32["conv5_1"][2] == 2 and p32["conv6_1"][2] == 3 and p32["conv6_1"][4] == 0
+    for B in (16, 8, 4):
+        for n, g in _WINO_LAYERS.items():
+            pl = _wino_plan(B, *g)
+            assert pl[0] in (1, 2) and pl[1] in (256, 480, 512), (B, n, pl)
+            assert pl[4] == 0 or (pl[6] >= 2 and pl[2] == 1), (B, n, pl)          # stream-K: from two whole rounds on, never with a K split
+    assert _wino_plan(2, 256, 60, 80, 96) == [-1] * 9             # Cout % 64 != 0: the one-wave kernel, no plan of this kind
+
+
+def _streamk_pieces(plan, slots):
+    """The piece walk of conv_wino8_kernel's persistent blocks (w8_iter_next / w8_run_owner in csrc/wino.hip), restated."""
+    _, _, _, ks, G, q, F, grid0, rem = plan
+    nlb = slots // 8
+
+    def owner(u):
+        big = rem * (q + 1)
+        return u // (q + 1) if u < big else rem + (u - big) // q
+    out = []
+    for b in range(slots):
+        lb, xcd = b >> 3, b & 7
+        u = lb * q + min(lb, rem)
+        uend = u + q + (1 if lb < rem else 0)
+        mine = [((vb * nlb + lb) * 8 + xcd, 0, G, -1, 0) for vb in range(F)]
+        while u < uend:
+            lt = u // G
+            g0 = u - lt * G
+            g1 = min(G, g0 + uend - u)
+            o0, o1 = owner(lt * G), owner(lt * G + G - 1)
+            npieces = o1 - o0 + 1
+            mine.append(((F * nlb + lt) * 8 + xcd, g0, g1, -1 if npieces == 1 else lb - o0, 0 if npieces == 1 else npieces))
+            u += g1 - g0
+        out.append(mine)
+    return out
+
+
+@pytest.mark.parametrize("B", [32, 16, 8, 4])
+def test_stream_k_piece_walk_covers_every_granule_once(B):
+    """Every (tile block, granule) of a stream-K layer is computed by exactly one piece; the pieces of a cut tile block carry the copy
+    numbers 0 … n-1 in K order and all know n (the arrival counter's target); no tile block is cut into more copies than the scratch
+    holds; no block walks more than its whole rounds + three pieces."""
+    seen_any = False
+    for name, g in _WINO_LAYERS.items():
+        plan = _wino_plan(B, *g)
+        G, q, F, grid0 = plan[4], plan[5], plan[6], plan[7]
+        if G == 0:
+            continue
+        seen_any = True
+        slots = plan[1]
+        assert grid0 % 8 == 0 and slots in (256, 512)
+        tiles = {}
+        for blk in _streamk_pieces(plan, slots):
+            assert len(blk) <= F + 3
+            for bid, g0, g1, copy, npieces in blk:
+                assert 0 <= bid < grid0 and 0 <= g0 < g1 <= G
+                tiles.setdefault(bid, []).append((g0, g1, copy, npieces))
+        assert sorted(tiles) == list(range(grid0)), name           # every tile block, padding included
+        for bid, ps in tiles.items():
+            ps.sort()
+            assert ps[0][0] == 0 and ps[-1][1] == G and all(a[1] == b[0] for a, b in zip(ps, ps[1:])), (name, bid, ps)
+            if len(ps) == 1:
+                assert ps[0][2:] == (-1, 0)
+            else:
+                assert [c for _, _, c, _ in ps] == list(range(len(ps))) and {n for *_, n in ps} == {len(ps)}, (name, bid, ps)
+                assert len(ps) <= -(-G // q) + 1 <= 8
+    assert seen_any or B == 4
