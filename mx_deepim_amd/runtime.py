@@ -166,7 +166,22 @@ class Context:
                 cls._default_id = max(0, int(v))
             except ValueError:
                 cls._default_id = 0
+            # launchers that mask the GPUs per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, SLURM --gpus-per-task) leave every
+            # rank ONE visible device and LOCAL_RANK > 0: fold the rank onto the visible devices, as bench.py does
+            n = cls.visible_devices()
+            if n > 0 and cls._default_id >= n and "DEEPIM_DEVICE" not in os.environ:
+                cls._default_id %= n
         return cls._default_id
+
+    @staticmethod
+    def visible_devices():
+        """hipGetDeviceCount through the library; 0 without a GPU or without the library (nothing is created)."""
+        try:
+            n = ctypes.c_int(0)
+            lib.load().deepim_device_count(ctypes.byref(n))
+            return int(n.value)
+        except Exception:       # noqa: BLE001
+            return 0
 
     @classmethod
     def set_default(cls, device_id):

@@ -26,12 +26,18 @@ def test_bench_line_single_gpu():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
                         "--verify", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096, len(last)          # the compact line the driver parses; detail in bench_detail.json
+    d = json.loads(last)
+    assert d == _last_json(r.stdout)
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "pose-refinement iters/sec" and d["dtype"] == "f32" and d["scaling"] == "strong"
-    assert d["comm"]["backend"] == "none" and d["comm"]["rccl_ranks"] == 0 and "libamdhip64" in d["comm"]["libamdhip64_path"]
+    assert d["comm"]["backend"] == "none" and d["comm"]["rccl_ranks"] == 0
+    full = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    assert "libamdhip64" in full["comm"]["libamdhip64_path"] and full["value"] == pytest.approx(d["value"], rel=1e-5)
+    assert 0 < d["roofline"]["dominant_frac"] < 1 and len(full["roofline"]["layers_live"]) == 10
     assert abs(d["value"] - 2 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
@@ -45,7 +51,7 @@ def test_bench_reports_parity_of_the_timed_configuration(extra, bar):
     sampled pairs replayed through the CPU oracle.  Bars: pose and se3 <= 1e-4 relative, zoom factors / crop indices /
     net input bit-exact."""
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
-                        "--verify", "2"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                        "--full", "--verify", "2"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     p = d["parity"]
@@ -62,7 +68,7 @@ def test_bench_parity_heads_and_config5_modes():
     written (`--fp16 --depth`: RGB-D input, against the oracle's fp16 emulation, bars 1e-4 / 1e-3)."""
     for extra in (["--heads", "--batch", "4"], ["--fp16", "--depth", "--batch", "8"]):
         r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
-                            "--verify", "1"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                            "--full", "--verify", "1"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stderr[-2000:]
         d = _last_json(r.stdout)
         p = d["parity"]
@@ -104,7 +110,7 @@ def _run_two_ranks(port, extra):
     env = dict(os.environ, DEEPIM_BENCH_BACKEND="host", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "1",
-                        "--warmup", "1"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+                        "--warmup", "1", "--full"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     return _last_json(r.stdout)
 
@@ -145,7 +151,7 @@ def test_bench_two_ranks_default_backend_agrees_on_the_rendezvous_fallback():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("DEEPIM_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29679", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4", "--no-other-configs"]
+           "--master-port", "29679", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4", "--no-other-configs", "--full"]
     if ndev.value < 2:
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
         assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.stdout[-1500:], r.stderr[-1500:])

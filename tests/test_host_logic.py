@@ -317,7 +317,7 @@ def test_eight_rank_launch_rehearsal(global_batch, counts):
     global_batch = global_batch or 32
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--dry-run"] + extra, cwd=root, capture_output=True, text=True, timeout=900,
+                        "--dry-run", "--full"] + extra, cwd=root, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -349,6 +349,18 @@ def test_default_context_follows_local_rank(monkeypatch):
             monkeypatch.setenv(k, v)
         monkeypatch.setattr(Context, "_default_id", None)
         assert Context.default_device_id() == want
+    # launchers that mask the GPUs per rank (one visible device, LOCAL_RANK = 5): the rank folds onto the visible devices instead of
+    # failing in deepim_create with 'no such device' (ADVICE r5); an explicit DEEPIM_DEVICE is taken as written
+    for ndev, env, want in ((1, {"LOCAL_RANK": "5"}, 0), (4, {"LOCAL_RANK": "5"}, 1), (8, {"LOCAL_RANK": "5"}, 5),
+                            (1, {"LOCAL_RANK": "5", "DEEPIM_DEVICE": "2"}, 2)):
+        monkeypatch.delenv("LOCAL_RANK", raising=False)
+        monkeypatch.delenv("DEEPIM_DEVICE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setattr(Context, "_default_id", None)
+        monkeypatch.setattr(Context, "visible_devices", staticmethod(lambda n=ndev: n))
+        assert Context.default_device_id() == want, (ndev, env)
+    monkeypatch.undo()
     monkeypatch.setattr(Context, "_default_id", None)
     Context.set_default(3)
     assert Context.default_device_id() == 3
@@ -449,6 +461,50 @@ def test_cpu_baseline_follows_the_stated_protocol():
     assert r["value"] > c["value"]            # the library convolutions beat the one-chain-per-output checker build
     from oracle import net as onet
     assert onet.BLOCKED is False            # the timing switch is reset: the checker stays the checker
+
+
+def test_bench_final_line_is_compact_and_parseable():
+    """the driver parses the LAST stdout line; round 5's 22.8 KB line (lists of dicts) came back `parsed: null`. The
+    final line is now `compact_line(record)`: < 4 KB, scalars and short strings only, with the contract's keys, `roofline.frac` and
+    `cpu_baseline.value`; the full record goes to bench_detail.json. Checked on round 5's own full record and end to end on a dry run."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = [l for l in open(os.path.join(root, "profiles", "r05_bench_default_n1.json.log")).read().splitlines() if l.startswith("{")][-1]
+    assert len(full) > 20000
+    rec = json.loads(full)
+    rec["roofline"].update(layers_live=[{"layer": "conv2", "kernel": "k", "ms": 1.0, "tflops": 200.0, "tflops_executed": 120.0, "frac": 0.76}],
+                           dominant_kernel="k (conv2)", dominant_ms=1.0, dominant_achieved=120.0, dominant_frac=0.76)
+    line = bench.compact_line(rec)
+    assert len(line) < 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "comm"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(rec["value"], rel=1e-5) and d["roofline"]["frac"] == pytest.approx(rec["roofline"]["frac"], rel=1e-5)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 128 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["pairs"] == "2 of 32" and d["parity"]["within_bar"] is True
+    assert d["roofline"]["dominant_frac"] == 0.76 and "per_kernel" not in d["roofline"] and "other_configs" not in d
+
+    def flat(v):
+        if isinstance(v, dict):
+            for x in v.values():
+                yield from flat(x)
+        else:
+            yield v
+    for v in flat(d):        # no lists of dicts, no string the driver's 128-character clip would cut
+        assert not (isinstance(v, list) and any(isinstance(x, (dict, list)) for x in v))
+        assert not isinstance(v, str) or len(v) <= 120
+    rows = bench.detail_lines(rec)
+    assert rows and all(r.startswith("# ") for r in rows) and any("configs[2]_per_gpu_share_batch4" in r for r in rows)
+    # end to end: the default output of a (dry) run ends in exactly that kind of line
+    r = subprocess.run([sys.executable, "bench.py", "--dry-run", "--steps", "2", "--warmup", "1"], cwd=root, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096 and json.loads(last)["dry_run"] is True
 
 
 def test_bench_roofline_block_is_physical(tmp_path):
