@@ -170,6 +170,8 @@ def cpu_baseline(params, cfg, batch, budget_s=20.0, with_depth=False, min_runs=5
                "n_group_share_of_time": conv_per_call / (float(np.mean(times + [warm]))),
                "protocol": "BASELINE.md section 3: 1 untimed warm-up call, then %d timed calls of %d pair-iterations; value = pairs / median" % (len(times), pairs),
                "seconds_per_call": {"median": med, "min": float(min(times)), "max": float(max(times)), "warmup": warm},
+               "sample_short": "%d calls x %d pair-iterations (480x640, FAST_TEST) in %.1f s: numpy zoom + oneDNN conv/fc + oracle pose update"
+                               % (len(times), pairs, float(sum(times))),
                "sample": "%d timed calls x %d pair-iterations (480x640, FAST_TEST graph: BASELINE config 1's unit of work) in %.1f s on pairs of "
                          "the same synthetic workload: oracle zoom front end (numpy, one pair per host thread) -> 10 convolutions + fc head on oneDNN (torch-CPU %s, this "
                          "run's weights) -> oracle inverse ZoomTrans + RT_transform; %d threads = the physical cores"
@@ -369,6 +371,8 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "threads", "kind", "sample", "skipped"))
+        if "sample_short" in cb:
+            c["cpu_baseline"]["sample"] = cb["sample_short"]
     pa = out.get("parity")
     if pa:
         c["parity"] = _pick(pa, ("pose_max_rel", "se3_max_rel", "flow_max_rel", "mask_flip_frac", "zoom_idx_bit_exact",
@@ -393,6 +397,9 @@ def compact_line(out):
             return _r(v)
         return v
     c = walk(c)
+    for k in ("value", "ms_per_step"):      # the two the driver cross-checks against its own clock: as measured
+        if k in out:
+            c[k] = out[k]
     line = json.dumps(c, separators=(",", ":"))
     assert len(line) < LINE_LIMIT, len(line)
     return line
@@ -583,12 +590,16 @@ class Loop(object):
         # iteration — every event record costs the stream ~5 µs (profiles/r03_heads_b4_iteration_trace.txt: the gaps sit exactly at
         # the records), which is 1-2 % of a B = 4 iteration with six of them. The front end, the re-render and the pose gather are
         # timed by the same events over AUX_STEPS extra steps right after the timed region.
-        self.enc_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(steps)]
+        self.enc_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(max(steps, self.AUX_STEPS))]
         self.zoom_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(self.AUX_STEPS)]
         self.render_timers = [[ctx.timer() for _ in range(NIT - 1)] for _ in range(self.AUX_STEPS)]
         self.gather_timers = [[ctx.timer() for _ in range(NIT)] for _ in range(self.AUX_STEPS)] if world > 1 else None
         self.use_graph = args.graph == "on"
         self.enc_graph = None
+        # "step": the whole step as hipGraph segments (auto: where the launches are short enough for the host gaps and the event records
+        # to show — per-GPU batches <= 8, the shards of an 8- / 4-GPU run; not with the host-side TCP exchange, which syncs anyway)
+        self.graph_step = (args.graph == "step" or (args.graph == "auto" and B <= 8)) and (world == 1 or comm is not None)
+        self.step_graphs, self._capturing = None, None
 
     def run_encoder(self):
         if self.enc_graph is not None:
@@ -597,6 +608,8 @@ class Loop(object):
             self.net.encoder()
 
     def step(self, timers=None, ztimers=None, rtimers=None, gtimers=None, tap=None):
+        if self.step_graphs is not None and not (timers or ztimers or rtimers or gtimers or tap):
+            return self.replay_step()
         args, net, h, NIT, B, Bmax = self.args, self.net, self.ctx.handle, self.NIT, self.B, self.Bmax
         pose_cur = self.pose_cur
         lib.deepim_d2d(h, pose_cur, self.pose_init, pose_cur.nbytes)
@@ -604,6 +617,7 @@ class Loop(object):
         if args.depth:
             data["depth_observed"] = self.depth_observed
         data.update(self.frames[0])
+        cap = self._capturing
         for it in range(NIT):
             if args.prestaged:
                 data.update(self.frames[it])
@@ -626,19 +640,11 @@ class Loop(object):
             if tap is not None:
                 tap("out", it, data)
             if self.world > 1:                     # every rank/host gets all refined poses
-                src = pose_cur
-                if B != Bmax:
-                    lib.deepim_d2d(h, self.gather_in, pose_cur, pose_cur.nbytes)
-                    src = self.gather_in
-                if gtimers:
-                    gtimers[it].start()
-                if self.comm is not None:          # one enqueue on the library's stream, no host sync
-                    self.comm.all_gather_poses(self.gather_out, src)
-                else:                              # host path: same exchange through the TCP rendezvous
-                    parts = self.rdzv.all_gather(src.asnumpy())
-                    self.gather_out.copyfrom(np.concatenate(parts, 0))
-                if gtimers:
-                    gtimers[it].stop()
+                if cap is not None:                # graph capture: the exchange stays a direct enqueue BETWEEN two graph segments
+                    cap("cut")
+                self.exchange(gtimers[it] if gtimers else None)
+                if cap is not None:
+                    cap("resume")
             if it < NIT - 1 and not args.prestaged:
                 if rtimers:
                     rtimers[it].start()
@@ -646,6 +652,60 @@ class Loop(object):
                                          light_intensity=self.light[it] if self.light else None)
                 if rtimers:
                     rtimers[it].stop()
+
+    def exchange(self, gtimer=None):
+        """The per-iteration pose all-gather: ONE ncclAllGather enqueued on the library's stream (ragged shards pad to the largest)."""
+        h, B, Bmax, pose_cur = self.ctx.handle, self.B, self.Bmax, self.pose_cur
+        src = pose_cur
+        if B != Bmax:
+            lib.deepim_d2d(h, self.gather_in, pose_cur, pose_cur.nbytes)
+            src = self.gather_in
+        if gtimer:
+            gtimer.start()
+        if self.comm is not None:          # one enqueue on the library's stream, no host sync
+            self.comm.all_gather_poses(self.gather_out, src)
+        else:                              # host path: same exchange through the TCP rendezvous
+            parts = self.rdzv.all_gather(src.asnumpy())
+            self.gather_out.copyfrom(np.concatenate(parts, 0))
+        if gtimer:
+            gtimer.stop()
+
+    def capture_step(self):
+        """Record one whole step — pose reset, and per iteration front end, encoder, [decoder + heads], pose head + update, re-render +
+        mask update — into hipGraph segments: ONE graph at N = 1; at N > 1 the segments between the pose exchanges (the all-gather is
+        enqueued directly between two replays). Every buffer is bound once (bind()), so the graphs replay on the same memory."""
+        h = self.ctx.handle
+        graphs = []
+
+        def begin():
+            lib.deepim_graph_begin(h)
+
+        def end():
+            gid = ctypes.c_int(-1)
+            lib.deepim_graph_end(h, ctypes.byref(gid))
+            graphs.append(gid.value)
+
+        def cap(what):
+            if what == "cut":
+                end()
+            else:
+                begin()
+        self.ctx.sync()
+        self._capturing = cap
+        begin()
+        try:
+            self.step()
+        finally:
+            self._capturing = None
+            end()
+        self.step_graphs = graphs
+
+    def replay_step(self):
+        h, g = self.ctx.handle, self.step_graphs
+        lib.deepim_graph_launch(h, g[0])
+        for gid in g[1:]:
+            self.exchange()
+            lib.deepim_graph_launch(h, gid)
 
     def fence(self):          # device idle on every rank, then a barrier, then nothing pending before the clock is read
         self.ctx.sync()
@@ -666,16 +726,25 @@ class Loop(object):
                 lib.deepim_graph_end(h, ctypes.byref(gid))
             self.enc_graph = gid.value
             self.step()
+        if self.graph_step:
+            try:
+                self.capture_step()
+            except Exception as e:      # noqa: BLE001 — a launch that cannot be captured: say so, time direct launches
+                sys.stderr.write("[bench] whole-step graph capture failed (%s): direct launches\n" % (repr(e)[:200],))
+                self.step_graphs = None
+                ctx.sync()
+            self.step()
         for _ in range(warmup):
             self.step()
         self.fence()
         t0 = time.perf_counter()
         for s_ in range(self.steps):
-            self.step(self.enc_timers[s_])
+            self.step(None if self.step_graphs else self.enc_timers[s_])
         self.fence()
         dt = time.perf_counter() - t0
         for s_ in range(self.AUX_STEPS):          # outside the timed region: front end / re-render / pose gather, by HIP events
-            self.step(None, self.zoom_timers[s_], self.render_timers[s_], self.gather_timers[s_] if self.gather_timers else None)
+            self.step(self.enc_timers[s_] if self.step_graphs else None, self.zoom_timers[s_], self.render_timers[s_],
+                      self.gather_timers[s_] if self.gather_timers else None)
         self.fence()
         if self.world > 1:
             dt_local = dt
@@ -694,7 +763,7 @@ class Loop(object):
 
     def means(self):
         m = lambda rows: float(np.mean([t.elapsed_ms() for row in rows for t in row])) if rows and rows[0] else None   # noqa: E731
-        return {"enc_ms": m(self.enc_timers), "zoom_ms": m(self.zoom_timers), "render_ms": m(self.render_timers),
+        return {"enc_ms": m(self.enc_timers[:self.AUX_STEPS] if self.step_graphs else self.enc_timers[:self.steps]), "zoom_ms": m(self.zoom_timers), "render_ms": m(self.render_timers),
                 "gather_ms": m(self.gather_timers) if self.gather_timers else None}
 
 
@@ -739,7 +808,11 @@ def main():
     ap.add_argument("--lit", choices=("auto", "on", "off"), default="auto", help="re-render between the iterations with the lit render "
                     "machine of the reference's ModelNet loops (render_py_light_modelnet_multi.py: per-fragment diffuse term); auto = on "
                     "for BASELINE config 5 as written (--fp16 --depth), off otherwise (LINEMOD loops draw unlit texture)")
-    ap.add_argument("--graph", choices=("on", "off"), default="off", help="replay the encoder's launches (10 convs + split-K "
+    ap.add_argument("--graph", choices=("auto", "step", "on", "off"), default="off", help="step: the WHOLE step (pose reset, 4 x (front end, "
+                    "encoder, pose head + update, re-render)) replayed from hipGraph segments — one graph at N = 1, cut at the pose exchanges at "
+                    "N > 1; the conv group's HIP-event time then comes from 3 direct-launch steps right after the timed region. auto: "
+                    "step for per-GPU batches <= 8, off above. off (default; measured in round 6, profiles/r06_b4_share.md: 3 425 vs 3 417 it/s at "
+                    "B = 4 — the queue stays ahead of the GPU either way). on: replay the encoder's launches (10 convs + split-K "
                     "second passes + layout passes) from one captured hipGraph instead of issuing them one by one. Measured "
                     "(profiles/r03_fp16_config5.md): no gain at B = 8 / B = 4 — the kernel trace shows no idle gaps between the "
                     "encoder's launches, the queue stays ahead of the GPU — so direct launches stay the default")
@@ -862,8 +935,8 @@ def main():
                 traffic, traffic_src = tj["conv_launch_group_bytes_corrected"], tj["source"]
         kname = ("encoder conv group: conv_f16_pp/dma_kernel + conv1 patch kernel (fp16 MFMA, fp32 accumulate)" if args.fp16 else
                  "encoder conv group: conv_f16_dma_kernel<X3> (3 fp16 MFMAs per product; peak = 2.5 PF / 3) + conv1_x3_kernel" if args.x3 else
-                 "encoder conv group (10 layers, fp32 MFMA): conv_direct_kernel, conv_nc8_kernel" +
-                 (", conv_wino8/4_kernel (F(2x2,3x3): %d layers)" % len(wino_layers) if wino_layers else ""))
+                 "encoder conv group, 10 layers, fp32 MFMA: conv_direct, conv_nc8" +
+                 (", conv_wino8/4 (F(2x2,3x3): %d layers)" % len(wino_layers) if wino_layers else "") + " kernels")
         rl, rl_hbm = roofline_block(kname, flops, encoder_executed_flops_per_pair(net) * B, enc_ms, peak, wino_layers, traffic, traffic_src,
                                     os.path.join(ROOT, "profiles", "per_kernel.json"), B,
                                     plain=not (args.fp16 or args.x3 or args.heads or args.depth) and bool(wino_layers))
@@ -883,13 +956,13 @@ def main():
         out.update({
             "config": {"workload": "LINEMOD-ape-like synthetic pairs, bs%d (%s/GPU, %s), %d iters, 480x640, %s, %s, %s" % (
                            gbatch, "/".join(str(c_) for c_ in sorted(set(counts), reverse=True)), scaling, NIT,
-                           "decoder + mask/flow heads" if args.heads else "FAST_TEST graph",
+                           "decoder + mask/flow heads" if args.heads else "FAST_TEST",
                            "RGB-D 10-ch" if args.depth else "8-ch",
-                           "pre-staged frames" if args.prestaged else "closed loop, %s re-render on device" % ("lit" if args.lit else "unlit")),
+                           "pre-staged frames" if args.prestaged else "closed loop (%s GPU re-render)" % ("lit" if args.lit else "unlit")),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT, "shard_counts": counts,
-                       "encoder_launch": "hipGraph replay" if use_graph else "direct launches",
-                       "parallelism": ("%d process(es), one per GPU, contiguous pair blocks; one ncclAllGather (RCCL) of the refined poses "
-                                       "per iteration; no torch" % world) if comm_note is None
+                       "encoder_launch": "whole step from %d hipGraph segment(s)" % len(L.step_graphs) if L.step_graphs else
+                                         "hipGraph replay" if use_graph else "direct launches",
+                       "parallelism": ("%d process(es), one per GPU, contiguous pair blocks; one RCCL ncclAllGather of the poses per iteration" % world) if comm_note is None
                                       else "%d ranks; %s; poses through the TCP rendezvous" % (world, comm_note)},
             "roofline": rl,
             "roofline_zoom": {"bound": "hbm", "kernel": "bbox + zoom_factor + resample (fused front end)",

@@ -77,7 +77,12 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * deterministic; rounding as for a K split; like "conv_tail_split" it makes the last bits of a pair's result depend on the pair's place in
  * the batch — which tile blocks are cut does —, never its 1e-5-of-range bound; on by default since it is worth +1 % of the loop where the
  * direct kernels' tail split was not; off with wino_split = 1 or wino_persistent = 0; 2 = wherever it applies, whatever the cost model
- * says; 0 = never: permuting the pairs of a batch then permutes the results bit for bit). "conv_fewout_quad": 1 (default) = the 3x3
+ * says; 0 = never: permuting the pairs of a batch then permutes the results bit for bit). "wino_fin": 1 = a layer split over
+ * the input channels is finished inside the kernel — the block whose slice of a tile block arrives last adds the raw copies in slice order,
+ * the bias and the activation: the second pass's sums bit for bit, without its launch —, 0 (default) = wino_reduce_kernel as a second pass
+ * (measured on MI355X, profiles/r06_b4_share.md: the lone finishing block's read-back is a serial tail that costs more than the parallel
+ * pass it replaces — conv6_1 at B = 4: 48 -> 129 us). The arrival counters of both in-kernel finishes (64 KB) are allocated by
+ * deepim_create: a layer's plan depends on geometry and options only, under graph capture as in eager runs. "conv_fewout_quad": 1 (default) = the 3x3
  * stride-1 pad-1 convolutions with Cout <= 4 and W % 4 == 0 (flow / mask predictors) compute four pixels per lane, 0 = one. Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <algorithm>
 #include "../../include/deepim_hip.h"
@@ -77,7 +78,9 @@ struct deepim_ctx {
   int conv_fewout_quad;  // 1 (default): the 3x3 stride-1 heads with W % 4 == 0 on the four-pixels-per-lane kernel; 0: one pixel per lane
   int wino_streamk;      // 1 (default): where a grid leaves a partly filled last round, the persistent blocks share the work granule by granule (stream-K; needs wino_persistent, off with wino_split = 1); 2: wherever it applies, whatever the cost model says; 0: never
   std::map<uintptr_t, size_t> allocs;   // deepim_malloc's live allocations (base -> bytes): deepim_d2d's residency test without a driver query
-  void* wino_counters;   // stream-K arrival counters, one per tile block (allocated on first use, zero between launches)
+  int wino_fin;          // 1: a K-split Winograd layer is finished inside the kernel by the block whose slice arrives last (no second pass); 0 (default): wino_reduce_kernel — the serial finish of the last slices costs more than the parallel second pass (profiles/r06_b4_share.md)
+  std::mutex allocs_mu;  // guards `allocs`: a DeviceArray finalizer on another Python thread may free while the main thread copies (ctypes drops the GIL)
+  void* wino_counters;   // arrival counters of the Winograd kernels' in-kernel finish, one per tile block (deepim_create; zero between launches)
   int wino_persistent;   // 1 (default): the shared-transform kernel's grid is one block per resident slot, each walking its share of the tiles; 0: one block per tile block
   int wino_two_wave;     // 0 (default): Winograd layers on the one-wave 16-position kernel; 1: the two-waves-per-SIMD kernel (measured slower on the big layers)
   int f16_dev_flags;     // dev: DI_F16_* bits — alternative tilings of the fp16 / x3 conv kernels (default 0)
@@ -91,6 +94,7 @@ static inline bool di_attr_needed(deepim_ctx* ctx, const void* tag) {
   return true;
 }
 
+#define DI_WINO_COUNTERS 16384   /* arrival counters per context (64 KB): tile blocks of one Winograd launch that can finish in-kernel */
 void deepim_set_error(const char* where, hipError_t e);
 void deepim_set_error_msg(const char* msg);
 

@@ -30,6 +30,7 @@ void deepim_ctx_default_options(deepim_ctx* c) {
   c->wino_shared = 1;
   c->wino_persistent = 1;
   c->wino_streamk = 1;
+  c->wino_fin = 0;   // measured slower than the second pass at every batch size (profiles/r06_b4_share.md)
   c->conv_fewout_quad = 1;
   c->wino_counters = nullptr;
   c->wino_split = 0;
@@ -80,7 +81,13 @@ extern "C" int deepim_create(int device_id, deepim_ctx** out) {
     for (size_t i = 0; i < init.size(); ++i) init[i] = (i & 1) ? -1 : INT_MAX;      // {minx,maxx,miny,maxy}: empty boxes
     e = hipMemcpy(c->zoom_box, init.data(), zbox_bytes, hipMemcpyHostToDevice);
   }
+  // arrival counters of the Winograd kernels' in-kernel finish (stream-K pieces, K slices): one word per tile block, zero between
+  // launches (the kernels leave them so). Allocated HERE so that a layer's plan is a function of geometry and options only
+  if (e == hipSuccess) e = hipMalloc(&c->wino_counters, (size_t)DI_WINO_COUNTERS * sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(c->wino_counters, 0, (size_t)DI_WINO_COUNTERS * sizeof(int), c->stream);
   if (e != hipSuccess) {
+    if (c->status) hipFree(c->status);
+    if (c->wino_counters) hipFree(c->wino_counters);
     deepim_set_error("hipMalloc(status)", e);
     hipStreamDestroy(c->stream);
     delete c;
@@ -130,6 +137,7 @@ int deepim_scratch(deepim_ctx* ctx, size_t bytes, void** out) {
 extern "C" int deepim_malloc(deepim_ctx* ctx, size_t bytes, void** dptr) {
   DI_DEVICE(ctx);
   DI_CHECK(hipMalloc(dptr, bytes ? bytes : 4));
+  std::lock_guard<std::mutex> lk(ctx->allocs_mu);
   ctx->allocs[(uintptr_t)*dptr] = bytes ? bytes : 4;
   return 0;
 }
@@ -137,8 +145,9 @@ extern "C" int deepim_free(deepim_ctx* ctx, void* dptr) {
   DI_DEVICE(ctx);
   if (!dptr) return 0;
   DI_CHECK(hipStreamSynchronize(ctx->stream));
+  DI_CHECK(hipFree(dptr));          // the table forgets the block only once the driver has (a failed free leaves it listed)
+  std::lock_guard<std::mutex> lk(ctx->allocs_mu);
   ctx->allocs.erase((uintptr_t)dptr);
-  DI_CHECK(hipFree(dptr));
   return 0;
 }
 extern "C" int deepim_memset(deepim_ctx* ctx, void* dptr, int value, size_t bytes) {
@@ -175,6 +184,7 @@ extern "C" int deepim_d2d(deepim_ctx* ctx, void* dst, const void* src, size_t by
   // first (deepim_malloc / deepim_free keep it: no driver call on the path this kernel exists to shorten); a pointer it does not
   // know is asked of the driver — never inside a stream capture, where an unknown pointer takes the memcpy node instead.
   auto mine = [&](const void* q, size_t n) {
+    std::lock_guard<std::mutex> lk(ctx->allocs_mu);
     auto it = ctx->allocs.upper_bound((uintptr_t)q);
     if (it == ctx->allocs.begin()) return false;
     --it;
@@ -225,6 +235,7 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "wino_two_wave") == 0) { ctx->wino_two_wave = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_persistent") == 0) { ctx->wino_persistent = value ? 1 : 0; return 0; }
   if (strcmp(name, "conv_fewout_quad") == 0) { ctx->conv_fewout_quad = value ? 1 : 0; return 0; }
+  if (strcmp(name, "wino_fin") == 0) { ctx->wino_fin = value != 0; return 0; }
   if (strcmp(name, "wino_streamk") == 0) { ctx->wino_streamk = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
   if (strcmp(name, "wino_split") == 0) { ctx->wino_split = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "wino_wide") == 0) { ctx->wino_wide = (value >= 0 && value <= 3) ? value : 1; return 0; }
@@ -246,7 +257,7 @@ extern "C" int deepim_get_option(deepim_ctx* ctx, const char* name, int* value) 
       {"conv_max_split", ctx->conv_max_split}, {"conv_direct", ctx->conv_direct}, {"fc_slices", ctx->fc_slices},
       {"conv_tail_split", ctx->conv_tail_split}, {"conv_force_plan", ctx->conv_force_plan}, {"conv_tail_slots", ctx->conv_tail_slots},
       {"conv_tile256", ctx->conv_tile256}, {"conv_autotune", ctx->conv_autotune}, {"dgrad_group", ctx->dgrad_group},
-      {"wgrad_lds", ctx->wgrad_lds}, {"wino_two_wave", ctx->wino_two_wave}, {"wino_shared", ctx->wino_shared}, {"wino_wide", ctx->wino_wide}, {"wino_split", ctx->wino_split}, {"wino_persistent", ctx->wino_persistent}, {"wino_streamk", ctx->wino_streamk}, {"conv_fewout_quad", ctx->conv_fewout_quad}, {"wino_s2d_skip", ctx->wino_s2d_skip}, {"f16_dev_flags", ctx->f16_dev_flags}, {"conv_xcd_swizzle", ctx->conv_xcd_swizzle}};
+      {"wgrad_lds", ctx->wgrad_lds}, {"wino_two_wave", ctx->wino_two_wave}, {"wino_shared", ctx->wino_shared}, {"wino_wide", ctx->wino_wide}, {"wino_split", ctx->wino_split}, {"wino_persistent", ctx->wino_persistent}, {"wino_streamk", ctx->wino_streamk}, {"wino_fin", ctx->wino_fin}, {"conv_fewout_quad", ctx->conv_fewout_quad}, {"wino_s2d_skip", ctx->wino_s2d_skip}, {"f16_dev_flags", ctx->f16_dev_flags}, {"conv_xcd_swizzle", ctx->conv_xcd_swizzle}};
   for (const auto& o : opts)
     if (strcmp(name, o.n) == 0) { *value = o.v; return 0; }
   deepim_set_error_msg("deepim_get_option: unknown option");

@@ -53,6 +53,7 @@ struct WinoParams {
   // order, the bias and the activation (a fixed order of fp32 adds: deterministic whatever the arrival order). Counters return to zero.
   int sk_G, sk_gran, sk_F, sk_q, sk_rem, sk_nlb;
   int* sk_count;
+  int fin_nchw, fin_ctotal, fin_coff;   // in-kernel finish of K slices whose output is NCHW (dense NCHW partials): the real channel slice of the output
 };
 
 #ifndef WINO_ABL
@@ -721,21 +722,22 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   }
 // column pass of row xi across the quad, IN PLACE: lane j holds t_j and needs (t0 - t2, t1 + t2, t2 - t1, t3 - t1)[j] (nu = 3 negated, as
 // packed) = self + sgn * T[lane (2, 2, 1, 1)[j]], sgn = (-1, +1, -1, -1): one v_fmac_f32 with a DPP quad_perm source per value.
-// s_nop 1: a DPP source written by the VALU instruction right before needs two wait states, and the hazard pass cannot see inside the asm
-#define W8_FMACD(t_)                                                                                  \
-  asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(t_) : "v"(sgn));
+// s_nop 1: a DPP source written by the VALU instruction right before needs two wait states, and the hazard pass cannot see inside the
+// asm — so the wait states and the DPP reads they protect are ONE asm statement (nothing can be scheduled between them)
+#define W8_DPPQ "quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
 #define W8_COL(xi, slot_)                                                                             \
   {                                                                                                   \
     if constexpr (WIDE) {                                                                             \
       float c0_ = T[xi].x, c1_ = T[xi].y;                                                             \
-      asm volatile("s_nop 1");                                                                        \
-      W8_FMACD(c0_) W8_FMACD(c1_)                                                                     \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 " W8_DPPQ "\n\tv_fmac_f32_dpp %1, %1, %2 " W8_DPPQ \
+                   : "+v"(c0_), "+v"(c1_) : "v"(sgn));                                                \
       f32x2 v_; v_.x = c0_; v_.y = c1_;                                                               \
       *reinterpret_cast<f32x2*>(smem + (vw + (unsigned)((slot_) * VSLOT + (xi) * 4 * QS))) = v_;      \
     } else {                                                                                          \
       float c0_ = T[xi][0], c1_ = T[xi][1], c2_ = T[xi][2 % (WIDE ? 2 : 4)], c3_ = T[xi][3 % (WIDE ? 2 : 4)]; \
-      asm volatile("s_nop 1");                                                                        \
-      W8_FMACD(c0_) W8_FMACD(c1_) W8_FMACD(c2_) W8_FMACD(c3_)                                         \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 " W8_DPPQ "\n\tv_fmac_f32_dpp %1, %1, %4 " W8_DPPQ \
+                   "\n\tv_fmac_f32_dpp %2, %2, %4 " W8_DPPQ "\n\tv_fmac_f32_dpp %3, %3, %4 " W8_DPPQ    \
+                   : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(c3_) : "v"(sgn));                          \
       f32x4 v_; v_.x = c0_; v_.y = c1_; v_.z = c2_; v_.w = c3_;                                       \
       W8_LDS4(vw + (unsigned)((slot_) * VSLOT + (xi) * 4 * QS)) = v_;                                 \
     }                                                                                                 \
@@ -882,7 +884,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
 #undef W8_RDA
 #undef W8_RDB
 #undef W8_COL
-#undef W8_FMACD
+#undef W8_DPPQ
 #undef W8_ROW
 #undef W8_PIX
 #undef W8_ACT
@@ -914,7 +916,7 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   float* const outp = copy >= 0 ? p.part + (long)copy * p.part_stride : p.out;
   const float* const biasp = copy >= 0 ? nullptr : p.bias;
   float slope_e = copy >= 0 ? 1.f : p.slope;
-  const bool through = copy >= 0 && p.sk_G > 0;
+  const bool through = copy >= 0 && p.sk_count != nullptr;   // a piece some block reads back inside this launch: straight to memory
   // channel-blocked output: 32-byte records addressed as the lane's base (its tile's first pixel in channel block mb*4) + a wave-uniform
   // scalar offset per (channel block, pixel) — no 64-bit address arithmetic per store (it was a third of this epilogue's vector work)
   const __amdgpu_buffer_rsrc_t rsrp = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, OUT_NC8 ? (int)p.out_bytes : 0, 0x00020000);
@@ -1021,6 +1023,29 @@ __device__ __forceinline__ void w8_finish_cut_tile_block(const WinoParams& p, ch
   int mb2, bx;
   w8_block_coords(p, bid, mb2, bx);
   const int tpi = p.TY * p.TX, c4n = CB >> 2;
+  if (p.fin_nchw) {            // dense NCHW partials (Cout channels each) -> channels [fin_coff, +Cout) of the fin_ctotal-channel output
+    const long hw = (long)p.H * p.W;
+    for (int i = threadIdx.x; i < TB * CB * 4; i += blockDim.x) {   // (channel, tile, pixel of its 2x2): pixels fastest
+      const int ab = i & 3, tl = (i >> 2) % TB, cl = (i >> 2) / TB;
+      const int t = bx * TB + tl;
+      if (t >= p.ntiles) continue;
+      const int n = t / tpi, tr = t - n * tpi;
+      const int ty = tr / p.TX, tx = tr - ty * p.TX;
+      const int y = 2 * ty + (ab >> 1), x = 2 * tx + (ab & 1);
+      if (y >= p.H || x >= p.W) continue;
+      const int c = mb2 * CB + cl;
+      const long src = ((long)n * p.Cout + c) * hw + (long)y * p.W + x;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.part, 0, (int)(p.part_stride * 4), 0x00020000);
+      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(src * 4), 0, 17));
+      for (int s_ = 1; s_ < npieces; ++s_) {
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (long)s_ * p.part_stride), 0, (int)(p.part_stride * 4), 0x00020000);
+        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (int)(src * 4), 0, 17));
+      }
+      v += p.bias ? p.bias[c] : 0.f;
+      p.out[((long)n * p.fin_ctotal + p.fin_coff + c) * hw + (long)y * p.W + x] = v > 0.f ? v : v * p.slope;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < TB * CB; i += blockDim.x) {     // (tile, pixel of its 2x2, 4 channels)
     const int c4 = i % c4n, ab = (i / c4n) & 3, tl = i / CB;
     const int t = bx * TB + tl;
@@ -1086,6 +1111,7 @@ __device__ __forceinline__ void w8_finish_cut_tile_block(const WinoParams& p, ch
         const int slice = __builtin_amdgcn_readfirstlane(v / p.grid0);                                \
         bid = v - slice * p.grid0; kb = slice * p.kslice; ke = min(p.Cin >> 3, kb + p.kslice);        \
         copy = p.ksplit > 1 ? slice : -1;                                                             \
+        if (p.ksplit > 1 && p.sk_count) npieces = p.ksplit;   /* K slices: the slice that arrives last sums them (no second pass) */ \
       }                                                                                               \
       BODY;                                                                                           \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the output exchange has been read: the slots are free for the next piece */ \
@@ -1172,7 +1198,7 @@ static int wino8_split_plan(long blocks, int nK, int step_granule, double out_mb
 // blocks. Same cost unit as wino8_split_plan (steps). Returns the granules per tile block, 0 where it does not apply: the XCD deal
 // needs grid % 8 == 0, and no tile block is cut into more than W8_SK_MAX_COPIES pieces.
 #define W8_SK_MAX_COPIES 8
-#define W8_SK_MAX_TILE_BLOCKS 16384      /* counters per context (64 KB) */
+#define W8_SK_MAX_TILE_BLOCKS DI_WINO_COUNTERS   /* counters per context (64 KB) */
 static int wino8_streamk_plan(long grid, int nK, int step_granule, int slots, double* cost, int* F, int* q, int* rem) {
   if (grid % 8 != 0 || nK % step_granule != 0 || grid > W8_SK_MAX_TILE_BLOCKS) return 0;
   const int G = nK / step_granule, nlb = slots / 8;
@@ -1337,7 +1363,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     const int skG = (ctx->wino_split != 1 && ctx->wino_persistent && ctx->wino_streamk && out_nc8 && out_elems * 4 < (1ull << 31)) ? wino8_streamk_plan(grid, nK, gran, slots, &cost_sk, &skF, &skq, &skrem) : 0;
     // measured (bench.py A/B in one box): +1 % at B = 32 (4-18 whole rounds before the cut one), -1 % at B = 4 (one): from two whole rounds on
     // (the arrival counters are allocated on the first such launch: not inside a graph capture — run the sequence once eagerly first)
-    const bool streamk = skG > 0 && (ctx->wino_counters || !ctx->capturing) &&
+    const bool streamk = skG > 0 &&
                          (ctx->wino_streamk == 2 || (skF >= 2 && cost_sk < cost_split * 0.98));   // 2: wherever it applies (tests)
     if (streamk) { S = 1; ks = nK; }
     p.grid0 = grid; p.kslice = ks; p.ksplit = S; p.part_stride = 0; p.part = nullptr;
@@ -1356,13 +1382,15 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
     if (ctx->wino_persistent) grid = (int)std::min<long>(grid, slots);   // one block per resident slot, each walks its share
     if (streamk) {
       p.sk_G = skG; p.sk_gran = gran; p.sk_F = skF; p.sk_q = skq; p.sk_rem = skrem; p.sk_nlb = slots / 8; grid = slots;
-      if (!plan_only) {
-        if (!ctx->wino_counters) {   // one word per tile block, zero between launches (the kernel leaves them so)
-          DI_CHECK(hipMalloc(&ctx->wino_counters, W8_SK_MAX_TILE_BLOCKS * sizeof(int)));
-          DI_CHECK(hipMemsetAsync(ctx->wino_counters, 0, W8_SK_MAX_TILE_BLOCKS * sizeof(int), ctx->stream));
-        }
-        p.sk_count = (int*)ctx->wino_counters;
-      }
+      if (!plan_only) p.sk_count = (int*)ctx->wino_counters;   // one word per tile block, zero between launches (the kernel leaves them so)
+    }
+    // K slices finished inside the kernel: the block whose slice of a tile block arrives last adds the S raw copies in slice order, the bias
+    // and the activation — the sums wino_reduce_kernel would form, without its launch and its pass over the whole output
+    const bool fin = S > 1 && ctx->wino_fin && p.grid0 <= DI_WINO_COUNTERS && (size_t)out_elems * 4 < (1ull << 31);
+    p.fin_nchw = 0; p.fin_ctotal = 0; p.fin_coff = 0;
+    if (fin) {
+      if (!plan_only) p.sk_count = (int*)ctx->wino_counters;
+      if (!out_nc8) { p.fin_nchw = 1; p.fin_ctotal = out_ctotal > 0 ? out_ctotal : Cout; p.fin_coff = out_coff; }
     }
     if (plan_only) {   // {block shape 0 / 1 wide / 2 four-wave, grid, K slices, K steps per slice, stream-K granules per tile block (0: off), granules per run, whole tile blocks per block before the run, tile blocks of the layer (incl. the padding of the XCD deal), runs that are one granule longer}
       plan_only[0] = half ? 2 : wide ? 1 : 0; plan_only[1] = grid; plan_only[2] = S; plan_only[3] = ks; plan_only[4] = p.sk_G; plan_only[5] = p.sk_q; plan_only[6] = p.sk_F; plan_only[7] = p.grid0; plan_only[8] = p.sk_rem;
@@ -1378,7 +1406,7 @@ static int wino_forward_impl(deepim_ctx* ctx, float* out, const float* in, const
       if (out_nc8) { W8_LAUNCH(1, 0) } else { W8_LAUNCH(0, 0) }
     }
 #undef W8_LAUNCH
-    if (S > 1) {
+    if (S > 1 && !fin) {
       const long total = out_nc8 ? (long)(out_elems / 4) : (long)out_elems;
       const int hw = p.out_s2d ? H * W / 4 : H * W;
       wino_reduce_kernel<<<di_div_up(total, 256), 256, 0, ctx->stream>>>(out, p.part, bias, total, p.part_stride, S, slope, out_nc8 ? 1 : 0,

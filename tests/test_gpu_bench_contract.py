@@ -40,7 +40,7 @@ def test_bench_line_single_gpu():
     assert 0 < d["roofline"]["dominant_frac"] < 1 and len(full["roofline"]["layers_live"]) == 10
     assert abs(d["value"] - 2 * 4 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert 0 < rf["frac"] < 1 and d["config"]["workload"]
 
 

@@ -28,6 +28,7 @@ def wino_kernel(ctx, request):
     lib.deepim_set_option(ctx.handle, b"wino_shared", 1)
     lib.deepim_set_option(ctx.handle, b"wino_streamk", 1)
     lib.deepim_set_option(ctx.handle, b"wino_split", 0)
+    lib.deepim_set_option(ctx.handle, b"wino_fin", 0)
 
 
 def _to_nc8(x):
@@ -130,6 +131,17 @@ def test_shared_transform_kernel_split_over_the_input_channels(ctx, case, slices
             o = ctx.array(np.full((B, max(ctotal, cout), H, W), 3.0, np.float32))
             lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, ctotal, coff)
             outs.append(o.asnumpy())
+        # the slices summed by the slice that arrives last (wino_fin = 1) instead of by the second pass (the default): the same adds in the
+        # same order — bit for bit; twice, so that the arrival counters are seen to return to zero
+        lib.deepim_set_option(ctx.handle, b"wino_split", slices)
+        lib.deepim_set_option(ctx.handle, b"wino_fin", 1)
+        o = ctx.array(np.full((B, max(ctotal, cout), H, W), 3.0, np.float32))
+        lib.deepim_conv2d_wino_forward(ctx.handle, o, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, ctotal, coff)
+        np.testing.assert_array_equal(o.asnumpy(), outs[1])
+        o2 = ctx.array(np.full((B, max(ctotal, cout), H, W), 3.0, np.float32))
+        lib.deepim_conv2d_wino_forward(ctx.handle, o2, xin, pk, bias, B, cin, H, W, cout, cf(0.1), out_nc8, ctotal, coff)
+        np.testing.assert_array_equal(o2.asnumpy(), outs[1])
+        lib.deepim_set_option(ctx.handle, b"wino_fin", 0)
         lib.deepim_set_option(ctx.handle, b"wino_split", 0)
         scale = max(1.0, float(np.abs(outs[0]).max()))
         assert np.abs(outs[0] - outs[1]).max() <= 2e-6 * scale

@@ -55,7 +55,7 @@ def cmd_stats(a):
         out.append("%s,%d,%.1f,%.2f,%.2f" % (n.replace(",", ";"), c, t / 1e3, t / 1e3 / c, 100.0 * t / total))
     ms = conv_ns / 1e6 / a.iters
     tf = ENC_GFLOP_PER_PAIR * a.batch / ms
-    bench = re.search(r'"ms_per_launch_group": ([0-9.]+)', open(a.bench).read()) if a.bench else None
+    bench = re.search(r'"ms_per_launch_group":\s*([0-9.]+)', open(a.bench).read()) if a.bench else None
     out.append("# conv launch group (10 conv launches + split-K reduces) per iteration: %.3f ms -> %.1f TFLOP/s%s" % (
         ms, tf, "; bench.py HIP events in the same (profiled) run: %.3f ms -> %.1f TFLOP/s" % (
             float(bench.group(1)), ENC_GFLOP_PER_PAIR * a.batch / float(bench.group(1))) if bench else ""))
@@ -202,7 +202,7 @@ def cmd_perkernel(a):
         tot_ms += ms + rms
     out["per_kernel"] = per
     out["sum_ms"] = tot_ms
-    bench = re.search(r'"ms_per_launch_group": ([0-9.]+)', open(a.bench).read()) if a.bench else None
+    bench = re.search(r'"ms_per_launch_group":\s*([0-9.]+)', open(a.bench).read()) if a.bench else None
     out["bench_ms_per_launch_group_same_run"] = float(bench.group(1)) if bench else None
     hbm = []
     for path, batch, it in ((a.heads_trace, a.batch, a.iters), (a.train_trace, a.train_batch, None)):
