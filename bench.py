@@ -868,6 +868,9 @@ def main():
             got = probe_out.asnumpy()[:, 0, 0]
             if not np.array_equal(got, np.arange(world, dtype=np.float32)):
                 err = "all-gather returned %s" % got.tolist()
+            nranks = comm_record(h)["rccl_ranks"]           # ncclCommCount of the communicator this rank really holds
+            if err is None and nranks != world:
+                err = "communicator has %d ranks, the launch has %d" % (nranks, world)
         except Exception as e:          # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         errs = rdzv.all_gather((err or "").encode())

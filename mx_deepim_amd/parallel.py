@@ -360,6 +360,11 @@ class PoseComm(object):
         self.rank, self.world = rdzv.rank, rdzv.world
         self._scalar = None
         if self.world > 1:
+            # first-run de-risking (no N > 1 RCCL run exists): RCCL's own diagnostics go to stderr when — and only
+            # when — something fails (WARN prints nothing on success), so the launcher's per-rank .err file explains a failed
+            # ncclCommInitRank; the dmabuf IPC mode the pool's driver needs stays set for this process's children too
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             uid = None
             if self.rank == 0:
                 # a failure here (librccl missing, …) must still reach the broadcast, or every other rank waits for the id
