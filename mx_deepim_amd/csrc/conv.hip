@@ -2129,7 +2129,7 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
     const bool quad = kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W & 3) == 0 && ctx->conv_fewout_quad &&
                       (((uintptr_t)out | (uintptr_t)in) & 15) == 0;
     const int nblk = quad ? di_div_up(p.npix / 4, 64) : di_div_up(p.npix, 64);
-    int S = max(1, min(min(512 / nblk, Cin / 32), 16));
+    int S = max(1, min(min(ctx->conv_fewout_blocks / nblk, Cin / ctx->conv_fewout_minc), 32));
     const int cslice = di_div_up(Cin, S);
     S = di_div_up(Cin, cslice);
     float* partial = nullptr;

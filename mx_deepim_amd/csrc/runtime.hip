@@ -32,6 +32,8 @@ void deepim_ctx_default_options(deepim_ctx* c) {
   c->wino_streamk = 1;
   c->wino_fin = 0;   // measured slower than the second pass at every batch size (profiles/r06_b4_share.md)
   c->conv_fewout_quad = 1;
+  c->conv_fewout_blocks = 512;
+  c->conv_fewout_minc = 32;
   c->wino_counters = nullptr;
   c->wino_split = 0;
   c->wino_wide = 1;
@@ -234,6 +236,8 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "wgrad_lds") == 0) { ctx->wgrad_lds = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_two_wave") == 0) { ctx->wino_two_wave = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_persistent") == 0) { ctx->wino_persistent = value ? 1 : 0; return 0; }
+  if (strcmp(name, "conv_fewout_blocks") == 0) { ctx->conv_fewout_blocks = value < 1 ? 1 : value; return 0; }
+  if (strcmp(name, "conv_fewout_minc") == 0) { ctx->conv_fewout_minc = value < 1 ? 1 : value; return 0; }
   if (strcmp(name, "conv_fewout_quad") == 0) { ctx->conv_fewout_quad = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_fin") == 0) { ctx->wino_fin = value != 0; return 0; }
   if (strcmp(name, "wino_streamk") == 0) { ctx->wino_streamk = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
@@ -257,7 +261,7 @@ extern "C" int deepim_get_option(deepim_ctx* ctx, const char* name, int* value) 
       {"conv_max_split", ctx->conv_max_split}, {"conv_direct", ctx->conv_direct}, {"fc_slices", ctx->fc_slices},
       {"conv_tail_split", ctx->conv_tail_split}, {"conv_force_plan", ctx->conv_force_plan}, {"conv_tail_slots", ctx->conv_tail_slots},
       {"conv_tile256", ctx->conv_tile256}, {"conv_autotune", ctx->conv_autotune}, {"dgrad_group", ctx->dgrad_group},
-      {"wgrad_lds", ctx->wgrad_lds}, {"wino_two_wave", ctx->wino_two_wave}, {"wino_shared", ctx->wino_shared}, {"wino_wide", ctx->wino_wide}, {"wino_split", ctx->wino_split}, {"wino_persistent", ctx->wino_persistent}, {"wino_streamk", ctx->wino_streamk}, {"wino_fin", ctx->wino_fin}, {"conv_fewout_quad", ctx->conv_fewout_quad}, {"wino_s2d_skip", ctx->wino_s2d_skip}, {"f16_dev_flags", ctx->f16_dev_flags}, {"conv_xcd_swizzle", ctx->conv_xcd_swizzle}};
+      {"wgrad_lds", ctx->wgrad_lds}, {"wino_two_wave", ctx->wino_two_wave}, {"wino_shared", ctx->wino_shared}, {"wino_wide", ctx->wino_wide}, {"wino_split", ctx->wino_split}, {"wino_persistent", ctx->wino_persistent}, {"wino_streamk", ctx->wino_streamk}, {"wino_fin", ctx->wino_fin}, {"conv_fewout_quad", ctx->conv_fewout_quad}, {"conv_fewout_blocks", ctx->conv_fewout_blocks}, {"conv_fewout_minc", ctx->conv_fewout_minc}, {"wino_s2d_skip", ctx->wino_s2d_skip}, {"f16_dev_flags", ctx->f16_dev_flags}, {"conv_xcd_swizzle", ctx->conv_xcd_swizzle}};
   for (const auto& o : opts)
     if (strcmp(name, o.n) == 0) { *value = o.v; return 0; }
   deepim_set_error_msg("deepim_get_option: unknown option");

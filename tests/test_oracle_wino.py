@@ -77,11 +77,10 @@ def test_layer_selection_rule():
     assert L.deepim_conv_wino_preferred(None, 64, 256, 60, 80, 256) and not L.deepim_conv_wino_preferred(None, 512, 256, 60, 80, 256)   # >= 2 GiB input
 
 
-def test_f4x4_3x3_in_float32_misses_the_layer_bar():
-    """VERDICT r4 item 4 (exploratory, kill criterion "every layer <= 1e-5 of its range"): F(4x4, 3x3) is the same convolution in exact
-    arithmetic, but carried in float32 its interpolation points +-2 and 1/24 cost an order of magnitude over F(2x2, 3x3) — at the
-    bar on conv3_1's 256 input channels, over it on conv4_1's 512 — before a kernel's longer sequential MFMA chains add theirs. Killed
-    on this evidence without a GPU session; F(2x2, 3x3) stays the fp32 Winograd form."""
+def test_f4x4_3x3_in_float32_layer_error():
+    """F(4x4, 3x3) is the same convolution in exact arithmetic; carried in float32 its interpolation points +-2 and 1/24 cost an order of
+    magnitude over F(2x2, 3x3) on random operands — 1e-5 of a layer's range at 256 input channels, 1.6e-5 at 512. Round 5 killed it on the
+    self-imposed every-layer bar of 1e-5; VERDICT r5 item 3 re-judged it on north_star's own bar (the test below)."""
     from oracle import wino
     rng = np.random.default_rng(0)
     errs = {}
@@ -94,9 +93,49 @@ def test_f4x4_3x3_in_float32_misses_the_layer_bar():
         scale = np.abs(ref).max()
         errs[cin] = (np.abs(wino.winograd_f2x2_3x3(x, w, np.float32) - ref).max() / scale,
                      np.abs(wino.winograd_f4x4_3x3(x, w, np.float32) - ref).max() / scale)
-    assert errs[256][0] < 2e-6 and errs[512][0] < 2e-6            # F(2x2): a comfortable factor inside the bar
-    assert errs[256][1] > 5e-6 and errs[512][1] > 1e-5            # F(4x4): at the bar / over it
+    assert errs[256][0] < 2e-6 and errs[512][0] < 2e-6            # F(2x2): a comfortable factor inside 1e-5
+    assert 5e-6 < errs[256][1] < 5e-5 and 1e-5 < errs[512][1] < 5e-5
     assert errs[512][1] > 10 * errs[512][0]
+
+
+def test_f4x4_3x3_on_conv3_1_and_conv4_1_meets_north_stars_pose_bar():
+    """VERDICT r5 item 3, the accuracy half of the keep criterion: one full refinement iteration of two 480x640 pairs with conv3_1 and
+    conv4_1 computed through float32 F(4x4, 3x3) (the two layers a kernel would take first), everything else the oracle — against the
+    oracle's own iteration. Layers 5.6e-6 / 6.4e-6 of range on the real activations (sparser than random operands), se3 3.5e-7, pose 7e-9:
+    two orders inside the 1e-5 bar (ten times north_star's 1e-4). The arithmetic is NOT what stopped F(4x4, 3x3); the register budget of a
+    two-waves-per-SIMD kernel is (profiles/r06_wino44.md: 36 positions = 144 accumulator registers per wave)."""
+    from oracle import net as onet, pipeline as opipe, se3 as ose3, wino
+    from mx_deepim_amd import synthetic
+    from mx_deepim_amd.config import default_config
+    from mx_deepim_amd.symbols import deepIM_flownet
+    onet.build()
+    cfg = default_config()
+    params = deepIM_flownet().get_symbol(cfg).init_weights(cfg, seed=2333)
+    params["trans_weight"] = params["trans_weight"] * np.float32(0.02)      # as bench.py: keeps the object in frame
+    params["trans_bias"] = params["trans_bias"] * np.float32(0.02)
+    d = synthetic.make_batch(2, seed=2333, n_frames=1)
+    means_rev = np.ascontiguousarray(synthetic.PIXEL_MEANS[::-1])
+    data = {"image_observed": d["image_observed"], "image_rendered": d["image_rendered"][0], "mask_observed": d["mask_observed"],
+            "mask_rendered": d["mask_rendered"][0], "src_pose": d["src_pose"][0]}
+    ref = opipe.refine_iteration(params, data, d["K"], means_rev, cfg.dataset.trans_means, cfg.dataset.trans_stds, cfg.network.ROT_COORD)
+    x, layer_err = ref["net_input"], {}
+    for name, s, p in opipe.ENCODER:
+        w, b = params[name + "_weight"], params[name + "_bias"]
+        if name in ("conv3_1", "conv4_1"):
+            y = wino.winograd_f4x4_3x3(x, w, np.float32) + b.reshape(1, -1, 1, 1)
+            x = np.where(y > 0, y, y * np.float32(0.1)).astype(np.float32)
+            layer_err[name] = float(np.abs(x - ref[name]).max() / np.abs(ref[name]).max())
+        else:
+            x = onet.conv2d(x, w, b, s, p, 0.1, pair_order=0)
+    _, _, se3 = opipe.pose_head(params, x, ref["zoom_factor"])
+    pose = np.stack([ose3.RT_transform(np.asarray(data["src_pose"][i], np.float32), se3[i, :4], se3[i, 4:], cfg.dataset.trans_means,
+                                       cfg.dataset.trans_stds, cfg.network.ROT_COORD) for i in range(2)])
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())
+    print("F(4x4,3x3) on conv3_1 / conv4_1: layers %s, se3 %.2e, pose %.2e" % (layer_err, rel(se3, ref["se3"]), rel(pose, ref["pose_est"])))
+    assert max(layer_err.values()) < 2e-5
+    assert rel(se3, ref["se3"]) < 1e-5 and rel(pose, ref["pose_est"]) < 1e-5
 
 
 def _wino_plan(B, cin, H, W, cout, out_nc8=1, s2d=0):
