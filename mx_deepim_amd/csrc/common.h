@@ -75,7 +75,7 @@ struct deepim_ctx {
   int wino_shared;       // 1 (default): Winograd layers with Cout % 64 == 0 on the 8-wave shared-transform kernel (conv_wino8_kernel); 0: the round-4 one-wave kernel
   int wino_wide;         // block shape of the shared-transform kernel: 1 (default) = per layer by the work per CU, 0 = 64 ch x 64 tiles, 3 = 128 x 32, 2 = 64 x 32 on four waves (two blocks per CU)
   int wino_split;        // K-split of the shared-transform kernel: 0 (default) = the plan of wino8_split_plan, 1 = never, n = at most n slices
-  int conv_fewout_blocks, conv_fewout_minc;   // few-filter heads: channel slices so that the grid has about this many blocks (default 512), of at least this many channels each (32)
+  int conv_fewout_blocks, conv_fewout_minc;   // few-filter heads: channel slices so that the grid has about this many blocks (0 = default: 1024 where the pixels alone give >= 32 blocks, else 512), of at least this many channels each (32)
   int conv_fewout_quad;  // 1 (default): the 3x3 stride-1 heads with W % 4 == 0 on the four-pixels-per-lane kernel; 0: one pixel per lane
   int wino_streamk;      // 1 (default): where a grid leaves a partly filled last round, the persistent blocks share the work granule by granule (stream-K; needs wino_persistent, off with wino_split = 1); 2: wherever it applies, whatever the cost model says; 0: never
   std::map<uintptr_t, size_t> allocs;   // deepim_malloc's live allocations (base -> bytes): deepim_d2d's residency test without a driver query

@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__(1024) void conv_fewout_kernel(float* __restrict__ o
 // ran at 0.10-0.20 of the HBM rate (profiles/per_kernel.json); this one at 0.19-0.24 (the 770-channel heads 75-79 -> 61-64 us). Eight waves split the block's
 // channel slice into eighths ((ci,ky,kx)-ordered chains, partial sums added in wave order through LDS), grid.y slices the channels
 // further where the pixels alone leave the chip empty (raw sums to partial[slice][n][co][hw], fixed-order second pass).
+#ifndef FEWOUT_UNROLL
+#define FEWOUT_UNROLL 2     // channels of the stream whose loads are in flight together (1: one at a time; same chains, same results)
+#endif
+#ifndef FEWOUT_HALO_DPP
+#define FEWOUT_HALO_DPP 1   // 0: the round-5 form (two dword loads per row for the halo columns), for A/B builds
+#endif
 template <int COUT>
 __global__ __launch_bounds__(512) void conv_fewout_quad_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                               const float* __restrict__ wp, const float* __restrict__ bias, int Cin,
@@ -1071,15 +1077,43 @@ __global__ __launch_bounds__(512) void conv_fewout_quad_kernel(float* __restrict
   // (Tried, same box: four channels' loads in flight together — 62.5 / 61.1 us against 63.6 / 61.4 on the 770-channel heads; the weights
   // staged in per-wave LDS strips instead of scalar loads from the packed layout's 256-byte lines — 75 us. Neither the load latency of a
   // wave nor the scalar cache is what holds this stream at ~2 TB/s; kept simple.)
-  for (int ci = c_lo; ci < c_hi; ++ci) {
+  // The two halo columns of a lane's quad are its neighbours' own pixels: lane - 1 holds x0 - 1 as its m.w, lane + 1 holds x0 + 4 as its
+  // m.x (quads are dealt in row order; at a row's ends the halo is the zero padding). They arrive by a whole-wave DPP shift instead of
+  // two more loads per row — the six dword loads per channel were 2/3 of the kernel's address-coalescer time (64 lanes x 4 bytes at a
+  // 16-byte stride cost a full-rate instruction each) —; only lanes 0 and 63, whose neighbour sits in another wave, still load theirs.
+  const bool edge = lane == 0 || lane == 63;
+  const bool dl = lane > 0 && x0 > 0, dr = lane < 63 && x0 + 4 < W;
+  // one channel's loads: three aligned dwordx4 (+ the halo pixels of lanes 0 / 63, whose neighbours sit in another wave)
+  auto load_ch = [&](const int ci, float4 (&m)[3], float (&e0)[3], float (&e5)[3]) {
     const int so = ci * hw * 4;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      m[ky] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ky][1], so, 0));
+      e0[ky] = 0.f; e5[ky] = 0.f;
+    }
+    if (!FEWOUT_HALO_DPP || edge) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        if (!FEWOUT_HALO_DPP || lane == 0) e0[ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][0], so, 0));
+        if (!FEWOUT_HALO_DPP || lane == 63) e5[ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][2], so, 0));
+      }
+    }
+  };
+  // ... and its 36 x COUT fmaf, in (ky, kx) order behind the channels before it: the chain of every output is the one-channel-at-a-time
+  // chain whatever FEWOUT_UNROLL is
+  auto fma_ch = [&](const int ci, const float4 (&m)[3], const float (&e0)[3], const float (&e5)[3]) {
     float x[3][6];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      x[ky][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][0], so, 0));
-      const float4 m = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[ky][1], so, 0));
-      x[ky][1] = m.x; x[ky][2] = m.y; x[ky][3] = m.z; x[ky][4] = m.w;
-      x[ky][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[ky][2], so, 0));
+      x[ky][0] = e0[ky]; x[ky][5] = e5[ky];
+      if (FEWOUT_HALO_DPP) {
+        // wave_shr:1 (0x138): lane i reads lane i - 1; wave_shl:1 (0x130): lane i reads lane i + 1 (GFX9 DPP controls)
+        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[ky].w), 0x138, 0xf, 0xf, false));
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[ky].x), 0x130, 0xf, 0xf, false));
+        x[ky][0] = dl ? fl : x[ky][0];
+        x[ky][5] = dr ? fr : x[ky][5];
+      }
+      x[ky][1] = m[ky].x; x[ky][2] = m[ky].y; x[ky][3] = m[ky].z; x[ky][4] = m[ky].w;
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -1091,6 +1125,25 @@ __global__ __launch_bounds__(512) void conv_fewout_quad_kernel(float* __restrict
 #pragma unroll
           for (int o = 0; o < 4; ++o) acc[co][o] = fmaf(wv, x[ky][o + kx], acc[co][o]);
         }
+  };
+  {
+    int ci = c_lo;
+    if (FEWOUT_UNROLL >= 2) {
+      for (; ci + 1 < c_hi; ci += 2) {   // two channels' loads in flight together
+        float4 ma[3], mb[3];
+        float a0[3], a5[3], b0[3], b5[3];
+        load_ch(ci, ma, a0, a5);
+        load_ch(ci + 1, mb, b0, b5);
+        fma_ch(ci, ma, a0, a5);
+        fma_ch(ci + 1, mb, b0, b5);
+      }
+    }
+    for (; ci < c_hi; ++ci) {
+      float4 ma[3];
+      float a0[3], a5[3];
+      load_ch(ci, ma, a0, a5);
+      fma_ch(ci, ma, a0, a5);
+    }
   }
   if (wave > 0) {
 #pragma unroll
@@ -2129,7 +2182,10 @@ static int conv2d_forward_impl(deepim_ctx* ctx, float* out, const float* in, con
     const bool quad = kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W & 3) == 0 && ctx->conv_fewout_quad &&
                       (((uintptr_t)out | (uintptr_t)in) & 15) == 0;
     const int nblk = quad ? di_div_up(p.npix / 4, 64) : di_div_up(p.npix, 64);
-    int S = max(1, min(min(ctx->conv_fewout_blocks / nblk, Cin / ctx->conv_fewout_minc), 32));
+    // measured with the DPP halo (profiles/r06_heads.md): ~1024 blocks where the pixels give >= 32 blocks of their own (the 30x40 and 15x20
+    // heads at B = 32: 53 -> 39 us), ~512 below (the 8x10 head and every head at B = 4: more slices only add second-pass traffic)
+    const int target = ctx->conv_fewout_blocks > 0 ? ctx->conv_fewout_blocks : (nblk >= 32 ? 1024 : 512);
+    int S = max(1, min(min(target / nblk, Cin / ctx->conv_fewout_minc), 32));
     const int cslice = di_div_up(Cin, S);
     S = di_div_up(Cin, cslice);
     float* partial = nullptr;

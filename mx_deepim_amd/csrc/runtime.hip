@@ -32,7 +32,7 @@ void deepim_ctx_default_options(deepim_ctx* c) {
   c->wino_streamk = 1;
   c->wino_fin = 0;   // measured slower than the second pass at every batch size (profiles/r06_b4_share.md)
   c->conv_fewout_quad = 1;
-  c->conv_fewout_blocks = 512;
+  c->conv_fewout_blocks = 0;     // 0 = by the grid (launch site)
   c->conv_fewout_minc = 32;
   c->wino_counters = nullptr;
   c->wino_split = 0;
@@ -236,7 +236,7 @@ extern "C" int deepim_set_option(deepim_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "wgrad_lds") == 0) { ctx->wgrad_lds = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_two_wave") == 0) { ctx->wino_two_wave = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_persistent") == 0) { ctx->wino_persistent = value ? 1 : 0; return 0; }
-  if (strcmp(name, "conv_fewout_blocks") == 0) { ctx->conv_fewout_blocks = value < 1 ? 1 : value; return 0; }
+  if (strcmp(name, "conv_fewout_blocks") == 0) { ctx->conv_fewout_blocks = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "conv_fewout_minc") == 0) { ctx->conv_fewout_minc = value < 1 ? 1 : value; return 0; }
   if (strcmp(name, "conv_fewout_quad") == 0) { ctx->conv_fewout_quad = value ? 1 : 0; return 0; }
   if (strcmp(name, "wino_fin") == 0) { ctx->wino_fin = value != 0; return 0; }

@@ -22,8 +22,12 @@ for name, cin, H, W, cout in LAYERS:
     ref = None
     row = []
     for blocks, minc in PLANS:
-        lib.deepim_set_option(ctx.handle, b"conv_fewout_blocks", blocks)
-        lib.deepim_set_option(ctx.handle, b"conv_fewout_minc", minc)
+        try:
+            lib.deepim_set_option(ctx.handle, b"conv_fewout_blocks", blocks)
+            lib.deepim_set_option(ctx.handle, b"conv_fewout_minc", minc)
+        except RuntimeError:      # an older build (A/B through DEEPIM_LIB): its fixed plan, once
+            if (blocks, minc) != PLANS[0]:
+                continue
         run(); run()
         got = out.asnumpy()
         if ref is None:
