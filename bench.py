@@ -825,6 +825,8 @@ def main():
                     "after the timed loop one more step is run and for this many sampled pairs every one of its refinement "
                     "iterations is replayed through the CPU oracle (fed the frames the GPU rendered) → `parity` in the JSON "
                     "line; 0 = off")
+    ap.add_argument("--no-layer-timings", action="store_true", help="skip the per-layer HIP-event timings after the timed region (6 extra launches per "
+                    "encoder layer; the rocprofv3 passes of tools/run_profiles.sh cut the trace by iteration count and must not see them)")
     ap.add_argument("--full", action="store_true", help="print the full record (what bench_detail.json holds) as the final line instead "
                     "of the compact one the driver parses (used by the secondary runs and the tests that read its fields)")
     ap.add_argument("--extras-budget", type=float, default=200.0, help="wall-clock budget in seconds for everything after the "
@@ -1012,7 +1014,7 @@ def main():
 
         def left():
             return deadline - time.time()
-        if not (args.fp16 or args.x3):       # live, this run: every encoder layer alone -> the dominant kernel's own roofline fraction
+        if not (args.fp16 or args.x3 or args.no_layer_timings):       # live, this run: every encoder layer alone -> the dominant kernel's own roofline fraction
             lt = layer_timings(ctx, net, peak=peak)
             dom = max(lt, key=lambda r: r["ms"])
             fam = [r for r in lt if r["kernel"] == dom["kernel"]]
