@@ -200,36 +200,6 @@ def cpu_baseline(params, cfg, batch, budget_s=20.0, with_depth=False, min_runs=5
     return res
 
 
-def cpu_onednn_secondary(cfg, seconds=8.0, pairs=4):
-    """Secondary, labelled CPU figure: the encoder conv stack + fc6/fc7 through torch-CPU, i.e. oneDNN — the
-    library MXNet-MKL would use for the same layers. Network forward only (no zoom, no pose update), random weights."""
-    import torch
-    import torch.nn.functional as F
-    torch.manual_seed(0)
-    cin, layers = 8 if cfg.network.INPUT_MASK else 6, []
-    for name, cout, k, s_, p_ in ENCODER:
-        layers.append((torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5, torch.zeros(cout), s_, p_))
-        cin = cout
-    w6, w7 = torch.randn(256, 1024 * 8 * 10) / 300, torch.randn(256, 256) / 16
-    x = torch.randn(pairs, 8 if cfg.network.INPUT_MASK else 6, 480, 640)
-
-    def fwd():
-        with torch.no_grad():
-            y = x
-            for w, b, s_, p_ in layers:
-                y = F.leaky_relu(F.conv2d(y, w, b, stride=s_, padding=p_), 0.1)
-            y = F.leaky_relu(F.linear(y.flatten(1), w6), 0.1)
-            return F.leaky_relu(F.linear(y, w7), 0.1)
-    fwd()
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        fwd()
-        n += pairs
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "network forwards/sec", "cores": os.cpu_count(), "threads": torch.get_num_threads(),
-            "kind": "secondary: torch-CPU (oneDNN) conv stack + fc6/fc7 only, batch %d, %d forwards in %.1f s" % (pairs, n, dt)}
-
-
 def verify_parity(args, cfg, net, params, ctx, step, pose_cur, K, B):
     """Parity of the configuration that was just timed (same context, same plans, same batch): one more step with taps
     that copy, for `--verify` sampled pairs, the inputs of every refinement iteration (observed frame, the frame the GPU
@@ -794,8 +764,6 @@ def main():
     ap.add_argument("--layers", action="store_true", help="also report per-layer conv timings")
     ap.add_argument("--heads", action="store_true", help="BASELINE config 4 mode: full test graph (FAST_TEST off) with the "
                     "FlowNetS decoder and the mask / flow heads in every iteration (NOT the headline)")
-    ap.add_argument("--no-cpu-onednn", action="store_true", help="skip the labelled secondary CPU figure (network forward "
-                    "through torch-CPU = oneDNN, as MXNet-MKL would run it; imports torch after the timed region, N=1 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short secondary runs of the other BASELINE "
                     "configurations (B=16, B=4 share of config 3, config 4 heads, config 5 fp16) that the default N=1 run "
                     "appends to its JSON line as `other_configs` (and, at N > 1, the weak-scaling figure)")
@@ -975,7 +943,7 @@ def main():
                               "frac": zoom_bytes / (zoom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": zoom_ms,
                               "note": "algorithmic bytes = read + write of every zoomed channel once (SURVEY 8d); the fused "
                                       "front end keeps BilinearSampler's float/double blend bit for bit (VALU work ~ the "
-                                      "HBM time), see DESIGN.md section 3"},
+                                      "HBM time), see profiles/r03_zoom_ablation.md"},
         })
         if rl_hbm:
             out["roofline_hbm"] = rl_hbm      # the Z / H / F kernels SURVEY 8(d) lists, algorithmic bytes / recorded time / 8 TB/s each
@@ -1036,14 +1004,6 @@ def main():
                        and args.batch == 32 and not args.no_other_configs and not args.no_cpu_baseline)
         if default_run:
             out["other_configs"] = other_configs(left)
-        if world == 1 and not args.no_cpu_baseline and not args.no_cpu_onednn:
-            if left() > 25:
-                try:
-                    out["cpu_baseline"]["secondary_onednn"] = cpu_onednn_secondary(cfg)
-                except ImportError as e:       # torch is test/bench tooling only; the figure is optional
-                    out["cpu_baseline"]["secondary_onednn"] = {"skipped": str(e)}
-            else:
-                out["cpu_baseline"]["secondary_onednn"] = {"skipped": "extras budget spent"}
         emit()
     if comm is not None:
         comm.close()

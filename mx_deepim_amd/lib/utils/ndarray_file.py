@@ -3,7 +3,7 @@ exchange; the reference loads them at lib/utils/load_model.py:21).
 
 MXNet is not installed and no checkpoint exists offline, so the layout below is RESTATED from MXNet 1.2's
 `src/ndarray/ndarray.cc` (`NDArray::Save/Load`, list magic 0x112) and exercised by round trips only — it is
-not pinned against a file written by MXNet itself (DESIGN.md §8). Little-endian throughout:
+not pinned against a file written by MXNet itself (DESIGN.md §4). Little-endian throughout:
 
     uint64 0x112 | uint64 reserved(0)
     uint64 n_arrays, then per array

@@ -4,7 +4,7 @@ Plain numpy / C restatement of the reference algorithm, used as the parity check
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.  Nothing
 under ``mx_deepim_amd/`` imports this package; the product path has no CPU fallback.
 
-Pinning status (see DESIGN.md §oracle):
+Pinning status (see DESIGN.md §4):
   * S-group (RT_transform, calc_RT_delta, se3_mul/inverse, quat/euler algebra) and F2
     (calc_flow) are pinned against the reference's own Python, imported in the build
     container from /root/reference (tests/golden/make_golden.py → tests/golden/*.npz),

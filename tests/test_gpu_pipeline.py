@@ -272,7 +272,7 @@ def test_checkpoint_import_reaches_the_bound_network(ctx, small_batch, tmp_path,
     file lacks is initialised) → bind. Every bound device tensor equals the file; the packed forms are checked through what they
     compute — the Winograd operand of conv3_1 element by element, and one refinement iteration against the oracle run on the FILE's
     weights. (The container layout itself is restated from MXNet 1.2 and round-trips through this repo's writer only: unpinned until an
-    MXNet-written file is available — DESIGN.md section 7.)"""
+    MXNet-written file is available — DESIGN.md section 4.)"""
     from mx_deepim_amd.lib.utils.load_model import load_param, save_checkpoint
     d = small_batch
     B = d["image_observed"].shape[0]
