@@ -83,7 +83,10 @@ void* deepim_stream(deepim_ctx* ctx);           /* hipStream_t, for interop */
  * (measured on MI355X, profiles/r06_b4_share.md: the lone finishing block's read-back is a serial tail that costs more than the parallel
  * pass it replaces — conv6_1 at B = 4: 48 -> 129 us). The arrival counters of both in-kernel finishes (64 KB) are allocated by
  * deepim_create: a layer's plan depends on geometry and options only, under graph capture as in eager runs. "conv_fewout_quad": 1 (default) = the 3x3
- * stride-1 pad-1 convolutions with Cout <= 4 and W % 4 == 0 (flow / mask predictors) compute four pixels per lane, 0 = one. Unknown names fail. */
+ * stride-1 pad-1 convolutions with Cout <= 4 and W % 4 == 0 (flow / mask predictors) compute four pixels per lane, 0 = one;
+ * "conv_fewout_blocks": the grid those few-filter convolutions slice their input channels for — 0 (default) = ~1024 blocks where the pixels
+ * alone give >= 32 blocks, ~512 below (measured, profiles/r06_heads.md), n = about n blocks; "conv_fewout_minc": the smallest channel slice
+ * (default 32). Unknown names fail. */
 int deepim_set_option(deepim_ctx* ctx, const char* name, int value);
 /* *value = the current setting of an option deepim_set_option knows (host code that has to follow the context's kernel selection —
  * e.g. which weight-gradient layout the training graph registers — reads it here). Unknown names fail. */
