@@ -927,11 +927,11 @@ def main():
                                             r.get("rccl_ranks") == my_rec.get("rccl_ranks") for r in recs),
             "note": comm_note}
         out.update({
-            "config": {"workload": "LINEMOD-ape-like synthetic pairs, bs%d (%s/GPU, %s), %d iters, 480x640, %s, %s, %s" % (
+            "config": {"workload": "LINEMOD-ape-like synthetic, bs%d (%s/GPU, %s), %d iters, 480x640, %s, %s, %s" % (
                            gbatch, "/".join(str(c_) for c_ in sorted(set(counts), reverse=True)), scaling, NIT,
-                           "decoder + mask/flow heads" if args.heads else "FAST_TEST",
-                           "RGB-D 10-ch" if args.depth else "8-ch",
-                           "pre-staged frames" if args.prestaged else "closed loop (%s GPU re-render)" % ("lit" if args.lit else "unlit")),
+                           "decoder+heads" if args.heads else "FAST_TEST",
+                           "RGB-D" if args.depth else "8-ch",
+                           "pre-staged frames" if args.prestaged else "closed loop, %s GPU re-render" % ("lit" if args.lit else "unlit")),
                        "pairs_per_gpu": B, "global_batch": pairs_total, "iters": NIT, "shard_counts": counts,
                        "encoder_launch": "whole step from %d hipGraph segment(s)" % len(L.step_graphs) if L.step_graphs else
                                          "hipGraph replay" if use_graph else "direct launches",
