@@ -12,8 +12,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NACC, int NM, int NV, int NPL, int NW, int NRA, int NRB>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NACC, int NM, int NV, int NPL, int NW, int NRA, int NRB, int WPS = 2>
+__global__ __launch_bounds__(WPS == 2 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k(float* out, const float* wsrc, const float* psrc, int steps, unsigned wbytes, unsigned pbytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x16 acc[NACC];
@@ -30,7 +30,7 @@ void k(float* out, const float* wsrc, const float* psrc, int steps, unsigned wby
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, (int)wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)psrc, 0, (int)pbytes, 0x00020000);
   const int vw = lane * 16 + wave * 1024, vp = (threadIdx.x * 8 + blockIdx.x * 4096) & (pbytes - 1);
-  const unsigned lw = threadIdx.x * 8, lr = (wave & 3) * 9216 + lane * 16;
+  const unsigned lw = (threadIdx.x & 511) * 8, lr = (wave & 3) * 9216 + lane * 16;
   constexpr int SLOTS = NM;
   for (int s = 0; s < steps; ++s) {
     const int so = (s * 16384) & (wbytes - 1) & ~16383;
@@ -77,18 +77,18 @@ void k(float* out, const float* wsrc, const float* psrc, int steps, unsigned wby
   out[blockIdx.x * 512 + threadIdx.x] = sum;
 }
 
-template <int NACC, int NM, int NV, int NPL, int NW, int NRA, int NRB>
+template <int NACC, int NM, int NV, int NPL, int NW, int NRA, int NRB, int WPS = 2>
 static double run(const char* name, float* out, float* w, float* p, unsigned wb, unsigned pb) {
   const int steps = 2048, grid = 256 * 4;
-  hipFuncSetAttribute((const void*)k<NACC, NM, NV, NPL, NW, NRA, NRB>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+  hipFuncSetAttribute((const void*)k<NACC, NM, NV, NPL, NW, NRA, NRB, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NACC, NM, NV, NPL, NW, NRA, NRB>), dim3(grid), dim3(512), 73728, 0, out, w, p, steps, wb, pb);
+    hipLaunchKernelGGL((k<NACC, NM, NV, NPL, NW, NRA, NRB, WPS>), dim3(grid), dim3(WPS == 2 ? 512 : 256), 73728, 0, out, w, p, steps, wb, pb);
     hipEventRecord(e1); hipEventSynchronize(e1);
   }
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double fl = (double)grid * 8 * steps * NM * 4096.0, tf = fl / ms / 1e9;
+  const double fl = (double)grid * (WPS == 2 ? 8 : 4) * steps * NM * 4096.0, tf = fl / ms / 1e9;
   printf("%-72s %8.3f ms  %6.1f TF  %.3f of 157.3\n", name, ms, tf, tf / 157.3);
   return tf / 157.3;
 }
@@ -103,6 +103,11 @@ int main() {
   const double c43 = run<9, 36, 72, 9, 9, 9, 9>("F(4,3) 64ch x 32 tiles: +72 VALU +9 px +9 dsw +9 A +9 B", out, w, p, wb, pb);
   const double c43h = run<9, 36, 36, 5, 5, 9, 9>("F(4,3) if every V fed 128 channels: +36 VALU +5 px +5 dsw +9 A +9 B", out, w, p, wb, pb);
   run<9, 36, 108, 9, 9, 9, 9>("F(4,3) with 1.5x the transform ops (address math, masks): +108 VALU ...", out, w, p, wb, pb);
+  // one wave per SIMD (512 registers): 18 accumulator tuples = 288 registers per wave, the whole transform on the four waves
+  run<16, 64, 0, 0, 0, 0, 0, 1>("1 wave/SIMD: 64 MFMAs on 16 acc, nothing else (round 4's shape)", out, w, p, wb, pb);
+  run<18, 72, 0, 0, 0, 0, 0, 1>("1 wave/SIMD, F(4,3) shape: 72 MFMAs on 18 acc (288 regs), nothing else", out, w, p, wb, pb);
+  const double c43o = run<18, 72, 144, 18, 18, 18, 18, 1>("1 wave/SIMD, F(4,3) 64ch x 32 tiles: +144 VALU +18 px +18 dsw +18 A +18 B", out, w, p, wb, pb);
+  printf("one-wave form: 1.778 x (%.3f / %.3f) = %.2f\n", c43o, c23, 1.7778 * c43o / c23);
   printf("K-loop speed-up of F(4,3) over F(2,3) at equal loop quality: MFMA count 16/4 : 36/16 = 1.778 x (%.3f / %.3f) = %.2f (wide: %.2f)\n",
          c43, c23, 1.7778 * c43 / c23, 1.7778 * c43h / c23);
   return 0;
