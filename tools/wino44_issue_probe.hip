@@ -108,6 +108,13 @@ int main() {
   run<18, 72, 0, 0, 0, 0, 0, 1>("1 wave/SIMD, F(4,3) shape: 72 MFMAs on 18 acc (288 regs), nothing else", out, w, p, wb, pb);
   const double c43o = run<18, 72, 144, 18, 18, 18, 18, 1>("1 wave/SIMD, F(4,3) 64ch x 32 tiles: +144 VALU +18 px +18 dsw +18 A +18 B", out, w, p, wb, pb);
   printf("one-wave form: 1.778 x (%.3f / %.3f) = %.2f\n", c43o, c23, 1.7778 * c43o / c23);
+  // F(4,3) x F(2,3): 4x2 output tiles, 6x4 patch, 24 positions (3 multiplies per output instead of 4): 6 accumulator tuples per wave on a
+  // 64 ch x 32 tiles block — the same outputs x channels per wave and step as the shipped 128 x 32 block of 2x2 tiles
+  run<6, 24, 0, 0, 0, 0, 0>("F(4,3)xF(2,3) shape: 24 MFMAs on 6 acc, nothing else", out, w, p, wb, pb);
+  const double c42 = run<6, 24, 36, 6, 6, 6, 6>("F(4,3)xF(2,3) 64ch x 32 tiles(4x2): +36 VALU +6 px +6 dsw +6 A +6 B", out, w, p, wb, pb);
+  const double c42b = run<6, 24, 48, 6, 6, 6, 6>("  same with 48 VALU", out, w, p, wb, pb);
+  printf("F(4,3)xF(2,3): time per wave-step %.0f vs shipped mix %.0f ticks-equivalent -> K-loop speed-up %.2f (48 VALU: %.2f)\n",
+         24 * 64 / c42, 32 * 64 / c23, (32.0 / c23) / (24.0 / c42), (32.0 / c23) / (24.0 / c42b));
   printf("K-loop speed-up of F(4,3) over F(2,3) at equal loop quality: MFMA count 16/4 : 36/16 = 1.778 x (%.3f / %.3f) = %.2f (wide: %.2f)\n",
          c43, c23, 1.7778 * c43 / c23, 1.7778 * c43h / c23);
   return 0;
