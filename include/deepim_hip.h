@@ -354,6 +354,14 @@ int deepim_conv2d_wino_forward_s2d(deepim_ctx* ctx, float* out, const float* in_
 int deepim_relayout_nc8_s2d(deepim_ctx* ctx, float* dst, const float* src, int B, int C, int H, int W, int to_s2d);
 int deepim_conv2d_wino_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
                                int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
+/* The same 3x3 stride-1 pad-1 Convolution + bias + LeakyReLU layers (deepIM_flownet.py:77-101) as fp32 Winograd F(4,3) x F(2,3): 4-row x
+ * 2-column output tiles, 24 positions, 3 multiply-adds per output, input and output channel instead of 4 (csrc/wino42.hip; Cout % 64 == 0,
+ * Cin % 8 == 0; channel-blocked input, channel-blocked (out_nc8 = 1) or NCHW-slice (0) output). ~3e-6 of the layer's range from the direct
+ * sum (bar 1e-5). Packed size: 24 floats per (output, input channel) pair. Measurements and the reason for this tile: profiles/r06_wino44.md. */
+size_t deepim_conv_wino42_packed_size(int Cout, int Cin);
+int deepim_conv_wino42_pack_weights(deepim_ctx* ctx, float* packed_w, const float* w, int Cout, int Cin);
+int deepim_conv2d_wino42_forward(deepim_ctx* ctx, float* out, const float* in, const float* packed_w, const float* bias,
+                                 int B, int Cin, int H, int W, int Cout, float slope, int out_nc8, int out_ctotal, int out_coff);
 /* fp16 conv path (BASELINE config 5): NHWC fp16 activations, fp16 weights (packed once), fp16 matrix cores
  * with fp32 accumulation, bias + LeakyReLU in fp32, NHWC fp16 output. Same layer semantics as
  * deepim_conv2d_forward (deepIM_flownet.py:63-107); tolerance documented in DESIGN.md (fp16 cannot meet 1e-4).

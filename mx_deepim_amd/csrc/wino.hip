@@ -689,7 +689,9 @@ __device__ __forceinline__ void wino8_body(const WinoParams& p, char* smem, cons
   {
     const float zf = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(acc[q]) : "v"(zf));
+    // (s_nop: the v_mov that makes zf may be scheduled right in front of the first of these, and the hazard pass cannot see inside the asm —
+    // a VALU write followed by an MFMA read of the register needs wait states; found in csrc/wino42.hip, where acc[0] started from garbage)
+    for (int q = 0; q < 8; ++q) asm volatile("s_nop 4\n\tv_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(acc[q]) : "v"(zf));
   }
   tvec raw[4], T[4];
   f32x4 A[8], Bv[8];

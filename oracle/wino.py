@@ -80,3 +80,23 @@ def winograd_f4x4_3x3(x, w, dtype=np.float64):
             M = np.einsum("ocxn,bcxn->boxn", U, V).astype(dtype)
             out[:, :, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = np.einsum("ax,boxn,en->boae", at, M, at)
     return out[:, :, :H, :W]
+
+
+def winograd_f4x2_3x3(x, w, dtype=np.float64):
+    """The same convolution through F(4,3) down the rows x F(2,3) along the columns: 6x4 input patches, 24 positions, 4-row x 2-column
+    output tiles — 3 multiply-adds per output, input and output channel (csrc/wino42.hip). float32 = the kernel's arithmetic."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    TY, TX = (H + 3) // 4, (W + 1) // 2
+    xp = np.zeros((B, Cin, 4 * TY + 2, 2 * TX + 2), dtype)
+    xp[:, :, 1:H + 1, 1:W + 1] = x
+    U = np.einsum("xa,ocab,nb->ocxn", G4, w.astype(np.float64), G).astype(dtype)           # (Cout,Cin,6,4)
+    bt4, bt2, at4, at2 = BT4.astype(dtype), BT.astype(dtype), AT4.astype(dtype), AT.astype(dtype)
+    out = np.zeros((B, Cout, 4 * TY, 2 * TX), dtype)
+    for ty in range(TY):
+        for tx in range(TX):
+            d = xp[:, :, 4 * ty:4 * ty + 6, 2 * tx:2 * tx + 4]                              # (B,Cin,6,4)
+            V = np.einsum("xi,bcij,nj->bcxn", bt4, d, bt2).astype(dtype)
+            M = np.einsum("ocxn,bcxn->boxn", U, V).astype(dtype)
+            out[:, :, 4 * ty:4 * ty + 4, 2 * tx:2 * tx + 2] = np.einsum("ax,boxn,en->boae", at4, M, at2)
+    return out[:, :, :H, :W]

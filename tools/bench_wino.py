@@ -31,6 +31,12 @@ for name, cin, H, W, cout in LAYERS:
     bias = ctx.array(rng.standard_normal(cout).astype(np.float32))
     o1, o2 = ctx.empty((B, cout, H, W)), ctx.empty((B, cout, H, W))
     out8 = 0 if name == "conv6_1" else 1
+    w42 = None
+    if hasattr(lib.load(), "deepim_conv_wino42_packed_size") and cout % 64 == 0:      # F(4,3) x F(2,3), csrc/wino42.hip
+        p42 = DeviceArray(ctx, (lib.load().deepim_conv_wino42_packed_size(cout, cin) // 4,))
+        lib.deepim_conv_wino42_pack_weights(ctx.handle, p42, wd, cout, cin)
+        o3 = ctx.empty((B, cout, H, W))
+        w42 = lambda: lib.deepim_conv2d_wino42_forward(ctx.handle, o3, x, p42, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
     direct = lambda: lib.deepim_conv2d_forward_ex(ctx.handle, o1, x, pk, bias, B, cin, H, W, cout, 3, 3, 1, 1, cf(0.1), 0, 0, 1, out8)
     wino = lambda: lib.deepim_conv2d_wino_forward(ctx.handle, o2, x, pw, bias, B, cin, H, W, cout, cf(0.1), out8, 0, 0)
     def wino1():   # the other block shape (128 channels x 32 tiles if the default is 64 x 64, and vice versa)
@@ -53,6 +59,21 @@ for name, cin, H, W, cout in LAYERS:
     fle = 2.0 * cout * cin * 16 * tiles
     print("%-8s B %2d: direct %.3f ms %5.1f TF | winograd %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f | max diff %.1e of range | other block shape %.3f ms"
           % (name, B, d, fl / d / 1e9, wv, fl / wv / 1e9, fle / wv / 1e9, d / wv, err, w1))
+    if w42 is not None:
+        w42()
+        c = o3.asnumpy()
+        e42 = float(np.abs(a - c).max() / max(1.0, np.abs(a).max()))
+        t4 = []
+        for r in range(ROUNDS):
+            w42()
+            t = ctx.timer(); t.start()
+            for _ in range(REPS):
+                w42()
+            t.stop(); t4.append(t.elapsed_ms() / REPS)
+        m42 = float(np.median(t4))
+        f42 = 2.0 * cout * cin * 24 * B * ((H + 3) // 4) * ((W + 1) // 2)
+        print("%-8s B %2d: F(4,3)xF(2,3) %.3f ms  %5.1f TF algorithmic, %5.1f TF executed | x%.2f over F(2x2,3x3) | max diff %.1e of range"
+              % (name, B, m42, fl / m42 / 1e9, f42 / m42 / 1e9, wv / m42, e42))
 # the 5x5 stride-2 layers: direct NC8 kernel vs the Winograd kernel over the space-to-depth input (zero positions skipped / not skipped)
 for name, cin, H, W, cout in [("conv2", 64, 240, 320, 128), ("conv3", 128, 120, 160, 256)]:
     if ONLY and name not in ONLY:
