@@ -1,6 +1,6 @@
 // fp32 Winograd F(4,3) x F(2,3) — 4x2 output tiles — for the encoder's 3x3 stride-1 layers on channel-blocked activations
-// [n][C/8][h][w][8] (round 6; option "wino_tile42", off by default: see profiles/r06_wino44.md section 4 for why this tile and for
-// what it measured). Per 4-row x 2-column output tile and channel the 6x4 input patch d becomes V = B4^T d B2 (24 positions), the 3x3
+// [n][C/8][h][w][8] (round 6; an entry point of its own, NOT bound by the network: profiles/r06_wino44.md sections 4-5 say why this
+// tile, and what the kernel measured — 0.96-0.98x of the tuned F(2x2,3x3) kernel in its first, untuned form). Per 4-row x 2-column output tile and channel the 6x4 input patch d becomes V = B4^T d B2 (24 positions), the 3x3
 // kernel g becomes U = G4 g G2^T (packed once, in double), the 24 positions are 24 independent GEMMs M = U.V over the input channels,
 // and the tile is Y = A4^T M A2: 3 multiply-adds per output, input and output channel where F(2x2,3x3) needs 4 and the direct sum 9.
 // The 6-point transform of F(4,3) (interpolation points 0, +-1, +-2, inf) costs accuracy: ~3e-6 of a layer's range against ~7e-7 for
@@ -109,6 +109,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 A[6], Bv[6];
   const int ke = c8n;
 
+#ifndef W42_ABL
+#define W42_ABL 0   // dev ablations (wrong results): 1 no step barriers, 4 no pixel loads + transform + V stores in the loop, 8 no operand reads in the loop, 16 no output transform / stores, 32 no MFMAs
+#endif
 #define W42_LDS4(off) (*reinterpret_cast<f32x4*>(smem + (off)))
 #define W42_PIX(stage)                                                                                \
   {                                                                                                   \
@@ -155,18 +158,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // two positions interleaved over eight MFMA slots; X(sl) = the slot's share of the other roles
 #define W42_M2X(i0, i1, X)                                                                            \
   _Pragma("unroll") for (int sl = 0; sl < 8; ++sl) {                                                  \
-    if (sl & 1) { W42_MFMA(i1, sl >> 1) } else { W42_MFMA(i0, sl >> 1) }                              \
+    if (!(W42_ABL & 32)) { if (sl & 1) { W42_MFMA(i1, sl >> 1) } else { W42_MFMA(i0, sl >> 1) } }     \
     X(sl) __builtin_amdgcn_sched_barrier(0);                                                          \
   }
-#define W42_R2(i0, i1, SLR) { W42_RD(i0, SLR) W42_RD(i1, SLR) } __builtin_amdgcn_sched_barrier(0);
+#define W42_R2(i0, i1, SLR) if (!(W42_ABL & 8)) { W42_RD(i0, SLR) W42_RD(i1, SLR) } __builtin_amdgcn_sched_barrier(0);
 #define W42_XNONE(sl)
 // transform of stage xst_ into slot xsl_ over the eight slots of an MFMA block pair: row pass, six column passes, then the pixel loads
 // of stage xst_ + 1 (behind the row pass: the loads' registers are its inputs)
 #define W42_XA(sl)                                                                                    \
+    if (!(W42_ABL & 4)) {                                                                             \
       if (sl == 0) { W42_ROW() }                                                                      \
       if (sl >= 1 && sl <= 3) { W42_COL(sl - 1, xsl_) }                                               \
       if (sl == 4) { W42_PIX(xst_ + 1) }                                                              \
-      if (sl >= 5 && sl <= 7) { W42_COL(sl - 2, xsl_) }
+      if (sl >= 5 && sl <= 7) { W42_COL(sl - 2, xsl_) }                                               \
+    }
 
   // ---- prologue: stage 0 into slot 0 and into the operand registers, stage 1 into slot 1, pixels of stage 2 in flight
   W42_PIX(0)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rsa_ = __builtin_amdgcn_readfirstlane(ra_s0 + min((k) + 1, ke - 1) * 24576);            \
     const int xst_ = (k) + 2; constexpr int xsl_ = (SL);                                              \
     W42_M2X(0, 1, W42_XNONE)                                                                          \
-    W42_SYNC()                                                                                        \
+    if (!(W42_ABL & 1)) { W42_SYNC() }                                                                \
     W42_R2(0, 1, (SL) ^ 1)                                                                            \
     W42_M2X(2, 3, W42_XA)                                                                             \
     W42_R2(2, 3, (SL) ^ 1)                                                                            \
@@ -211,17 +216,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- output transform. acc[xi][r]: channel (r&3) + 8(r>>2) + 4 lrow of the wave's 32, tile lcol, position (xi, nu = pg).
   W42_SYNC()   // every wave is done with both slots
+  if (W42_ABL & 16) { if (acc[0][0] == 123.f && acc[5][15] == 4.f) p.out[0] = acc[3][2]; return; }
   // row direction (A4^T, 6 -> 4) on whole vectors: p = m1 + m2, q = m1 - m2, u = m3 + m4, v = m3 - m4;
   // r0 = (m0 + p) + u, r1 = q + 2 v, r2 = p + 4 u, r3 = (q + 8 v) + m5
   f32x16 rr[4];
   {
     const f32x16 pp = acc[1] + acc[2], qq = acc[1] - acc[2], uu = acc[3] + acc[4], vv = acc[3] - acc[4];
-#ifndef W42_DBG
-#define W42_DBG 0
-#endif
-    rr[0] = (W42_DBG == 1) ? pp + uu : (acc[0] + pp) + uu;
-    if (W42_DBG == 2) rr[0] = acc[0];
-    if (W42_DBG == 3) rr[0] = acc[5];
+    rr[0] = (acc[0] + pp) + uu;
     rr[1] = qq + 2.f * vv;
     rr[2] = pp + 4.f * uu;
     rr[3] = (qq + 8.f * vv) + acc[5];
